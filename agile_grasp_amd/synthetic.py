@@ -1,0 +1,173 @@
+"""Synthetic tabletop scenes for parity tests and benchmarks.
+
+The reference ships no PCD files, so the workloads are generated: a table plane plus 14 objects (upright
+cylinders, boxes, lying cylinders) sampled at 1.5 mm, kept with probability 0.8 per camera, each camera snapped to
+its own 3 mm voxel lattice exactly as ``Localization::voxelizeCloud`` leaves it
+(/root/reference/src/agile_grasp/localization.cpp:282-351: ``floor((p - min)/0.003)*0.003 + min``, de-duplicated,
+lexicographic voxel order, camera 0 block then camera 1 block).  The result is the cloud *as it enters*
+``HandSearch::findHands``: float32 xyz + camera id per point + explicit sample indices.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+# camera poses of the reference node (/root/reference/src/nodes/find_grasps.cpp:35-45)
+_BASE_TF = np.array(
+    [[0, 0.445417, 0.895323, 0.215], [1, 0, 0, -0.015], [0, 0.895323, -0.445417, 0.23], [0, 0, 0, 1]], dtype=np.float64
+)
+_SQRT_TF = np.array(
+    [
+        [0.9366, -0.0162, 0.3500, -0.2863],
+        [0.0151, 0.9999, 0.0058, 0.0058],
+        [-0.3501, -0.0002, 0.9367, 0.0554],
+        [0, 0, 0, 1],
+    ],
+    dtype=np.float64,
+)
+
+
+def camera_poses() -> tuple[np.ndarray, np.ndarray]:
+    """cam_tf_left = base_tf * sqrt_tf^-1, cam_tf_right = base_tf * sqrt_tf (find_grasps.cpp:44-45)."""
+    return _BASE_TF @ np.linalg.inv(_SQRT_TF), _BASE_TF @ _SQRT_TF
+
+
+def camera_origins() -> np.ndarray:
+    left, right = camera_poses()
+    return np.stack([left[:3, 3], right[:3, 3]]).astype(np.float64)
+
+
+@dataclasses.dataclass
+class Scene:
+    xyz: np.ndarray  # (N, 3) float32
+    cam: np.ndarray  # (N,) int32, 0 = left, 1 = right
+    cam_origins: np.ndarray  # (2, 3) float64
+    samples: np.ndarray  # (S,) int32 sorted ascending
+    seed: int
+    name: str = ""
+
+    @property
+    def n(self) -> int:
+        return int(self.xyz.shape[0])
+
+
+def _grid2(u0, u1, v0, v1, step):
+    u = np.arange(u0, u1, step)
+    v = np.arange(v0, v1, step)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    return uu.ravel(), vv.ravel()
+
+
+def _surface_points(rng: np.random.Generator, table: tuple[float, float, float, float, float], n_objects: int,
+                    step: float) -> np.ndarray:
+    """Raw surface samples (float64) of the table and the objects, before the per-camera keep/voxelisation."""
+    x0, x1, y0, y1, zt = table
+    parts = []
+    u, v = _grid2(x0, x1, y0, y1, step)
+    parts.append(np.stack([u, v, np.full_like(u, zt)], 1))
+    # object centres on a jittered grid inside the table, 12 cm margin
+    gx = int(np.ceil(np.sqrt(n_objects * (x1 - x0) / max(y1 - y0, 1e-9))))
+    gy = int(np.ceil(n_objects / gx))
+    cells = [(i, j) for i in range(gx) for j in range(gy)][:n_objects]
+    for k, (i, j) in enumerate(cells):
+        cx = x0 + 0.12 + (i + 0.5) * (x1 - x0 - 0.24) / gx + rng.uniform(-0.02, 0.02)
+        cy = y0 + 0.12 + (j + 0.5) * (y1 - y0 - 0.24) / gy + rng.uniform(-0.02, 0.02)
+        kind = k % 3
+        if kind == 0:  # upright cylinder r 2-4 cm, h 8-20 cm
+            r, h = rng.uniform(0.02, 0.04), rng.uniform(0.08, 0.20)
+            a, z = _grid2(0.0, 2 * np.pi * r, 0.0, h, step)
+            parts.append(np.stack([cx + r * np.cos(a / r), cy + r * np.sin(a / r), zt + z], 1))
+            u, v = _grid2(-r, r, -r, r, step)
+            m = u * u + v * v <= r * r
+            parts.append(np.stack([cx + u[m], cy + v[m], np.full(m.sum(), zt + h)], 1))
+        elif kind == 1:  # box 3-8 x 3-8 x 5-15 cm, rotated about z
+            lx, ly, lz = rng.uniform(0.03, 0.08), rng.uniform(0.03, 0.08), rng.uniform(0.05, 0.15)
+            th = rng.uniform(0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            faces = []
+            u, v = _grid2(-lx / 2, lx / 2, -ly / 2, ly / 2, step)
+            faces.append(np.stack([u, v, np.full_like(u, lz)], 1))
+            u, v = _grid2(-lx / 2, lx / 2, 0, lz, step)
+            faces.append(np.stack([u, np.full_like(u, -ly / 2), v], 1))
+            faces.append(np.stack([u, np.full_like(u, ly / 2), v], 1))
+            u, v = _grid2(-ly / 2, ly / 2, 0, lz, step)
+            faces.append(np.stack([np.full_like(u, -lx / 2), u, v], 1))
+            faces.append(np.stack([np.full_like(u, lx / 2), u, v], 1))
+            f = np.concatenate(faces)
+            parts.append(np.stack([cx + c * f[:, 0] - s * f[:, 1], cy + s * f[:, 0] + c * f[:, 1], zt + f[:, 2]], 1))
+        else:  # lying cylinder r 1.5-3 cm, L 10-25 cm, axis in the table plane
+            r, ln = rng.uniform(0.015, 0.03), rng.uniform(0.10, 0.25)
+            th = rng.uniform(0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            a, t = _grid2(0.0, 2 * np.pi * r, -ln / 2, ln / 2, step)
+            lx_, ly_, lz_ = t, r * np.cos(a / r), r + r * np.sin(a / r)
+            parts.append(np.stack([cx + c * lx_ - s * ly_, cy + s * lx_ + c * ly_, zt + lz_], 1))
+            u, v = _grid2(-r, r, -r, r, step)
+            m = u * u + v * v <= r * r
+            for end in (-ln / 2, ln / 2):
+                ex, ey, ez = np.full(m.sum(), end), u[m], r + v[m]
+                parts.append(np.stack([cx + c * ex - s * ey, cy + s * ex + c * ey, zt + ez], 1))
+    return np.concatenate(parts).astype(np.float64)
+
+
+def _voxelize(pts: np.ndarray, cell: float = 0.003) -> np.ndarray:
+    """Per-camera voxel snap in lexicographic voxel order (localization.cpp:282-351)."""
+    mn = pts.min(0)
+    vox = np.floor((pts - mn) / cell).astype(np.int64)
+    vox = np.unique(vox, axis=0)  # lexicographic (ix, iy, iz), like std::set<Vector3i, comparator>
+    return vox.astype(np.float64) * cell + mn
+
+
+def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, n_objects: int = 14,
+               name: str = "") -> Scene:
+    """Build a scene with exactly ``n_points`` points and ``n_samples`` sorted sample indices."""
+    rng = np.random.default_rng(seed)
+    views = 2 if two_view else 1
+    # voxel density: 1/9e-6 per m^2 per camera on flat surfaces; objects add roughly 0.023 m^2 each
+    want_area = 1.08 * n_points * 9e-6 / views
+    obj_area = 0.023 * n_objects
+    table_area = max(want_area - obj_area, 0.25 * want_area)
+    aspect = 1.3
+    lx, ly = np.sqrt(table_area * aspect), np.sqrt(table_area / aspect)
+    for _ in range(6):
+        table = (0.5, 0.5 + lx, -ly / 2, ly / 2, -0.10)
+        raw = _surface_points(np.random.default_rng(seed), table, n_objects, 0.0015)
+        clouds = []
+        crng = np.random.default_rng(seed + 7919)
+        for _cam in range(views):
+            keep = crng.random(raw.shape[0]) < 0.8
+            jit = crng.uniform(-0.0003, 0.0003, size=(int(keep.sum()), 3))
+            clouds.append(_voxelize(raw[keep] + jit))
+        total = sum(c.shape[0] for c in clouds)
+        if total >= n_points:
+            break
+        grow = np.sqrt(1.1 * n_points / total)
+        lx, ly = lx * grow, ly * grow
+    else:
+        raise RuntimeError("could not reach the requested point count")
+    xyz = np.concatenate(clouds).astype(np.float32)
+    cam = np.concatenate([np.full(c.shape[0], i, np.int32) for i, c in enumerate(clouds)])
+    if total > n_points:  # drop random points, order preserved
+        keep_idx = np.sort(rng.permutation(total)[:n_points])
+        xyz, cam = xyz[keep_idx], cam[keep_idx]
+    samples = np.sort(rng.permutation(n_points)[:n_samples]).astype(np.int32)
+    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), camera_origins(), samples, seed, name)
+
+
+# BASELINE.json configs made concrete
+def config(name: str) -> Scene:
+    if name == "C1":
+        return make_scene(50_000, 500, seed=1, two_view=False, name="C1")
+    if name in ("C2", "C3"):
+        return make_scene(300_000, 2000, seed=2, two_view=True, name=name)
+    if name == "C4":
+        return make_scene(1_000_000, 8000, seed=4, two_view=True, n_objects=48, name="C4")
+    if name.startswith("C5"):
+        k = int(name[3:]) if len(name) > 2 else 0
+        return make_scene(300_000, 2000, seed=10 + k, two_view=True, name=name)
+    if name == "tiny":
+        return make_scene(12_000, 64, seed=3, two_view=True, n_objects=3, name="tiny")
+    if name == "small":
+        return make_scene(40_000, 200, seed=5, two_view=True, n_objects=6, name="small")
+    raise KeyError(name)

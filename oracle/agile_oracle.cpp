@@ -1,0 +1,1499 @@
+/*
+ * agile_oracle.cpp -- CPU ORACLE for the agile_grasp hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see agile_oracle.h).  Dependency-free C++17 restatement of the reference's
+ * OpenMP CPU path, operation for operation, in the reference's precision (float32 points, float64
+ * arithmetic, float32 HOG/SVM).  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference; "x.cpp" = src/agile_grasp/x.cpp, "x.h" = include/agile_grasp/x.h).
+ *
+ * PARITY UNPINNED at the third-party seams (the libraries are not in the reference tree and not in this
+ * image): FLANN radius search, LAPACK dggev, Eigen::EigenSolver, OpenCV 2.4 HOGDescriptor / CvSVM.  The
+ * interpretation used at each seam is stated where it is implemented; tests/golden pins the eigen seam
+ * against scipy's LAPACK dggev.
+ *
+ * Floating-point contract: compiled with -ffp-contract=off, no -ffast-math; every sum is written in the
+ * order it is evaluated (left to right unless stated), so the HIP kernels can reproduce it bit for bit.
+ */
+#include "agile_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace
+{
+
+struct V3
+{
+  double x, y, z;
+};
+
+inline double dot3(const double* a, const double* b)
+{
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+inline void cross3(const double* a, const double* b, double* o)
+{
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a2  pcl::KdTreeFLANN<PointXYZRGBA>::radiusSearch (call sites hand_search.cpp:85,147) -- THIRD PARTY.
+ * Interpretation (FLANN 1.8 L2_Simple<float>, RadiusResultSet, sorted=true):
+ *   d2 = ((dx*dx) + dy*dy) + dz*dz in float32 with dx = q.x - p.x; keep iff d2 < (float)(r*r) (strict);
+ *   results ascending by (d2, index) -- FLANN's DistanceIndex::operator<.  The query point is included.
+ * An exact uniform grid stands in for the kd-tree (same result set, no approximation).
+ * ------------------------------------------------------------------------------------------------- */
+struct Neighbor
+{
+  float d2;
+  int32_t idx;
+};
+
+inline bool nb_less(const Neighbor& a, const Neighbor& b)
+{
+  return (a.d2 < b.d2) || ((a.d2 == b.d2) && a.idx < b.idx);
+}
+
+struct Cloud
+{
+  const float* xyz;
+  int64_t stride;
+  const int32_t* cam;
+  int64_t n;
+  inline const float* pt(int64_t i) const { return xyz + i * stride; }
+};
+
+struct GridIndex
+{
+  double cell = 0;
+  double mn[3] = { 0, 0, 0 };
+  int64_t dim[3] = { 1, 1, 1 };
+  std::vector<int64_t> start; /* CSR over cells */
+  std::vector<int32_t> items;
+
+  inline void coords(const float* p, int64_t c[3]) const
+  {
+    for (int a = 0; a < 3; a++)
+    {
+      int64_t v = (int64_t) std::floor(((double) p[a] - mn[a]) / cell);
+      c[a] = std::min(std::max(v, (int64_t) 0), dim[a] - 1);
+    }
+  }
+
+  void build(const Cloud& cl, double cell_size)
+  {
+    cell = cell_size;
+    double mx[3] = { 0, 0, 0 };
+    for (int a = 0; a < 3; a++)
+    {
+      mn[a] = 1e300;
+      mx[a] = -1e300;
+    }
+    for (int64_t i = 0; i < cl.n; i++)
+      for (int a = 0; a < 3; a++)
+      {
+        mn[a] = std::min(mn[a], (double) cl.pt(i)[a]);
+        mx[a] = std::max(mx[a], (double) cl.pt(i)[a]);
+      }
+    if (cl.n == 0)
+      for (int a = 0; a < 3; a++)
+        mn[a] = mx[a] = 0;
+    for (int a = 0; a < 3; a++)
+      dim[a] = (int64_t) std::floor((mx[a] - mn[a]) / cell) + 1;
+    /* keep the table bounded for sparse far-flung clouds */
+    while ((double) dim[0] * (double) dim[1] * (double) dim[2] > 6.4e7)
+    {
+      cell *= 2.0;
+      for (int a = 0; a < 3; a++)
+        dim[a] = (int64_t) std::floor((mx[a] - mn[a]) / cell) + 1;
+    }
+    int64_t ncell = dim[0] * dim[1] * dim[2];
+    start.assign(ncell + 1, 0);
+    std::vector<int64_t> key(cl.n);
+    for (int64_t i = 0; i < cl.n; i++)
+    {
+      int64_t c[3];
+      coords(cl.pt(i), c);
+      key[i] = (c[2] * dim[1] + c[1]) * dim[0] + c[0];
+      start[key[i] + 1]++;
+    }
+    for (int64_t k = 0; k < ncell; k++)
+      start[k + 1] += start[k];
+    items.resize(cl.n);
+    std::vector<int64_t> fill(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < cl.n; i++)
+      items[fill[key[i]]++] = (int32_t) i;
+  }
+
+  void query(const Cloud& cl, const float* q, double radius, std::vector<Neighbor>& out) const
+  {
+    out.clear();
+    const float r2 = static_cast<float>(radius * radius);
+    int64_t lo[3], hi[3];
+    for (int a = 0; a < 3; a++)
+    {
+      int64_t l = (int64_t) std::floor(((double) q[a] - radius - mn[a]) / cell) - 1;
+      int64_t h = (int64_t) std::floor(((double) q[a] + radius - mn[a]) / cell) + 1;
+      lo[a] = std::min(std::max(l, (int64_t) 0), dim[a] - 1);
+      hi[a] = std::min(std::max(h, (int64_t) 0), dim[a] - 1);
+    }
+    for (int64_t cz = lo[2]; cz <= hi[2]; cz++)
+      for (int64_t cy = lo[1]; cy <= hi[1]; cy++)
+      {
+        int64_t base = (cz * dim[1] + cy) * dim[0];
+        for (int64_t k = start[base + lo[0]]; k < start[base + hi[0] + 1]; k++)
+        {
+          const int32_t i = items[k];
+          const float* p = cl.pt(i);
+          const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+          float d2 = 0.0f;
+          d2 += dx * dx;
+          d2 += dy * dy;
+          d2 += dz * dz;
+          if (d2 < r2)
+            out.push_back(Neighbor{ d2, i });
+        }
+      }
+    std::sort(out.begin(), out.end(), nb_less);
+  }
+};
+
+/* ---------------------------------------------------------------------------------------------------
+ * glibc rand() (TYPE_3 additive feedback generator), the generator behind quadric.cpp:184-187.
+ * ------------------------------------------------------------------------------------------------- */
+struct GlibcRand
+{
+  std::vector<uint32_t> r;
+  size_t pos = 0;
+  explicit GlibcRand(uint32_t seed)
+  {
+    r.resize(344);
+    int32_t s = (int32_t) (seed == 0 ? 1u : seed);
+    r[0] = (uint32_t) s;
+    for (int i = 1; i < 31; i++)
+    {
+      int64_t hi = (int32_t) r[i - 1] / 127773;
+      int64_t lo = (int32_t) r[i - 1] % 127773;
+      int64_t word = 16807 * lo - 2836 * hi;
+      if (word < 0)
+        word += 2147483647;
+      r[i] = (uint32_t) word;
+    }
+    for (int i = 31; i < 34; i++)
+      r[i] = r[i - 31];
+    for (int i = 34; i < 344; i++)
+      r[i] = r[i - 31] + r[i - 3];
+    pos = 344;
+  }
+  int32_t next()
+  {
+    r.push_back(r[pos - 31] + r[pos - 3]);
+    uint32_t o = r[pos] >> 1;
+    pos++;
+    return (int32_t) o;
+  }
+};
+
+/* ---------------------------------------------------------------------------------------------------
+ * Cyclic Jacobi for a small symmetric matrix (row-major n x n).  Stands in for LAPACK dggev's QZ
+ * (quadric.cpp:330-363, after the reduction below) and for Eigen::EigenSolver on the symmetric 3x3
+ * (quadric.cpp:268-270).  d[j] = eigenvalue, column j of V = eigenvector.
+ * ------------------------------------------------------------------------------------------------- */
+template <int NN>
+void jacobi_sym(double A[NN][NN], double V[NN][NN], double d[NN])
+{
+  for (int i = 0; i < NN; i++)
+    for (int j = 0; j < NN; j++)
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; sweep++)
+  {
+    double off = 0.0;
+    for (int p = 0; p < NN - 1; p++)
+      for (int q = p + 1; q < NN; q++)
+        off += A[p][q] * A[p][q];
+    if (off == 0.0)
+      break;
+    for (int p = 0; p < NN - 1; p++)
+      for (int q = p + 1; q < NN; q++)
+      {
+        const double apq = A[p][q];
+        if (apq == 0.0)
+          continue;
+        const double app = A[p][p], aqq = A[q][q];
+        const double aabs = std::fabs(apq);
+        if (sweep > 3 && (std::fabs(app) + aabs == std::fabs(app)) && (std::fabs(aqq) + aabs == std::fabs(aqq)))
+        {
+          A[p][q] = 0.0;
+          A[q][p] = 0.0;
+          continue;
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        if (theta < 0.0)
+          t = -t;
+        const double c = 1.0 / std::sqrt(t * t + 1.0);
+        const double s = t * c;
+        A[p][p] = app - t * apq;
+        A[q][q] = aqq + t * apq;
+        A[p][q] = 0.0;
+        A[q][p] = 0.0;
+        for (int k = 0; k < NN; k++)
+        {
+          if (k == p || k == q)
+            continue;
+          const double akp = A[k][p], akq = A[k][q];
+          const double np_ = c * akp - s * akq;
+          const double nq_ = s * akp + c * akq;
+          A[k][p] = np_;
+          A[p][k] = np_;
+          A[k][q] = nq_;
+          A[q][k] = nq_;
+        }
+        for (int k = 0; k < NN; k++)
+        {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < NN; i++)
+    d[i] = A[i][i];
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Quadric::solveGeneralizedEigenProblem + the eigenvalue selection of fitQuadric
+ * (quadric.cpp:143-153, 330-363) -- dggev is THIRD PARTY.
+ * N's 10th row/column is identically zero, so the pencil (M,N) has exactly one infinite eigenvalue and
+ * the reference takes the smallest of "the first 9" = the smallest finite one (scipy/LAPACK places the
+ * infinite one at index 9, see tests/golden).  Eliminating the 10th unknown (v10 = -b.v9/n) gives the
+ * symmetric-definite 9x9 problem (A - b b^T/n) v = lambda N9 v, solved by Cholesky(N9) + Jacobi.
+ * The eigenvector's sign and scale are arbitrary in both solvers and cancel downstream
+ * (quadric.cpp:246-247 normalises, 294-301 re-orients).
+ * Returns false if N9 is not positive definite (degenerate neighbourhood) -- the reference would carry
+ * on with whatever dggev returned; here the sample is marked invalid and yields no hypotheses.
+ * ------------------------------------------------------------------------------------------------- */
+bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], double* lambda)
+{
+  const double n = M[9][9];
+  double S[9][9], L[9][9], Y[9][9], C[9][9];
+  if (!(n > 0.0))
+    return false;
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++)
+      S[i][j] = M[i][j] - (M[i][9] * M[j][9]) / n;
+  /* Cholesky N9 = L L^T */
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++)
+      L[i][j] = 0.0;
+  for (int j = 0; j < 9; j++)
+  {
+    double sum = N[j][j];
+    for (int k = 0; k < j; k++)
+      sum -= L[j][k] * L[j][k];
+    if (!(sum > 0.0))
+      return false;
+    const double ljj = std::sqrt(sum);
+    L[j][j] = ljj;
+    for (int i = j + 1; i < 9; i++)
+    {
+      double s2 = N[i][j];
+      for (int k = 0; k < j; k++)
+        s2 -= L[i][k] * L[j][k];
+      L[i][j] = s2 / ljj;
+    }
+  }
+  /* Y = L^-1 S */
+  for (int j = 0; j < 9; j++)
+    for (int i = 0; i < 9; i++)
+    {
+      double s2 = S[i][j];
+      for (int k = 0; k < i; k++)
+        s2 -= L[i][k] * Y[k][j];
+      Y[i][j] = s2 / L[i][i];
+    }
+  /* C = Y L^-T, lower triangle mirrored so that C is exactly symmetric */
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++)
+    {
+      double s2 = Y[i][j];
+      for (int k = 0; k < j; k++)
+        s2 -= C[i][k] * L[j][k];
+      C[i][j] = s2 / L[j][j];
+    }
+  for (int i = 0; i < 9; i++)
+    for (int j = i + 1; j < 9; j++)
+      C[i][j] = C[j][i];
+  double V[9][9], d[9];
+  jacobi_sym<9>(C, V, d);
+  int mi = 0;
+  for (int i = 1; i < 9; i++)
+    if (d[i] < d[mi])
+      mi = i;
+  /* v9 = L^-T y */
+  for (int i = 8; i >= 0; i--)
+  {
+    double s2 = V[i][mi];
+    for (int k = i + 1; k < 9; k++)
+      s2 -= L[k][i] * v[k];
+    v[i] = s2 / L[i][i];
+  }
+  double bv = 0.0;
+  for (int k = 0; k < 9; k++)
+    bv += M[k][9] * v[k];
+  v[9] = -bv / n;
+  *lambda = d[mi];
+  return true;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a3  Quadric::fitQuadric (quadric.cpp:14-157).  Neighbours in radius-search order, un-centred absolute
+ * coordinates cast float->double (29-31); M upper triangle (40-73) with the repeated entries copied
+ * (76-100), N (103-131), n on the diagonals (134,137-139), symmetrise (136,141).
+ * ------------------------------------------------------------------------------------------------- */
+void accumulate_MN(const Cloud& cl, const std::vector<Neighbor>& nb, double M[10][10], double N[10][10])
+{
+  for (int i = 0; i < 10; i++)
+    for (int j = 0; j < 10; j++)
+      M[i][j] = N[i][j] = 0.0;
+  for (size_t t = 0; t < nb.size(); t++)
+  {
+    const float* p = cl.pt(nb[t].idx);
+    if (std::isnan(p[0]))
+      continue;
+    const double x = p[0], y = p[1], z = p[2];
+    const double x2 = x * x, y2 = y * y, z2 = z * z;
+    const double xy = x * y, yz = y * z, xz = x * z;
+    M[0][0] += x2 * x2;
+    M[0][1] += x2 * y2;
+    M[0][2] += x2 * z2;
+    M[0][3] += x2 * xy;
+    M[0][4] += x2 * yz;
+    M[0][5] += x2 * xz;
+    M[0][6] += x2 * x;
+    M[0][7] += x2 * y;
+    M[0][8] += x2 * z;
+    M[0][9] += x2;
+    M[1][1] += y2 * y2;
+    M[1][2] += y2 * z2;
+    M[1][3] += y2 * xy;
+    M[1][4] += y2 * yz;
+    M[1][5] += y2 * xz;
+    M[1][6] += y2 * x;
+    M[1][7] += y2 * y;
+    M[1][8] += y2 * z;
+    M[1][9] += y2;
+    M[2][2] += z2 * z2;
+    M[2][3] += z2 * xy;
+    M[2][4] += z2 * yz;
+    M[2][5] += z2 * xz;
+    M[2][6] += z2 * x;
+    M[2][7] += z2 * y;
+    M[2][8] += z2 * z;
+    M[2][9] += z2;
+    M[3][8] += x * yz;
+    M[3][9] += xy;
+    M[4][9] += yz;
+    M[5][9] += xz;
+    M[6][9] += x;
+    M[7][9] += y;
+    M[8][9] += z;
+
+    N[0][0] += 4.0 * x2;
+    N[0][3] += 2.0 * xy;
+    N[0][5] += 2.0 * xz;
+    N[0][6] += 2.0 * x;
+    N[1][1] += 4.0 * y2;
+    N[1][3] += 2.0 * xy;
+    N[1][4] += 2.0 * yz;
+    N[1][7] += 2.0 * y;
+    N[2][2] += 4.0 * z2;
+    N[2][4] += 2.0 * yz;
+    N[2][5] += 2.0 * xz;
+    N[2][8] += 2.0 * z;
+    N[3][3] += x2 + y2;
+    N[3][4] += xz;
+    N[3][5] += yz;
+    N[3][6] += y;
+    N[3][7] += x;
+    N[4][4] += y2 + z2;
+    N[4][5] += xy;
+    N[4][7] += z;
+    N[4][8] += y;
+    N[5][5] += x2 + z2;
+    N[5][6] += z;
+    N[5][8] += x;
+  }
+  /* repeating elements in M (quadric.cpp:76-100; assigning after the loop gives the same values) */
+  M[3][3] = M[0][1];
+  M[5][5] = M[0][2];
+  M[3][5] = M[0][4];
+  M[3][6] = M[0][7];
+  M[5][6] = M[0][8];
+  M[6][6] = M[0][9];
+  M[4][4] = M[1][2];
+  M[3][4] = M[1][5];
+  M[3][7] = M[1][6];
+  M[4][7] = M[1][8];
+  M[7][7] = M[1][9];
+  M[4][5] = M[2][3];
+  M[5][8] = M[2][6];
+  M[4][8] = M[2][7];
+  M[8][8] = M[2][9];
+  M[4][6] = M[3][8];
+  M[5][7] = M[3][8];
+  M[6][7] = M[3][9];
+  M[7][8] = M[4][9];
+  M[6][8] = M[5][9];
+  const double n = (double) (int) nb.size();
+  M[9][9] = n;
+  N[6][6] = n;
+  N[7][7] = n;
+  N[8][8] = n;
+  for (int i = 0; i < 10; i++)
+    for (int j = i + 1; j < 10; j++)
+    {
+      M[j][i] = M[i][j];
+      N[j][i] = N[i][j];
+    }
+}
+
+inline double pow6(double v, int libm)
+{
+  if (libm)
+    return std::pow(v, 6.0); /* Eigen 3.2 ArrayBase::pow(6) -> std::pow(double,double) */
+  const double v2 = v * v;
+  return (v2 * v2) * v2;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a3+a4+a5  Quadric::fitQuadric -> findTaubinNormalAxis -> findAverageNormalAxis
+ * (quadric.cpp:14-157, 159-251, 263-305) for one sample.  draws = the glibc rand() values this sample
+ * consumes in ORC_NORMALS_RAND50 mode (quadric.cpp:184), or nullptr for the deterministic mode.
+ * ------------------------------------------------------------------------------------------------- */
+void fit_frame(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>& nb, const float* sample_f,
+  const int32_t* draws, orc_frame& F)
+{
+  std::memset(&F, 0, sizeof(F));
+  for (int a = 0; a < 3; a++)
+    F.sample[a] = (double) sample_f[a]; /* hand_search.cpp:95 */
+  F.n_nb = (int32_t) nb.size();
+  double M[10][10], N[10][10];
+  accumulate_MN(cl, nb, M, N);
+  double v[10], lambda = 0.0;
+  if (!solve_taubin(M, N, v, &lambda))
+  {
+    F.valid = 0;
+    return;
+  }
+  F.valid = 1;
+  F.eigenvalue = lambda;
+  for (int k = 0; k < 10; k++)
+    F.params[k] = v[k];
+  for (int k = 3; k < 6; k++)
+    F.params[k] *= 0.5; /* quadric.cpp:153 */
+
+  /* findTaubinNormalAxis (quadric.cpp:159-251) */
+  const double a = F.params[0], b = F.params[1], c = F.params[2];
+  const double d = 2.0 * F.params[3], e = 2.0 * F.params[4], f = 2.0 * F.params[5];
+  const double g = F.params[6], h = F.params[7], i9 = F.params[8];
+  const int n = (int) nb.size();
+  int k_s = n;
+  std::vector<int32_t> pick; /* neighbour slot of each subsample */
+  if (P.normals_mode == ORC_NORMALS_RAND50 && n > 50)
+  {
+    k_s = 50;
+    pick.resize(50);
+    for (int t = 0; t < 50; t++)
+      pick[t] = draws[t] % n; /* quadric.cpp:184 (no NaN in the cloud, 185-188 never loops) */
+  }
+  else
+  {
+    pick.resize(n);
+    for (int t = 0; t < n; t++)
+      pick[t] = t;
+  }
+  /* majority camera (quadric.cpp:215-226): first maximum wins */
+  double num_source[2] = { 0.0, 0.0 };
+  for (int t = 0; t < k_s; t++)
+  {
+    const int cs = cl.cam[nb[pick[t]].idx];
+    if (cs == 0)
+      num_source[0]++;
+    else if (cs == 1)
+      num_source[1]++;
+  }
+  F.majority_cam = (num_source[1] > num_source[0]) ? 1 : 0;
+
+  /* normals = normalised quadric gradient (quadric.cpp:238-247) */
+  std::vector<double> nrm(3 * (size_t) k_s);
+  for (int t = 0; t < k_s; t++)
+  {
+    const float* p = cl.pt(nb[pick[t]].idx);
+    const double x = p[0], y = p[1], z = p[2];
+    const double fx = (((2.0 * a) * x + d * y) + f * z) + g;
+    const double fy = (((2.0 * b) * y + d * x) + e * z) + h;
+    const double fz = (((2.0 * c) * z + e * y) + f * x) + i9;
+    const double mag = std::sqrt((fx * fx + fy * fy) + fz * fz);
+    nrm[3 * t + 0] = fx / mag;
+    nrm[3 * t + 1] = fy / mag;
+    nrm[3 * t + 2] = fz / mag;
+  }
+
+  /* findAverageNormalAxis (quadric.cpp:263-305) */
+  double M3[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+  for (int t = 0; t < k_s; t++)
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++)
+        M3[r][q] += nrm[3 * t + r] * nrm[3 * t + q];
+  double V3[3][3], d3[3];
+  jacobi_sym<3>(M3, V3, d3);
+  int mi = 0;
+  for (int r = 1; r < 3; r++)
+    if (d3[r] < d3[mi])
+      mi = r;
+  double axis[3] = { V3[0][mi], V3[1][mi], V3[2][mi] };
+
+  /* max_index: argmax_j sum_i (n_i . n_j)^6, first maximum wins (quadric.cpp:283-284) */
+  int max_index = 0;
+  double best = 0.0;
+  for (int j = 0; j < k_s; j++)
+  {
+    double s = 0.0;
+    for (int i = 0; i < k_s; i++)
+      s += pow6(dot3(&nrm[3 * i], &nrm[3 * j]), P.pow6_libm);
+    if (j == 0 || s > best)
+    {
+      best = s;
+      max_index = j;
+    }
+  }
+  F.max_index = max_index;
+  /* normal = normalise((I - a a^T) n_max)  (quadric.cpp:285-288) */
+  double np_[3];
+  for (int r = 0; r < 3; r++)
+  {
+    double pr[3];
+    for (int q = 0; q < 3; q++)
+      pr[q] = ((r == q) ? 1.0 : 0.0) - axis[r] * axis[q];
+    np_[r] = (pr[0] * nrm[3 * max_index + 0] + pr[1] * nrm[3 * max_index + 1]) + pr[2] * nrm[3 * max_index + 2];
+  }
+  const double nn = std::sqrt((np_[0] * np_[0] + np_[1] * np_[1]) + np_[2] * np_[2]);
+  double normal[3] = { np_[0] / nn, np_[1] / nn, np_[2] / nn };
+  double binormal[3];
+  cross3(axis, normal, binormal); /* quadric.cpp:291 */
+  double s2s[3];
+  for (int r = 0; r < 3; r++)
+    s2s[r] = F.sample[r] - P.cam_origin[F.majority_cam][r]; /* quadric.cpp:294 */
+  if (dot3(normal, s2s) > 0)
+    for (int r = 0; r < 3; r++)
+      normal[r] *= -1.0;
+  if (dot3(binormal, s2s) > 0)
+    for (int r = 0; r < 3; r++)
+      binormal[r] *= -1.0;
+  cross3(normal, binormal, axis); /* quadric.cpp:304 */
+  for (int r = 0; r < 3; r++)
+  {
+    F.normal[r] = normal[r];
+    F.axis[r] = axis[r];
+    F.binormal[r] = binormal[r];
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a10-a12  FingerHand (finger_hand.cpp:3-233), literal.
+ * ------------------------------------------------------------------------------------------------- */
+struct FingerHandO
+{
+  double fw, od, depth;
+  double back_of_hand = 0, grasp_width = 0;
+  double fs[20];
+  bool fingers[20];
+  bool hand[10];
+  const double* px = nullptr; /* points_ row 0 */
+  const double* py = nullptr; /* points_ row 1 */
+  int np = 0;
+  double bottom[2], surface[2];
+
+  FingerHandO(double finger_width, double hand_outer_diameter, double hand_depth)
+    : fw(finger_width), od(hand_outer_diameter), depth(hand_depth)
+  {
+    /* finger_hand.cpp:8-15: fs_half = LinSpaced(10, 0, od - fw) -> low + i*step (Eigen 3.2 linspaced_op) */
+    const double low = 0.0, high = od - fw;
+    const double step = (high - low) / 9.0;
+    for (int i = 0; i < 10; i++)
+    {
+      const double h = low + i * step;
+      fs[i] = (h - od) + fw;
+      fs[10 + i] = h;
+    }
+    for (int i = 0; i < 20; i++)
+      fingers[i] = false;
+    for (int i = 0; i < 10; i++)
+      hand[i] = false;
+  }
+
+  void evaluateFingers(double bite) /* finger_hand.cpp:20-98 */
+  {
+    back_of_hand = -1.0 * (depth - bite);
+    for (int i = 0; i < 20; i++)
+      fingers[i] = false;
+    std::vector<int> cropped;
+    for (int i = 0; i < np; i++)
+      if (py[i] < bite)
+      {
+        cropped.push_back(i);
+        if (py[i] < back_of_hand)
+          return;
+      }
+    const int m = 20;
+    for (int i = 0; i < m; i++)
+    {
+      int num_in_gap = 0;
+      for (size_t j = 0; j < cropped.size(); j++)
+      {
+        const double x = px[cropped[j]];
+        if (x > fs[i] && x < fs[i] + fw)
+          num_in_gap++;
+      }
+      if (num_in_gap == 0)
+      {
+        int sum = 0;
+        if (i <= m / 2)
+        {
+          for (size_t j = 0; j < cropped.size(); j++)
+            if (px[cropped[j]] > fs[i] + fw)
+              sum++;
+        }
+        else
+        {
+          for (size_t j = 0; j < cropped.size(); j++)
+            if (px[cropped[j]] < fs[i])
+              sum++;
+        }
+        if (sum > 0)
+          fingers[i] = true;
+      }
+    }
+  }
+
+  void evaluateHand() /* finger_hand.cpp:100-115 */
+  {
+    for (int i = 0; i < 10; i++)
+      hand[i] = fingers[i] && fingers[10 + i];
+  }
+
+  int handSum() const
+  {
+    int s = 0;
+    for (int i = 0; i < 10; i++)
+      s += hand[i] ? 1 : 0;
+    return s;
+  }
+
+  /* finger_hand.cpp:173-233; returns the number of successful deepen steps, *e_out = eroded index */
+  int deepenHand(double init_deepness, double max_deepness, int* e_out)
+  {
+    std::vector<int> hand_idx;
+    for (int i = 0; i < 10; i++)
+      if (hand[i])
+        hand_idx.push_back(i);
+    if (hand_idx.empty())
+      return 0;
+    const int e = hand_idx[(int) std::ceil(hand_idx.size() / 2.0) - 1];
+    *e_out = e;
+    FingerHandO new_hand = *this;
+    FingerHandO last_new_hand = new_hand;
+    int steps = 0;
+    const double deepen_step_size = 0.005;
+    for (double d = init_deepness + deepen_step_size; d <= max_deepness; d += deepen_step_size)
+    {
+      new_hand.evaluateFingers(d);
+      new_hand.evaluateHand();
+      if (!new_hand.hand[e])
+        break;
+      last_new_hand = new_hand;
+      steps++;
+    }
+    *this = last_new_hand;
+    for (int i = 0; i < 10; i++)
+      hand[i] = (i == e);
+    return steps;
+  }
+
+  void evaluateGraspParameters(double bite) /* finger_hand.cpp:117-171 */
+  {
+    double fs_sum = 0.0;
+    int hsum = 0;
+    for (int i = 0; i < 10; i++)
+    {
+      fs_sum += fs[i] * (hand[i] ? 1.0 : 0.0);
+      hsum += hand[i] ? 1 : 0;
+    }
+    const double hor_pos = (od / 2.0) + (fs_sum / hsum);
+    double ymax = py[0], ymin = py[0];
+    for (int i = 1; i < np; i++)
+    {
+      if (py[i] > ymax)
+        ymax = py[i];
+      if (py[i] < ymin)
+        ymin = py[i];
+    }
+    bottom[0] = hor_pos;
+    bottom[1] = ymax;
+    surface[0] = hor_pos;
+    surface[1] = ymin;
+    std::vector<int> hand_idx;
+    for (int i = 0; i < 10; i++)
+      if (hand[i])
+        hand_idx.push_back(i);
+    const int e = hand_idx[hand_idx.size() / 2];
+    const double left = fs[e], right = fs[10 + e];
+    double mx = -100000.0, mn = 100000.0;
+    for (int i = 0; i < np; i++)
+      if (py[i] < bite && px[i] > left && px[i] < right)
+      {
+        if (px[i] < mn)
+          mn = px[i];
+        if (px[i] > mx)
+          mx = px[i];
+      }
+    grasp_width = mx - mn;
+  }
+};
+
+inline void mat3mul(const double A[3][3], const double B[3][3], double C[3][3])
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[i][j] = (A[i][0] * B[0][j] + A[i][1] * B[1][j]) + A[i][2] * B[2][j];
+}
+
+inline void mat3vec(const double A[3][3], const double* v, double* o)
+{
+  for (int i = 0; i < 3; i++)
+    o[i] = (A[i][0] * v[0] + A[i][1] * v[1]) + A[i][2] * v[2];
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a17  Learning::convertToImage (learning.cpp:320-365) with createInstance (375-400): 80 rows x 100 cols.
+ * ------------------------------------------------------------------------------------------------- */
+void make_image(const std::vector<double>& bx, const std::vector<double>& by, bool positive_x, uint8_t* image)
+{
+  std::memset(image, 0, 8000);
+  const double HL0 = -0.05, HL1 = 0.05, VL0 = 0.0;
+  const double cell = (HL1 - HL0) / (double) 100;
+  for (size_t i = 0; i < bx.size(); i++)
+  {
+    double hx = positive_x ? (bx[i] - HL0) / cell : (-bx[i] - HL0) / cell;
+    double vy = (by[i] - VL0) / cell;
+    int hc = (int) std::floor(hx);
+    int vc = (int) std::floor(vy);
+    hc = std::min(99, std::max(0, hc));
+    vc = std::min(79, std::max(0, vc));
+    image[(80 - 1 - vc) * 100 + hc] = 255;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a7-a9,a13  HandSearch::findHands (private, hand_search.cpp:116-206) body for one sample:
+ * gather (154-160), RotatingHand ctor (rotating_hand.cpp:4-16), transformPoints (19-75),
+ * evaluateHand (78-177), Antipodal::evaluateGrasp (antipodal.cpp:12-86).
+ * normals: per-cloud-point normals (cloud_normals_, 3 doubles each) or nullptr (all zero).
+ * ------------------------------------------------------------------------------------------------- */
+struct HandOut
+{
+  orc_hypothesis h;
+  std::vector<uint8_t> image;
+};
+
+void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>& nb, const orc_frame& F,
+  const double* normals, int sample_pos, int sample_cam, bool want_images, std::vector<HandOut>& out)
+{
+  out.clear();
+  if (!F.valid)
+    return;
+  const int n = (int) nb.size();
+  float sample_f[3] = { (float) F.sample[0], (float) F.sample[1], (float) F.sample[2] }; /* hand_search.cpp:141-144 */
+  /* frame_ << normal, normal x axis, axis (rotating_hand.cpp:24-25) */
+  double fr[3][3];
+  double nxa[3];
+  cross3(F.normal, F.axis, nxa);
+  for (int r = 0; r < 3; r++)
+  {
+    fr[r][0] = F.normal[r];
+    fr[r][1] = nxa[r];
+    fr[r][2] = F.axis[r];
+  }
+  /* points_ = frame^T * centered (26), normals_ likewise (33); crop |z| < hand_height (37-51) */
+  std::vector<double> X, Y, NX, NY;
+  std::vector<int> CAMS;
+  X.reserve(n);
+  Y.reserve(n);
+  for (int j = 0; j < n; j++)
+  {
+    const float* p = cl.pt(nb[j].idx);
+    const double cx = (double) (p[0] - sample_f[0]); /* float subtraction, hand_search.cpp:157-158 */
+    const double cy = (double) (p[1] - sample_f[1]);
+    const double cz = (double) (p[2] - sample_f[2]);
+    const double tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+    const double ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+    const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
+    if (tz > -1.0 * P.hand_height && tz < P.hand_height)
+    {
+      X.push_back(tx);
+      Y.push_back(ty);
+      CAMS.push_back(cl.cam[nb[j].idx]);
+      if (normals)
+      {
+        const double* nn = normals + 3 * (size_t) nb[j].idx;
+        NX.push_back((fr[0][0] * nn[0] + fr[1][0] * nn[1]) + fr[2][0] * nn[2]);
+        NY.push_back((fr[0][1] * nn[0] + fr[1][1] * nn[1]) + fr[2][1] * nn[2]);
+      }
+    }
+  }
+  const int nc = (int) X.size();
+  double cams[2][3]; /* cams_ columns = camera origin - sample (hand_search.cpp:164-166) */
+  for (int c = 0; c < 2; c++)
+    for (int r = 0; r < 3; r++)
+      cams[c][r] = P.cam_origin[c][r] - F.sample[r];
+
+  FingerHandO finger_hand(P.finger_width, P.hand_outer_diameter, P.hand_depth);
+  std::vector<double> XR(nc), YR(nc), NXR(nc);
+  const double step = (M_PI - (-1.0 * M_PI)) / 8.0; /* LinSpaced(9, -pi, pi) (rotating_hand.cpp:14) */
+  for (int o = 0; o < 8; o++)
+  {
+    const double ang = -1.0 * M_PI + o * step;
+    const double cs = std::cos(ang), sn = std::sin(ang);
+    const double rot[3][3] = { { cs, -1.0 * sn, 0.0 }, { sn, cs, 0.0 }, { 0.0, 0.0, 1.0 } };
+    double rotT[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++)
+        rotT[r][q] = rot[q][r];
+    double T[3][3];
+    mat3mul(fr, rotT, T); /* frame_ * rot^T (rotating_hand.cpp:96,104,120-121) */
+    const double ex[3] = { 1.0, 0.0, 0.0 }, ey[3] = { 0.0, 1.0, 0.0 };
+    double approach[3], binormal[3];
+    mat3vec(T, ey, approach);
+    if (dot3(approach, cams[0]) > 0 && dot3(approach, cams[1]) > 0) /* rotating_hand.cpp:99-102 */
+      continue;
+    mat3vec(T, ex, binormal);
+    if (nc == 0)
+      continue; /* Eigen would read empty matrices; no point can make a finger true */
+    for (int j = 0; j < nc; j++)
+    {
+      /* points_rot = rot * points_ (91); the 0.0*z terms cannot change a comparison and are dropped */
+      XR[j] = rot[0][0] * X[j] + rot[0][1] * Y[j];
+      YR[j] = rot[1][0] * X[j] + rot[1][1] * Y[j];
+      if (normals)
+        NXR[j] = rot[0][0] * NX[j] + rot[0][1] * NY[j];
+    }
+    finger_hand.px = XR.data();
+    finger_hand.py = YR.data();
+    finger_hand.np = nc;
+    finger_hand.evaluateFingers(P.init_bite);
+    finger_hand.evaluateHand();
+    if (finger_hand.handSum() > 0)
+    {
+      int e = -1;
+      const int steps = finger_hand.deepenHand(P.init_bite, P.hand_depth, &e);
+      finger_hand.evaluateGraspParameters(P.init_bite);
+      double surf_l[3] = { finger_hand.surface[0], finger_hand.surface[1], 0.0 };
+      double bot_l[3] = { finger_hand.bottom[0], finger_hand.bottom[1], 0.0 };
+      double surface[3], bottom[3];
+      mat3vec(T, surf_l, surface);
+      mat3vec(T, bot_l, bottom);
+      const double box_y = finger_hand.back_of_hand + finger_hand.depth; /* rotating_hand.cpp:127 */
+      std::vector<double> bx, by;
+      int numl = 0, numr = 0, nbox = 0;
+      const double cos_thresh = std::cos(20 * M_PI / 180.0); /* antipodal.cpp:16 */
+      for (int j = 0; j < nc; j++)
+        if (YR[j] < box_y)
+        {
+          nbox++;
+          bx.push_back(XR[j] - surface[0]); /* rotating_hand.cpp:138 (world-frame offset, replicated as-is) */
+          by.push_back(YR[j] - surface[1]);
+          if (normals)
+          {
+            if (-1.0 * NXR[j] > cos_thresh)
+              numl++;
+            if (NXR[j] > cos_thresh)
+              numr++;
+          }
+        }
+      HandOut ho;
+      std::memset(&ho.h, 0, sizeof(ho.h));
+      for (int r = 0; r < 3; r++)
+      {
+        ho.h.axis[r] = F.axis[r];
+        ho.h.approach[r] = approach[r];
+        ho.h.binormal[r] = binormal[r];
+        ho.h.bottom[r] = bottom[r] + F.sample[r];   /* rotating_hand.cpp:153-154 */
+        ho.h.surface[r] = surface[r] + F.sample[r];
+      }
+      ho.h.width = finger_hand.grasp_width;
+      ho.h.sample = sample_pos;
+      ho.h.orientation = o;
+      ho.h.cam_source = sample_cam;
+      ho.h.n_in_box = nbox;
+      ho.h.valid = 1;
+      ho.h.finger_index = e;
+      ho.h.depth_index = steps;
+      /* antipodal.cpp:12-86: HALF iff numl>6 or numr>6, FULL iff both (order independent) */
+      const bool half = (numl > 6) || (numr > 6);
+      const bool full = (numl > 6) && (numr > 6);
+      ho.h.half_antipodal = (half || full) ? 1 : 0;
+      ho.h.full_antipodal = full ? 1 : 0;
+      if (want_images)
+      {
+        /* learning.cpp:375-400 + 320-365 with cam_pos = camera origins (localization.cpp:148-150) */
+        double s2c[3];
+        const int cs_i = (sample_cam == 1) ? 1 : 0;
+        for (int r = 0; r < 3; r++)
+          s2c[r] = ho.h.surface[r] - P.cam_origin[cs_i][r];
+        ho.image.resize(8000);
+        make_image(bx, by, dot3(binormal, s2c) > 0, ho.image.data());
+      }
+      out.push_back(std::move(ho));
+    }
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * a18  cv::HOGDescriptor::compute -- THIRD PARTY (OpenCV 2.4 modules/objdetect/src/hog.cpp), restated:
+ * computeGradient (gamma sqrt LUT, BORDER_REFLECT_101, fastAtan2 polynomial, 9 unsigned bins with linear
+ * bin interpolation), HOGCache::init (Gaussian sigma 4, cell bilinear weights, count1/2/4 pixel groups),
+ * getBlock (sequential float accumulation in pixData order), normalizeBlockHistogram (L2-Hys 0.2).
+ * Call site learning.cpp:194-195,220: winSize 64x64, winStride 32x32, padding 0 -> windows at x=0,32.
+ * ------------------------------------------------------------------------------------------------- */
+struct HogTables
+{
+  struct PixData
+  {
+    int gradOfs, qangleOfs;
+    int histOfs[4];
+    float histWeights[4];
+    float gradWeight;
+  };
+  std::vector<PixData> pix;
+  int count1 = 0, count2 = 0, count4 = 0;
+  HogTables()
+  {
+    const int bs = 16, cellsz = 8, ncell = 2, nbins = 9, raw = 256;
+    const int W = 100; /* grad.cols */
+    float weights[16][16];
+    const float sigma = 4.0f; /* winSigma=-1 -> (blockSize.w+blockSize.h)/8 */
+    const float scale = 1.f / (sigma * sigma * 2);
+    for (int i = 0; i < bs; i++)
+      for (int j = 0; j < bs; j++)
+      {
+        const float di = i - bs * 0.5f, dj = j - bs * 0.5f;
+        weights[i][j] = std::exp(-(di * di + dj * dj) * scale);
+      }
+    std::vector<PixData> tmp(raw * 3);
+    int c1 = 0, c2 = 0, c4 = 0;
+    for (int j = 0; j < bs; j++)
+      for (int i = 0; i < bs; i++)
+      {
+        PixData* data = nullptr;
+        float cellX = (j + 0.5f) / cellsz - 0.5f;
+        float cellY = (i + 0.5f) / cellsz - 0.5f;
+        int icellX0 = (int) std::floor(cellX), icellY0 = (int) std::floor(cellY);
+        int icellX1 = icellX0 + 1, icellY1 = icellY0 + 1;
+        cellX -= icellX0;
+        cellY -= icellY0;
+        if ((unsigned) icellX0 < (unsigned) ncell && (unsigned) icellX1 < (unsigned) ncell)
+        {
+          if ((unsigned) icellY0 < (unsigned) ncell && (unsigned) icellY1 < (unsigned) ncell)
+          {
+            data = &tmp[raw * 2 + (c4++)];
+            data->histOfs[0] = (icellX0 * ncell + icellY0) * nbins;
+            data->histWeights[0] = (1.f - cellX) * (1.f - cellY);
+            data->histOfs[1] = (icellX1 * ncell + icellY0) * nbins;
+            data->histWeights[1] = cellX * (1.f - cellY);
+            data->histOfs[2] = (icellX0 * ncell + icellY1) * nbins;
+            data->histWeights[2] = (1.f - cellX) * cellY;
+            data->histOfs[3] = (icellX1 * ncell + icellY1) * nbins;
+            data->histWeights[3] = cellX * cellY;
+          }
+          else
+          {
+            data = &tmp[raw + (c2++)];
+            if ((unsigned) icellY0 < (unsigned) ncell)
+            {
+              icellY1 = icellY0;
+              cellY = 1.f - cellY;
+            }
+            data->histOfs[0] = (icellX0 * ncell + icellY1) * nbins;
+            data->histWeights[0] = (1.f - cellX) * cellY;
+            data->histOfs[1] = (icellX1 * ncell + icellY1) * nbins;
+            data->histWeights[1] = cellX * cellY;
+            data->histOfs[2] = data->histOfs[3] = 0;
+            data->histWeights[2] = data->histWeights[3] = 0;
+          }
+        }
+        else
+        {
+          if ((unsigned) icellX0 < (unsigned) ncell)
+          {
+            icellX1 = icellX0;
+            cellX = 1.f - cellX;
+          }
+          if ((unsigned) icellY0 < (unsigned) ncell && (unsigned) icellY1 < (unsigned) ncell)
+          {
+            data = &tmp[raw + (c2++)];
+            data->histOfs[0] = (icellX1 * ncell + icellY0) * nbins;
+            data->histWeights[0] = cellX * (1.f - cellY);
+            data->histOfs[1] = (icellX1 * ncell + icellY1) * nbins;
+            data->histWeights[1] = cellX * cellY;
+            data->histOfs[2] = data->histOfs[3] = 0;
+            data->histWeights[2] = data->histWeights[3] = 0;
+          }
+          else
+          {
+            data = &tmp[c1++];
+            if ((unsigned) icellY0 < (unsigned) ncell)
+            {
+              icellY1 = icellY0;
+              cellY = 1.f - cellY;
+            }
+            data->histOfs[0] = (icellX1 * ncell + icellY1) * nbins;
+            data->histWeights[0] = cellX * cellY;
+            data->histOfs[1] = data->histOfs[2] = data->histOfs[3] = 0;
+            data->histWeights[1] = data->histWeights[2] = data->histWeights[3] = 0;
+          }
+        }
+        data->gradOfs = (W * i + j) * 2;
+        data->qangleOfs = (W * i + j) * 2;
+        data->gradWeight = weights[i][j];
+      }
+    pix.resize(raw);
+    for (int k = 0; k < c1; k++)
+      pix[k] = tmp[k];
+    for (int k = 0; k < c2; k++)
+      pix[k + c1] = tmp[k + raw];
+    for (int k = 0; k < c4; k++)
+      pix[k + c1 + c2] = tmp[k + raw * 2];
+    count1 = c1;
+    count2 = c1 + c2;
+    count4 = c1 + c2 + c4;
+  }
+};
+
+const HogTables& hog_tables()
+{
+  static HogTables t;
+  return t;
+}
+
+inline int border101(int p, int len)
+{
+  if (p < 0)
+    return -p;
+  if (p >= len)
+    return 2 * len - 2 - p;
+  return p;
+}
+
+inline float fast_atan2_deg(float y, float x)
+{
+  /* OpenCV 2.4 modules/core/src/mathfuncs.cpp FastAtan2_32f (scalar tail) */
+  const float sc = (float) (180 / M_PI);
+  const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc;
+  const float p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
+  const float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay)
+  {
+    c = ay / (ax + (float) 2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  else
+  {
+    c = ax / (ay + (float) 2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0)
+    a = 180.f - a;
+  if (y < 0)
+    a = 360.f - a;
+  return a;
+}
+
+void hog_compute(const uint8_t* img, float* desc)
+{
+  const int W = 100, H = 80, nbins = 9;
+  const HogTables& T = hog_tables();
+  std::vector<float> grad((size_t) W * H * 2);
+  std::vector<uint8_t> qangle((size_t) W * H * 2);
+  float lut[256];
+  for (int i = 0; i < 256; i++)
+    lut[i] = std::sqrt((float) i); /* gammaCorrection = true */
+  const float angleScale = (float) (nbins / M_PI);
+  const float rad = (float) (M_PI / 180);
+  for (int y = 0; y < H; y++)
+  {
+    const uint8_t* cur = img + W * border101(y, H);
+    const uint8_t* prev = img + W * border101(y - 1, H);
+    const uint8_t* next = img + W * border101(y + 1, H);
+    for (int x = 0; x < W; x++)
+    {
+      const int x1 = border101(x, W);
+      const float dx = (float) (lut[cur[border101(x + 1, W)]] - lut[cur[border101(x - 1, W)]]);
+      const float dy = (float) (lut[next[x1]] - lut[prev[x1]]);
+      const float mag = std::sqrt(dx * dx + dy * dy);
+      float angle = (float) (fast_atan2_deg(dy, dx) * rad);
+      angle = angle * angleScale - 0.5f;
+      int hidx = (int) std::floor(angle);
+      angle -= hidx;
+      grad[(y * W + x) * 2] = mag * (1.f - angle);
+      grad[(y * W + x) * 2 + 1] = mag * angle;
+      if (hidx < 0)
+        hidx += nbins;
+      else if (hidx >= nbins)
+        hidx -= nbins;
+      qangle[(y * W + x) * 2] = (uint8_t) hidx;
+      hidx++;
+      hidx &= hidx < nbins ? -1 : 0;
+      qangle[(y * W + x) * 2 + 1] = (uint8_t) hidx;
+    }
+  }
+  const int nbx = 7, nby = 7, bhs = 36;
+  for (int win = 0; win < 2; win++)
+  {
+    const int wx = win * 32, wy = 0;
+    for (int j = 0; j < nbx; j++)
+      for (int i = 0; i < nby; i++)
+      {
+        float* hist = desc + win * 1764 + (j * nby + i) * bhs;
+        const int ptx = wx + j * 8, pty = wy + i * 8;
+        const float* gradPtr = grad.data() + ((size_t) pty * W + ptx) * 2;
+        const uint8_t* qPtr = qangle.data() + ((size_t) pty * W + ptx) * 2;
+        for (int k = 0; k < bhs; k++)
+          hist[k] = 0.f;
+        int k = 0;
+        for (; k < T.count4; k++)
+        {
+          const HogTables::PixData& pk = T.pix[k];
+          const float a0 = gradPtr[pk.gradOfs], a1 = gradPtr[pk.gradOfs + 1];
+          const int h0 = qPtr[pk.qangleOfs], h1 = qPtr[pk.qangleOfs + 1];
+          const int ncontrib = (k < T.count1) ? 1 : (k < T.count2 ? 2 : 4);
+          for (int cidx = 0; cidx < ncontrib; cidx++)
+          {
+            float* hh = hist + pk.histOfs[cidx];
+            const float w = pk.gradWeight * pk.histWeights[cidx];
+            const float t0 = hh[h0] + a0 * w;
+            const float t1 = hh[h1] + a1 * w;
+            hh[h0] = t0;
+            hh[h1] = t1;
+          }
+        }
+        /* normalizeBlockHistogram */
+        float sum = 0;
+        for (k = 0; k < bhs; k++)
+          sum += hist[k] * hist[k];
+        float scale = 1.f / (std::sqrt(sum) + bhs * 0.1f);
+        const float thresh = 0.2f;
+        sum = 0;
+        for (k = 0; k < bhs; k++)
+        {
+          hist[k] = std::min(hist[k] * scale, thresh);
+          sum += hist[k] * hist[k];
+        }
+        scale = 1.f / (std::sqrt(sum) + 1e-3f);
+        for (k = 0; k < bhs; k++)
+          hist[k] *= scale;
+      }
+  }
+}
+
+/* a19  CvSVM::predict, linear kernel, 1 support vector -- THIRD PARTY (OpenCV 2.4 modules/ml/src/svm.cpp):
+ * calc_non_rbf_base: float products, 4 summed in float, accumulated in double; result stored as float;
+ * sum = -rho + alpha*that; class_labels[sum > 0 ? 0 : 1]; the reference keeps prediction == 1
+ * (learning.cpp:225-227), i.e. sum <= 0. */
+int svm_keep(const float* desc, const float* w, int n_w, double rho, double* sum_out)
+{
+  double s = 0;
+  int k = 0;
+  for (; k <= n_w - 4; k += 4)
+    s += w[k] * desc[k] + w[k + 1] * desc[k + 1] + w[k + 2] * desc[k + 2] + w[k + 3] * desc[k + 3];
+  for (; k < n_w; k++)
+    s += w[k] * desc[k];
+  const float res = (float) (s * 1.0 + 0.0);
+  const double sum = -rho + 1.0 * res;
+  if (sum_out)
+    *sum_out = sum;
+  return (sum > 0) ? 0 : 1;
+}
+
+struct Searcher
+{
+  Cloud cl;
+  GridIndex g_taubin, g_hands, g_normals;
+};
+
+void sample_point(const Cloud& cl, int32_t idx, float q[3])
+{
+  q[0] = cl.pt(idx)[0];
+  q[1] = cl.pt(idx)[1];
+  q[2] = cl.pt(idx)[2];
+}
+
+/* HandSearch::findQuadrics (hand_search.cpp:65-113): OMP loop A. */
+void fit_frames_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, double radius,
+  const int32_t* sample_idx, int64_t S, orc_frame* frames, GlibcRand* rng)
+{
+  /* RAND50: the reference consumes rand() in loop order on one thread; reproduce that order by assigning
+   * each sample its 50 draws up front (needs the neighbour counts first). */
+  std::vector<int32_t> draws;
+  std::vector<int64_t> draw_ofs(S, -1);
+  if (P.normals_mode == ORC_NORMALS_RAND50)
+  {
+    std::vector<int32_t> counts(S);
+#pragma omp parallel for num_threads(P.num_threads) schedule(static)
+    for (int64_t i = 0; i < S; i++)
+    {
+      std::vector<Neighbor> nb;
+      float q[3];
+      sample_point(cl, sample_idx[i], q);
+      grid.query(cl, q, radius, nb);
+      counts[i] = (int32_t) nb.size();
+    }
+    int64_t total = 0;
+    for (int64_t i = 0; i < S; i++)
+      if (counts[i] > 50)
+      {
+        draw_ofs[i] = total;
+        total += 50;
+      }
+    draws.resize(total);
+    for (int64_t k = 0; k < total; k++)
+      draws[k] = rng->next();
+  }
+#pragma omp parallel for num_threads(P.num_threads) schedule(static)
+  for (int64_t i = 0; i < S; i++)
+  {
+    std::vector<Neighbor> nb;
+    float q[3];
+    sample_point(cl, sample_idx[i], q);
+    grid.query(cl, q, radius, nb);
+    fit_frame(P, cl, nb, q, draw_ofs[i] >= 0 ? &draws[draw_ofs[i]] : nullptr, frames[i]);
+  }
+}
+
+int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, const int32_t* sample_idx, int64_t S,
+  const orc_frame* frames, const double* normals, orc_hypothesis* out, int64_t cap, int64_t* n_out, int32_t* nh_out,
+  uint8_t* images_out)
+{
+  std::vector<std::vector<HandOut>> lists(S);
+#pragma omp parallel for num_threads(P.num_threads) schedule(static)
+  for (int64_t i = 0; i < S; i++)
+  {
+    std::vector<Neighbor> nb;
+    float q[3] = { (float) frames[i].sample[0], (float) frames[i].sample[1], (float) frames[i].sample[2] };
+    grid.query(cl, q, P.nn_radius_hands, nb);
+    if (nh_out)
+      nh_out[i] = (int32_t) nb.size();
+    /* hands_cam_source(i) = pts_cam_source(indices[i]) (hand_search.cpp:40-42; defined so for explicit indices) */
+    hands_for_sample(P, cl, nb, frames[i], normals, (int) i, cl.cam[sample_idx[i]], images_out != nullptr, lists[i]);
+  }
+  int64_t k = 0;
+  for (int64_t i = 0; i < S; i++) /* concatenation, hand_search.cpp:194-200 */
+    for (size_t j = 0; j < lists[i].size(); j++)
+    {
+      if (k < cap)
+      {
+        out[k] = lists[i][j].h;
+        if (images_out)
+          std::memcpy(images_out + k * 8000, lists[i][j].image.data(), 8000);
+      }
+      k++;
+    }
+  *n_out = k;
+  return (k <= cap) ? 0 : -2;
+}
+
+} // namespace
+
+extern "C" {
+
+int64_t orc_radius_search(const float* xyz, int64_t stride_floats, int64_t n, const float q[3], double radius,
+  int32_t* idx_out, float* d2_out, int64_t cap)
+{
+  Cloud cl{ xyz, stride_floats, nullptr, n };
+  GridIndex g;
+  g.build(cl, radius);
+  std::vector<Neighbor> nb;
+  g.query(cl, q, radius, nb);
+  for (int64_t i = 0; i < (int64_t) nb.size() && i < cap; i++)
+  {
+    idx_out[i] = nb[i].idx;
+    d2_out[i] = nb[i].d2;
+  }
+  return (int64_t) nb.size();
+}
+
+int orc_fit_frames(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, double radius, orc_frame* frames_out)
+{
+  Cloud cl{ xyz, stride_floats, cam, n };
+  GridIndex g;
+  g.build(cl, radius);
+  GlibcRand rng(p->rand_seed);
+  fit_frames_impl(*p, cl, g, radius, sample_idx, n_samples, frames_out, &rng);
+  return 0;
+}
+
+int orc_find_hands(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal, orc_hypothesis* out, int64_t cap,
+  int64_t* n_out, orc_frame* frames_out, int32_t* nh_out, uint8_t* images_out)
+{
+  Cloud cl{ xyz, stride_floats, cam, n };
+  GridIndex g_t, g_h;
+  g_t.build(cl, p->nn_radius_taubin);
+  g_h.build(cl, p->nn_radius_hands);
+  GlibcRand rng(p->rand_seed);
+  std::vector<double> normals;
+  if (calculates_antipodal)
+  {
+    /* hand_search.cpp:17-26: findQuadrics over ALL points with r = 0.01; cloud_normals_.col(i) = normal */
+    GridIndex g_n;
+    g_n.build(cl, p->nn_radius_normals);
+    std::vector<int32_t> all(n);
+    for (int64_t i = 0; i < n; i++)
+      all[i] = (int32_t) i;
+    std::vector<orc_frame> fr(n);
+    fit_frames_impl(*p, cl, g_n, p->nn_radius_normals, all.data(), n, fr.data(), &rng);
+    normals.assign(3 * (size_t) n, 0.0);
+    for (int64_t i = 0; i < n; i++)
+      if (fr[i].valid)
+        for (int r = 0; r < 3; r++)
+          normals[3 * i + r] = fr[i].normal[r];
+  }
+  std::vector<orc_frame> frames(n_samples);
+  fit_frames_impl(*p, cl, g_t, p->nn_radius_taubin, sample_idx, n_samples, frames.data(), &rng);
+  if (calculates_antipodal)
+    for (int64_t i = 0; i < n_samples; i++) /* hand_search.cpp:102 also runs for the sample pass */
+      if (frames[i].valid)
+        for (int r = 0; r < 3; r++)
+          normals[3 * (size_t) sample_idx[i] + r] = frames[i].normal[r];
+  if (frames_out)
+    std::memcpy(frames_out, frames.data(), sizeof(orc_frame) * n_samples);
+  return hands_impl(*p, cl, g_h, sample_idx, n_samples, frames.data(), calculates_antipodal ? normals.data() : nullptr,
+    out, cap, n_out, nh_out, images_out);
+}
+
+int orc_hands_from_frames(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam,
+  int64_t n, const int32_t* sample_idx, int64_t n_samples, const orc_frame* frames, const double* normals,
+  orc_hypothesis* out, int64_t cap, int64_t* n_out, int32_t* nh_out, uint8_t* images_out)
+{
+  Cloud cl{ xyz, stride_floats, cam, n };
+  GridIndex g_h;
+  g_h.build(cl, p->nn_radius_hands);
+  return hands_impl(*p, cl, g_h, sample_idx, n_samples, frames, normals, out, cap, n_out, nh_out, images_out);
+}
+
+int orc_hog(const uint8_t* image, float* desc_out)
+{
+  hog_compute(image, desc_out);
+  return 0;
+}
+
+int orc_svm_keep(const float* desc, const float* weights, int32_t n_w, double rho, double* sum_out)
+{
+  return svm_keep(desc, weights, n_w, rho, sum_out);
+}
+
+int orc_classify(const uint8_t* images, int64_t n_hyp, const float* weights, int32_t n_w, double rho,
+  uint8_t* keep_out, double* sum_out, int num_threads)
+{
+  if (n_w != 3528)
+    return -1;
+  hog_tables();
+#pragma omp parallel for num_threads(num_threads) schedule(static) /* learning.cpp:198-201, OMP loop C */
+  for (int64_t i = 0; i < n_hyp; i++)
+  {
+    float desc[3528];
+    hog_compute(images + i * 8000, desc);
+    double s = 0;
+    keep_out[i] = (uint8_t) svm_keep(desc, weights, n_w, rho, &s);
+    if (sum_out)
+      sum_out[i] = s;
+  }
+  return 0;
+}
+
+int orc_load_svm(const char* path, float* weights_out, int32_t cap, double* rho_out)
+{
+  FILE* f = std::fopen(path, "rb");
+  if (!f)
+    return -1;
+  std::string txt;
+  char buf[4096];
+  size_t r;
+  while ((r = std::fread(buf, 1, sizeof(buf), f)) > 0)
+    txt.append(buf, r);
+  std::fclose(f);
+  size_t sv = txt.find("support_vectors:");
+  size_t df = txt.find("decision_functions:");
+  if (sv == std::string::npos || df == std::string::npos)
+    return -2;
+  size_t lb = txt.find('[', sv);
+  size_t rb = txt.find(']', lb);
+  if (lb == std::string::npos || rb == std::string::npos || rb > df)
+    return -2;
+  int32_t n = 0;
+  const char* s = txt.c_str() + lb + 1;
+  const char* end = txt.c_str() + rb;
+  while (s < end)
+  {
+    char* e2 = nullptr;
+    double v = std::strtod(s, &e2);
+    if (e2 == s)
+    {
+      s++;
+      continue;
+    }
+    if (n < cap)
+      weights_out[n] = (float) v;
+    n++;
+    s = e2;
+  }
+  size_t rp = txt.find("rho:", df);
+  if (rp == std::string::npos)
+    return -2;
+  *rho_out = std::strtod(txt.c_str() + rp + 4, nullptr);
+  return n;
+}
+
+void orc_glibc_rand(uint32_t seed, int32_t* out, int64_t count)
+{
+  GlibcRand g(seed);
+  for (int64_t i = 0; i < count; i++)
+    out[i] = g.next();
+}
+
+int orc_solve_taubin(const double* M, const double* N, double* v_out, double* lambda_out)
+{
+  double Mm[10][10], Nm[10][10];
+  for (int i = 0; i < 10; i++)
+    for (int j = 0; j < 10; j++)
+    {
+      Mm[i][j] = M[i * 10 + j];
+      Nm[i][j] = N[i * 10 + j];
+    }
+  return solve_taubin(Mm, Nm, v_out, lambda_out) ? 0 : -1;
+}
+
+} // extern "C"

@@ -1,0 +1,162 @@
+"""Independent numpy transcription of the reference's hand-evaluation logic, used ONLY to cross-check the C++ oracle.
+
+Second implementation written line by line from /root/reference/src/agile_grasp/finger_hand.cpp (3-233),
+rotating_hand.cpp (78-177), antipodal.cpp (12-86) and learning.cpp (320-365).  It is self-generated (the reference
+pins no numbers), so agreement with the oracle shows two independent readings of the source
+coincide; it is not a reference-pinned golden.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+class FingerHand:
+    def __init__(self, finger_width, hand_outer_diameter, hand_depth):
+        self.fw, self.od, self.depth = finger_width, hand_outer_diameter, hand_depth
+        n = 10
+        low, high = 0.0, hand_outer_diameter - finger_width
+        step = (high - low) / (n - 1)
+        fs_half = np.array([low + i * step for i in range(n)])
+        self.fs = np.concatenate([(fs_half - hand_outer_diameter) + finger_width, fs_half])
+        self.fingers = np.zeros(2 * n, bool)
+        self.hand = np.zeros(n, bool)
+        self.back_of_hand = 0.0
+        self.pts = None
+
+    def copy(self):
+        o = FingerHand.__new__(FingerHand)
+        o.__dict__.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self.__dict__.items()})
+        return o
+
+    def evaluate_fingers(self, bite):
+        self.back_of_hand = -1.0 * (self.depth - bite)
+        self.fingers[:] = False
+        cropped = []
+        for i in range(self.pts.shape[1]):
+            if self.pts[1, i] < bite:
+                cropped.append(i)
+                if self.pts[1, i] < self.back_of_hand:
+                    return
+        cp = self.pts[:, cropped]
+        m = self.fs.size
+        for i in range(m):
+            num_in_gap = int(np.count_nonzero((cp[0] > self.fs[i]) & (cp[0] < self.fs[i] + self.fw)))
+            if num_in_gap == 0:
+                if i <= m // 2:
+                    s = int(np.count_nonzero(cp[0] > self.fs[i] + self.fw))
+                else:
+                    s = int(np.count_nonzero(cp[0] < self.fs[i]))
+                if s > 0:
+                    self.fingers[i] = True
+
+    def evaluate_hand(self):
+        n = self.fingers.size // 2
+        self.hand = self.fingers[:n] & self.fingers[n:]
+
+    def deepen_hand(self, init_deepness, max_deepness):
+        hand_idx = [i for i in range(self.hand.size) if self.hand[i]]
+        if not hand_idx:
+            return None, 0
+        e = hand_idx[int(math.ceil(len(hand_idx) / 2.0)) - 1]
+        new_hand = self.copy()
+        last = new_hand.copy()
+        d = init_deepness + 0.005
+        steps = 0
+        while d <= max_deepness:
+            new_hand.evaluate_fingers(d)
+            new_hand.evaluate_hand()
+            if not new_hand.hand[e]:
+                break
+            last = new_hand.copy()
+            steps += 1
+            d += 0.005
+        self.__dict__.update(last.__dict__)
+        self.hand = np.zeros(10, bool)
+        self.hand[e] = True
+        return e, steps
+
+    def grasp_parameters(self, bite):
+        fs_sum = 0.0
+        for i in range(self.hand.size):
+            fs_sum += self.fs[i] * float(self.hand[i])
+        hor_pos = (self.od / 2.0) + (fs_sum / int(self.hand.sum()))
+        bottom = (hor_pos, self.pts[1].max())
+        surface = (hor_pos, self.pts[1].min())
+        hand_idx = [i for i in range(self.hand.size) if self.hand[i]]
+        e = hand_idx[len(hand_idx) // 2]
+        left, right = self.fs[e], self.fs[self.hand.size + e]
+        mx, mn = -100000.0, 100000.0
+        sel = (self.pts[1] < bite) & (self.pts[0] > left) & (self.pts[0] < right)
+        if sel.any():
+            mn = min(mn, self.pts[0][sel].min())
+            mx = max(mx, self.pts[0][sel].max())
+        return bottom, surface, mx - mn
+
+
+def evaluate_hand(points, normals, cam_ids, frame, cams, geom, init_bite, sample):
+    """rotating_hand.cpp:78-177 on already transformed+cropped points (3 x n), normals (3 x n), frame (3x3)."""
+    fw, od, depth = geom
+    out = []
+    angles = [-1.0 * math.pi + k * ((math.pi - (-1.0 * math.pi)) / 8.0) for k in range(8)]
+    fh = FingerHand(fw, od, depth)
+    for o, ang in enumerate(angles):
+        c, s = math.cos(ang), math.sin(ang)
+        rot = np.array([[c, -1.0 * s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        # sequential left-to-right 3-term sums, like the oracle's stated order
+        pr = np.empty_like(points)
+        nr = np.empty_like(normals)
+        for r in range(2):
+            pr[r] = rot[r, 0] * points[0] + rot[r, 1] * points[1]
+            nr[r] = rot[r, 0] * normals[0] + rot[r, 1] * normals[1]
+        pr[2], nr[2] = points[2], normals[2]
+        T = np.empty((3, 3))
+        for i in range(3):
+            for j in range(3):
+                T[i, j] = (frame[i, 0] * rot[j, 0] + frame[i, 1] * rot[j, 1]) + frame[i, 2] * rot[j, 2]
+        approach = np.array([(T[i, 0] * 0.0 + T[i, 1] * 1.0) + T[i, 2] * 0.0 for i in range(3)])
+
+        def dot(a, b):
+            return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+
+        if dot(approach, cams[:, 0]) > 0 and dot(approach, cams[:, 1]) > 0:
+            continue
+        binormal = np.array([(T[i, 0] * 1.0 + T[i, 1] * 0.0) + T[i, 2] * 0.0 for i in range(3)])
+        if pr.shape[1] == 0:
+            continue
+        fh.pts = pr
+        fh.evaluate_fingers(init_bite)
+        fh.evaluate_hand()
+        if fh.hand.sum() > 0:
+            e, steps = fh.deepen_hand(init_bite, depth)
+            bottom2, surface2, width = fh.grasp_parameters(init_bite)
+            surface = np.array([(T[i, 0] * surface2[0] + T[i, 1] * surface2[1]) + T[i, 2] * 0.0 for i in range(3)])
+            bottom = np.array([(T[i, 0] * bottom2[0] + T[i, 1] * bottom2[1]) + T[i, 2] * 0.0 for i in range(3)])
+            box = pr[1] < fh.back_of_hand + depth
+            pib = pr[:, box] - surface[:, None]
+            nib = nr[:, box]
+            cos_t = math.cos(20 * math.pi / 180.0)
+            numl = int(np.count_nonzero(-1.0 * nib[0] > cos_t))
+            numr = int(np.count_nonzero(nib[0] > cos_t))
+            out.append(dict(orientation=o, approach=approach, binormal=binormal, surface=surface + sample,
+                            bottom=bottom + sample, width=width, n_in_box=int(box.sum()), finger_index=e,
+                            depth_index=steps, half=(numl > 6 or numr > 6), full=(numl > 6 and numr > 6),
+                            points_in_box=pib))
+    return out
+
+
+def convert_to_image(pts, binormal, source_to_center):
+    """learning.cpp:320-365 (80 rows x 100 cols)."""
+    cell = (0.05 - (-0.05)) / 100.0
+    if float((binormal[0] * source_to_center[0] + binormal[1] * source_to_center[1])
+             + binormal[2] * source_to_center[2]) > 0:
+        hc = np.floor((pts[0] - (-0.05)) / cell).astype(np.int64)
+    else:
+        hc = np.floor((-pts[0] - (-0.05)) / cell).astype(np.int64)
+    vc = np.floor((pts[1] - 0.0) / cell).astype(np.int64)
+    img = np.zeros((80, 100), np.uint8)
+    hc = np.minimum(99, np.maximum(0, hc))
+    vc = np.minimum(79, np.maximum(0, vc))
+    img[79 - vc, hc] = 255
+    return img
