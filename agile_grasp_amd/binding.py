@@ -1,0 +1,262 @@
+"""ctypes binding of libagile_grasp_hip.so (the C ABI of include/agh.h) for tests and bench.py.
+
+The product is the shared library; this module only marshals numpy / torch buffers into it.  There is no CPU
+fallback: if the library or a gfx950 device is missing, loading or ``Context()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NORMALS_DETERMINISTIC = 0
+NORMALS_RAND50 = 1
+
+
+class AghParams(C.Structure):
+    _fields_ = [
+        ("finger_width", C.c_double),
+        ("hand_outer_diameter", C.c_double),
+        ("hand_depth", C.c_double),
+        ("hand_height", C.c_double),
+        ("init_bite", C.c_double),
+        ("nn_radius_taubin", C.c_double),
+        ("nn_radius_hands", C.c_double),
+        ("nn_radius_normals", C.c_double),
+        ("cam_origin", (C.c_double * 3) * 2),
+        ("normals_mode", C.c_int32),
+        ("rand_seed", C.c_uint32),
+        ("device", C.c_int32),
+        ("profile", C.c_int32),
+    ]
+
+
+class AghTiming(C.Structure):
+    _fields_ = [("ms", C.c_float * 16), ("name", C.c_char_p * 16), ("n", C.c_int32), ("total_ms", C.c_float)]
+
+
+HYP_DTYPE = np.dtype(
+    [
+        ("axis", "<f8", 3),
+        ("approach", "<f8", 3),
+        ("binormal", "<f8", 3),
+        ("bottom", "<f8", 3),
+        ("surface", "<f8", 3),
+        ("width", "<f8"),
+        ("sample", "<i4"),
+        ("orientation", "<i4"),
+        ("cam_source", "<i4"),
+        ("n_in_box", "<i4"),
+        ("half_antipodal", "u1"),
+        ("full_antipodal", "u1"),
+        ("svm_keep", "u1"),
+        ("valid", "u1"),
+        ("finger_index", "<i4"),
+        ("depth_index", "<i4"),
+        ("pad_", "<i4"),
+    ]
+)
+FRAME_DTYPE = np.dtype(
+    [
+        ("sample", "<f8", 3),
+        ("normal", "<f8", 3),
+        ("axis", "<f8", 3),
+        ("binormal", "<f8", 3),
+        ("params", "<f8", 10),
+        ("eigenvalue", "<f8"),
+        ("n_nb", "<i4"),
+        ("majority_cam", "<i4"),
+        ("max_index", "<i4"),
+        ("valid", "<i4"),
+    ]
+)
+assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200
+
+EXPORTS = [
+    "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device",
+    "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
+    "agh_get_normals", "agh_get_timing", "agh_synchronize", "agh_selftest_math",
+]
+
+
+class AghError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"agh error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libagile_grasp_hip.so")
+
+
+def load_library():
+    """dlopen the HIP library.  torch is imported first when available so that both share one HIP runtime."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "agile_grasp_amd has no CPU implementation.")
+        if os.environ.get("AGH_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401  (loads torch's libamdhip64 first; ours then binds to the same runtime)
+            except Exception:
+                pass
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib.agh_last_error.restype = C.c_char_p
+        lib.agh_last_error.argtypes = [C.c_void_p]
+        lib.agh_selftest_math.restype = C.c_int64
+        lib.agh_destroy.restype = None
+        lib.agh_default_params.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Context:
+    """One agh_ctx: HandSearch + Learning::classify state for one cloud on one GPU."""
+
+    def __init__(self, cam_origins, normals_mode: int = NORMALS_DETERMINISTIC, device: int = 0, profile: bool = False,
+                 rand_seed: int = 1, **geometry):
+        self.lib = load_library()
+        p = AghParams()
+        self.lib.agh_default_params(C.byref(p))
+        for c in range(2):
+            for r in range(3):
+                p.cam_origin[c][r] = float(cam_origins[c][r])
+        p.normals_mode, p.device, p.profile, p.rand_seed = normals_mode, device, 1 if profile else 0, rand_seed
+        for k, v in geometry.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        rc = self.lib.agh_create(C.byref(p), C.byref(self._h))
+        if rc != 0:
+            raise AghError(rc, self.lib.agh_last_error(None).decode())
+        self._keep = []  # device tensors that must outlive the context's use of them
+
+    def close(self):
+        if self._h:
+            self.lib.agh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise AghError(rc, self.lib.agh_last_error(self._h).decode())
+        return rc
+
+    # ---- host-buffer API ----
+    def set_cloud(self, xyz: np.ndarray, cam: np.ndarray | None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        stride = xyz.strides[0]
+        camp = None
+        if cam is not None:
+            cam = np.ascontiguousarray(cam, np.int32)
+            camp = _p(cam, C.c_int32)
+        self._check(self.lib.agh_set_cloud(self._h, _p(xyz, C.c_float), C.c_int64(stride), camp,
+                                           C.c_int64(xyz.shape[0])))
+        self.n = xyz.shape[0]
+
+    def find_hands(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
+        samples = np.ascontiguousarray(samples, np.int32)
+        cap = max(8 * samples.shape[0], 1)
+        out = np.zeros(cap, HYP_DTYPE)
+        n = C.c_int64(0)
+        self._check(self.lib.agh_find_hands(self._h, _p(samples, C.c_int32), C.c_int64(samples.shape[0]),
+                                            C.c_int(1 if calculates_antipodal else 0), out.ctypes.data_as(C.c_void_p),
+                                            C.c_int64(cap), C.byref(n)))
+        self.last_samples = samples.shape[0]
+        self.last_n = n.value
+        return out[:n.value].copy()
+
+    def frames(self) -> np.ndarray:
+        fr = np.zeros(self.last_samples, FRAME_DTYPE)
+        n = self._check(self.lib.agh_get_frames(self._h, fr.ctypes.data_as(C.c_void_p), C.c_int64(fr.shape[0])))
+        return fr[:n]
+
+    def neighbor_counts(self):
+        nt = np.zeros(self.last_samples, np.int32)
+        nh = np.zeros(self.last_samples, np.int32)
+        self._check(self.lib.agh_get_neighbor_counts(self._h, _p(nt, C.c_int32), _p(nh, C.c_int32),
+                                                     C.c_int64(nt.shape[0])))
+        return nt, nh
+
+    def images(self) -> np.ndarray:
+        im = np.zeros((max(self.last_n, 1), 8000), np.uint8)
+        n = self._check(self.lib.agh_get_images(self._h, _p(im, C.c_uint8), C.c_int64(self.last_n)))
+        return im[:n]
+
+    def normals(self) -> np.ndarray:
+        nr = np.zeros((self.n, 3), np.float64)
+        self._check(self.lib.agh_get_normals(self._h, _p(nr, C.c_double), C.c_int64(self.n)))
+        return nr
+
+    def load_svm(self, w: np.ndarray, rho: float):
+        w = np.ascontiguousarray(w, np.float32)
+        self._check(self.lib.agh_load_svm(self._h, _p(w, C.c_float), C.c_int32(w.size), C.c_double(rho)))
+
+    def load_svm_file(self, path: str):
+        self._check(self.lib.agh_load_svm_file(self._h, path.encode()))
+
+    def classify(self) -> np.ndarray:
+        keep = np.zeros(max(self.last_n, 1), np.uint8)
+        nk = C.c_int64(0)
+        self._check(self.lib.agh_classify(self._h, _p(keep, C.c_uint8), C.c_int64(self.last_n), C.byref(nk)))
+        return keep[:self.last_n]
+
+    def hog(self):
+        desc = np.zeros((max(self.last_n, 1), 3528), np.float32)
+        sums = np.zeros(max(self.last_n, 1), np.float64)
+        n = self._check(self.lib.agh_get_hog(self._h, _p(desc, C.c_float), _p(sums, C.c_double), C.c_int64(self.last_n)))
+        return desc[:n], sums[:n]
+
+    def timing(self) -> dict:
+        t = AghTiming()
+        self._check(self.lib.agh_get_timing(self._h, C.byref(t)))
+        return {t.name[i].decode(): float(t.ms[i]) for i in range(t.n)}
+
+    def synchronize(self):
+        self._check(self.lib.agh_synchronize(self._h))
+
+    def selftest_math(self, n: int = 1 << 20, seed: int = 1) -> int:
+        return int(self.lib.agh_selftest_math(self._h, C.c_int64(n), C.c_uint64(seed)))
+
+    # ---- device-resident API (torch tensors) ----
+    def set_cloud_torch(self, xyz_t, cam_t, stream=None):
+        """xyz_t: float32 CUDA tensor (N, 3) or (N, 8) contiguous; cam_t: int32 CUDA tensor (N,) or None."""
+        assert xyz_t.is_cuda and xyz_t.is_contiguous()
+        self._keep = [xyz_t, cam_t]
+        self.n = xyz_t.shape[0]
+        self._check(self.lib.agh_set_cloud_device(
+            self._h, C.c_void_p(xyz_t.data_ptr()), C.c_int64(xyz_t.stride(0) * 4),
+            C.c_void_p(cam_t.data_ptr()) if cam_t is not None else None, C.c_int64(self.n),
+            C.c_void_p(stream) if stream else None))
+
+    def find_hands_torch(self, samples_t, out_t, nout_t, calculates_antipodal: bool = False, stream=None):
+        """samples_t int32 CUDA (S,), out_t uint8 CUDA (cap*160,), nout_t int64 CUDA (1,).  Asynchronous."""
+        S = samples_t.shape[0]
+        cap = out_t.numel() // 160
+        self.last_samples = S
+        self._check(self.lib.agh_find_hands_device(
+            self._h, C.c_void_p(samples_t.data_ptr()), C.c_int64(S), C.c_int(1 if calculates_antipodal else 0),
+            C.c_void_p(out_t.data_ptr()), C.c_int64(cap), C.c_void_p(nout_t.data_ptr()),
+            C.c_void_p(stream) if stream else None))
+
+    def classify_torch(self, keep_t=None, stream=None):
+        self._check(self.lib.agh_classify_device(self._h, C.c_void_p(keep_t.data_ptr()) if keep_t is not None else None,
+                                                 C.c_void_p(stream) if stream else None))

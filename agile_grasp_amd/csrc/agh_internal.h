@@ -1,0 +1,279 @@
+// agh_internal.h -- shared declarations of the HIP implementation (gfx950 only, no CPU path).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "agh.h"
+
+namespace agh
+{
+
+constexpr int kCellCap = 1 << 21;  // cells in the uniform grid table (8 MiB of int32)
+constexpr int kMaxRows = 128;      // (y,z) cell rows one ball query may touch
+constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (quadric.cpp:40-131)
+constexpr int kSumStride = 40;     // doubles per sample in the sums buffer
+constexpr int kSlots = 8;          // hypothesis slots per sample = hand orientations (rotating_hand.cpp:13)
+constexpr int kImageWords = 250;   // 80x100 occupancy bitmap, one bit per pixel
+
+// Uniform grid over the cloud's bounding box (stands in for the kd-tree of hand_search.cpp:10-11).
+struct GridDesc
+{
+  double mn[3];
+  double cell;
+  double inv_cell;
+  int dim[3];
+  int ncell;
+  unsigned bbox[6];  // order-preserving uint encoding of float min[3], max[3] (scratch for the reduction)
+};
+
+// Everything a search kernel needs to walk the grid.
+struct GridView
+{
+  const GridDesc* desc;
+  const int* cell_start;   // ncell + 1
+  const float4* sorted;    // x, y, z, bits((idx << 1) | cam), cell-major
+};
+
+struct HandGeom
+{
+  double finger_width, hand_outer_diameter, hand_depth, hand_height, init_bite;
+  double cam_origin[2][3];
+  double cos_a[8], sin_a[8];   // host libm cos/sin of the 8 hand angles (rotating_hand.cpp:13-15, 89-90)
+  double fs[20];               // finger_spacing_ (finger_hand.cpp:8-15)
+  double thr[40];              // sorted unique thresholds {fs_i, fs_i + fw}
+  int n_thr;
+  int lo_idx[20], hi_idx[20];  // index of fs_i and of fs_i + fw in thr
+  double depths[16];           // init_bite, then += 0.005 while <= hand_depth (finger_hand.cpp:204)
+  double backs[16];            // -1.0 * (hand_depth - depth_k)
+  double boxy[16];             // backs[k] + hand_depth (rotating_hand.cpp:127)
+  int n_depths;
+  double cos_antipodal;        // cos(20 deg) (antipodal.cpp:16)
+};
+
+struct HogTablesDev
+{
+  // Gradient LUT for binary images: index = (sx+1)*3 + (sy+1), sx/sy = sign of dx/dy
+  float mag0[9], mag1[9];
+  int bin0[9], bin1[9];
+  // pixData of HOGCache::init in its accumulation order (count1 | count2 | count4 groups)
+  int pix_x[256], pix_y[256];
+  int pix_ncell[256];
+  int pix_cell[256][4];
+  float pix_w[256][4];  // gradWeight * histWeights[c]
+};
+
+enum SampleStatus : int
+{
+  kStatusOk = 0,
+  kStatusOverflow = 1,    // neighbourhood larger than the kernel's LDS capacity
+  kStatusDegenerate = 2,  // N9 not positive definite: no frame, no hypotheses
+  kStatusRows = 3
+};
+
+struct Ctx
+{
+  agh_params p;
+  HandGeom geom;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // cloud
+  int64_t n = 0;
+  const float* d_xyz = nullptr;  // borrowed or owned
+  int64_t stride_floats = 3;
+  const int32_t* d_cam = nullptr;
+  float* own_xyz = nullptr;
+  int32_t* own_cam = nullptr;
+  int64_t own_cap = 0;
+
+  // grid
+  GridDesc* d_desc = nullptr;
+  int* d_cell_start = nullptr;  // kCellCap + 1
+  int* d_cell_count = nullptr;  // kCellCap
+  int* d_block_sums = nullptr;
+  int* d_cell_of = nullptr;     // n
+  float4* d_sorted = nullptr;   // n
+  int64_t grid_cap = 0;
+  bool has_cloud = false;
+
+  // per-call buffers (sized for s_cap samples)
+  int64_t s_cap = 0;
+  int32_t* d_samples = nullptr;
+  double* d_sums = nullptr;        // s_cap * kSumStride
+  int32_t* d_nt = nullptr;         // n_taubin
+  int32_t* d_nh = nullptr;         // n_hands
+  int32_t* d_status = nullptr;
+  float4* d_nbr = nullptr;         // s_cap * nbr_stride sorted neighbour lists
+  int64_t nbr_stride = 0;
+  double* d_eig = nullptr;         // s_cap * 12 : params[10], eigenvalue, valid
+  agh_frame* d_frames = nullptr;
+  agh_hypothesis* d_slots = nullptr;   // s_cap * 8
+  uint32_t* d_images = nullptr;        // s_cap * 8 * kImageWords
+  int32_t* d_slot_index = nullptr;     // compacted position of each slot (or -1)
+  int32_t* d_scan_tmp = nullptr;
+  agh_hypothesis* d_out_own = nullptr;  // compacted hypotheses when the caller gave host memory
+  int64_t* d_nout = nullptr;
+  uint32_t* d_out_images = nullptr;     // compacted images (s_cap * 8 * kImageWords)
+  int32_t* d_draw_ofs = nullptr;        // RAND50: offset of each sample's 50 draws
+  int32_t* d_draws = nullptr;
+  int64_t draws_cap = 0;
+  int64_t last_s = 0;
+  int64_t last_nout = -1;
+  int64_t last_cap = 0;
+  agh_hypothesis* d_out_last = nullptr;  // where the last call's compacted records live
+  int64_t* d_nout_last = nullptr;
+  int32_t* d_flags = nullptr;  // [0] any overflow, [1] ...
+
+  // normals for the antipodal test (cloud_normals_, hand_search.cpp:13-14)
+  double* d_normals = nullptr;  // 3 * n
+  int64_t normals_cap = 0;
+  bool has_normals = false;
+
+  // svm / hog
+  float* d_svm_w = nullptr;
+  double svm_rho = 0.0;
+  bool has_svm = false;
+  HogTablesDev* d_hog = nullptr;
+  HandGeom* d_geom = nullptr;
+  float* d_desc_out = nullptr;  // optional descriptor dump
+  double* d_svm_sums = nullptr;
+  uint8_t* d_keep = nullptr;
+  int64_t keep_cap = 0;
+
+  // timing
+  std::vector<hipEvent_t> ev;
+  std::vector<const char*> ev_name;
+  int ev_used = 0;
+  agh_timing timing;
+};
+
+// ---- kernel launchers (defined in the .hip files) ----
+int grid_build(Ctx* c, hipStream_t st);
+int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
+  bool write_normals, hipStream_t st);
+int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
+int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
+int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
+void hog_tables_host(HogTablesDev* t);
+int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);
+
+void timing_mark(Ctx* c, const char* name, hipStream_t st);
+
+// ---- device helpers ----
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ unsigned enc_float(float f)
+{
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_float(unsigned u)
+{
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ int cell_coord(const GridDesc& g, double v, int a)
+{
+  int c = (int) floor((v - g.mn[a]) * g.inv_cell);
+  return min(max(c, 0), g.dim[a] - 1);
+}
+
+// Squared distance exactly as FLANN's L2_Simple<float> accumulates it (see oracle a2): ((0+dx*dx)+dy*dy)+dz*dz.
+__device__ __forceinline__ float flann_d2(float qx, float qy, float qz, float px, float py, float pz)
+{
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  float d2 = __fmul_rn(dx, dx);
+  d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+  d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+  return d2;
+}
+
+// Row table of one ball query, built cooperatively in LDS.
+struct RowTable
+{
+  int begin[kMaxRows];
+  int prefix[kMaxRows + 1];
+  int nrows;
+  int total;
+  int bad;
+};
+
+// Fill rt for the ball (q, rpad).  Must be called by all threads of the block; ends with a barrier.
+__device__ __forceinline__ void build_rows(const GridView& gv, float qx, float qy, float qz, double rpad, RowTable& rt)
+{
+  const GridDesc& g = *gv.desc;
+  const int tid = threadIdx.x;
+  const int lx = cell_coord(g, (double) qx - rpad, 0), hx = cell_coord(g, (double) qx + rpad, 0);
+  const int ly = cell_coord(g, (double) qy - rpad, 1), hy = cell_coord(g, (double) qy + rpad, 1);
+  const int lz = cell_coord(g, (double) qz - rpad, 2), hz = cell_coord(g, (double) qz + rpad, 2);
+  const int ny = hy - ly + 1, nz = hz - lz + 1;
+  const int nrows = ny * nz;
+  if (tid == 0)
+  {
+    rt.nrows = nrows;
+    rt.bad = nrows > kMaxRows;
+  }
+  if (nrows <= kMaxRows)
+  {
+    for (int t = tid; t < nrows; t += blockDim.x)
+    {
+      const int cy = ly + t % ny, cz = lz + t / ny;
+      // distance from q to the row's (y,z) slab; rows that cannot touch the ball are skipped
+      const double y0 = g.mn[1] + cy * g.cell, z0 = g.mn[2] + cz * g.cell;
+      const double dy = fmax(fmax(y0 - (double) qy, (double) qy - (y0 + g.cell)), 0.0);
+      const double dz = fmax(fmax(z0 - (double) qz, (double) qz - (z0 + g.cell)), 0.0);
+      int b = 0, len = 0;
+      if (dy * dy + dz * dz <= rpad * rpad)
+      {
+        const int base = (cz * g.dim[1] + cy) * g.dim[0];
+        b = gv.cell_start[base + lx];
+        len = gv.cell_start[base + hx + 1] - b;
+      }
+      rt.begin[t] = b;
+      rt.prefix[t + 1] = len;
+    }
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    int acc = 0;
+    rt.prefix[0] = 0;
+    const int nr = rt.bad ? 0 : nrows;
+    for (int t = 0; t < nr; t++)
+    {
+      acc += rt.prefix[t + 1];
+      rt.prefix[t + 1] = acc;
+    }
+    rt.total = acc;
+  }
+  __syncthreads();
+}
+
+// Candidate j of the query -> position in the sorted array.
+__device__ __forceinline__ int row_lookup(const RowTable& rt, int j)
+{
+  int lo = 0, hi = rt.nrows;  // find the largest r with prefix[r] <= j
+  while (hi - lo > 1)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (rt.prefix[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return rt.begin[lo] + (j - rt.prefix[lo]);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace agh
+
+struct agh_ctx
+{
+  agh::Ctx c;
+};

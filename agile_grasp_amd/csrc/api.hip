@@ -1,0 +1,684 @@
+// api.hip -- host side of the C ABI declared in include/agh.h (context, buffers, launch order, error reporting).
+//
+// Launch order of one agh_find_hands_device call = HandSearch::findHands (reference hand_search.cpp:4-62):
+//   [all-points normals pass, r = 0.01, only if calculates_antipodal (17-26)]  K1 over every cloud point
+//   findQuadrics over the samples (53)                                          K1a moments, K1b eigen, K1c frame
+//   findHands over the quadrics (59)                                            K2 hand sweep
+//   concatenation of the per-sample lists (194-200)                             K4 compaction
+// Everything is enqueued on one HIP stream with no host synchronisation in between.
+#include "agh_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace agh;
+
+
+namespace
+{
+thread_local std::string g_create_error;
+
+#define HIPCHK(ctx, expr)                                                                             \
+  do                                                                                                  \
+  {                                                                                                   \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+    {                                                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                \
+      return AGH_ERR_HIP;                                                                             \
+    }                                                                                                 \
+  } while (0)
+
+template <typename T>
+int dev_alloc(Ctx* c, T** p, size_t count)
+{
+  if (*p)
+  {
+    (void) hipFree(*p);
+    *p = nullptr;
+  }
+  HIPCHK(c, hipMalloc((void**) p, std::max<size_t>(count, 1) * sizeof(T)));
+  return AGH_OK;
+}
+
+// glibc rand() (TYPE_3 additive feedback) -- the generator behind quadric.cpp:184 in a default Linux build.
+struct GlibcRand
+{
+  std::vector<uint32_t> r;
+  size_t pos;
+  explicit GlibcRand(uint32_t seed)
+  {
+    r.resize(344);
+    int32_t word = (int32_t) (seed == 0 ? 1u : seed);
+    r[0] = (uint32_t) word;
+    for (int i = 1; i < 31; i++)
+    {
+      const long hi = word / 127773, lo = word % 127773;
+      long w = 16807 * lo - 2836 * hi;
+      if (w < 0)
+        w += 2147483647;
+      word = (int32_t) w;
+      r[i] = (uint32_t) word;
+    }
+    for (int i = 31; i < 34; i++)
+      r[i] = r[i - 31];
+    for (int i = 34; i < 344; i++)
+      r[i] = r[i - 31] + r[i - 3];
+    pos = 344;
+  }
+  int32_t next()
+  {
+    r.push_back(r[pos - 31] + r[pos - 3]);
+    const uint32_t o = r[pos] >> 1;
+    pos++;
+    return (int32_t) o;
+  }
+};
+
+void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
+{
+  std::memset(g, 0, sizeof(*g));
+  g->finger_width = p.finger_width;
+  g->hand_outer_diameter = p.hand_outer_diameter;
+  g->hand_depth = p.hand_depth;
+  g->hand_height = p.hand_height;
+  g->init_bite = p.init_bite;
+  std::memcpy(g->cam_origin, p.cam_origin, sizeof(g->cam_origin));
+  // hand angles: LinSpaced(9, -pi, pi) without the last (rotating_hand.cpp:13-15); cos/sin from the host libm
+  const double step = (M_PI - (-1.0 * M_PI)) / 8.0;
+  for (int o = 0; o < 8; o++)
+  {
+    const double ang = -1.0 * M_PI + o * step;
+    g->cos_a[o] = std::cos(ang);
+    g->sin_a[o] = std::sin(ang);
+  }
+  // finger_spacing_ (finger_hand.cpp:8-15): fs_half = LinSpaced(10, 0, od - fw) = low + i * step
+  const double low = 0.0, high = p.hand_outer_diameter - p.finger_width;
+  const double fstep = (high - low) / 9.0;
+  for (int i = 0; i < 10; i++)
+  {
+    const double h = low + i * fstep;
+    g->fs[i] = (h - p.hand_outer_diameter) + p.finger_width;
+    g->fs[10 + i] = h;
+  }
+  std::vector<double> t;
+  for (int i = 0; i < 20; i++)
+  {
+    t.push_back(g->fs[i]);
+    t.push_back(g->fs[i] + p.finger_width);  // formed as fs_i + fw at use (finger_hand.cpp:63,77)
+  }
+  std::sort(t.begin(), t.end());
+  t.erase(std::unique(t.begin(), t.end()), t.end());
+  g->n_thr = (int) t.size();
+  for (int k = 0; k < g->n_thr; k++)
+    g->thr[k] = t[k];
+  for (int i = 0; i < 20; i++)
+  {
+    g->lo_idx[i] = (int) (std::lower_bound(t.begin(), t.end(), g->fs[i]) - t.begin());
+    g->hi_idx[i] = (int) (std::lower_bound(t.begin(), t.end(), g->fs[i] + p.finger_width) - t.begin());
+  }
+  // bite depths: init_bite, then repeated += 0.005 while <= hand_depth (finger_hand.cpp:199-204)
+  int k = 0;
+  g->depths[k++] = p.init_bite;
+  for (double d = p.init_bite + 0.005; d <= p.hand_depth; d += 0.005)
+  {
+    if (k >= 16)
+    {
+      *err = "more than 15 deepening steps (hand_depth - init_bite > 0.075) are not supported";
+      break;
+    }
+    g->depths[k++] = d;
+  }
+  g->n_depths = k;
+  for (int i = 0; i < k; i++)
+  {
+    g->backs[i] = -1.0 * (p.hand_depth - g->depths[i]);  // finger_hand.cpp:22
+    g->boxy[i] = g->backs[i] + p.hand_depth;             // rotating_hand.cpp:127
+  }
+  g->cos_antipodal = std::cos(20 * M_PI / 180.0);  // antipodal.cpp:16 with thresh 20 (rotating_hand.cpp:162)
+}
+
+int ensure_call_buffers(Ctx* c, int64_t S)
+{
+  if (S <= c->s_cap)
+    return AGH_OK;
+  const int64_t cap = std::max<int64_t>(S, 1024);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_samples, cap)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_sums, cap * kSumStride)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_nt, cap)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_nh, cap)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_status, cap)))
+    return rc;
+  c->nbr_stride = 2048;
+  if ((rc = dev_alloc(c, &c->d_nbr, cap * c->nbr_stride)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_eig, cap * 12)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_frames, cap)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_slots, cap * 8)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_images, cap * 8 * kImageWords)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_slot_index, cap * 8)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_scan_tmp, (cap * 8 + 1023) / 1024 + 1)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_out_own, cap * 8)))
+    return rc;
+  if ((rc = dev_alloc(c, &c->d_draw_ofs, cap)))
+    return rc;
+  c->s_cap = cap;
+  return AGH_OK;
+}
+
+int ensure_draws(Ctx* c, int64_t count, hipStream_t st)
+{
+  if (count <= c->draws_cap)
+    return AGH_OK;
+  std::vector<int32_t> h((size_t) count);
+  GlibcRand g(c->p.rand_seed);
+  for (int64_t i = 0; i < count; i++)
+    h[i] = g.next();
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_draws, (size_t) count)))
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_draws, h.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->draws_cap = count;
+  return AGH_OK;
+}
+
+__global__ void k_iota(int32_t* out, int base, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = base + i;
+}
+
+void timing_begin(Ctx* c, hipStream_t st)
+{
+  c->ev_used = 0;
+  c->ev_name.clear();
+  if (!c->p.profile)
+    return;
+  timing_mark(c, "start", st);
+}
+
+}  // namespace
+
+namespace agh
+{
+void timing_mark(Ctx* c, const char* name, hipStream_t st)
+{
+  if (!c->p.profile)
+    return;
+  if (c->ev_used >= (int) c->ev.size())
+  {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess)
+      return;
+    c->ev.push_back(e);
+  }
+  (void) hipEventRecord(c->ev[c->ev_used], st);
+  c->ev_name.push_back(name);
+  c->ev_used++;
+}
+}  // namespace agh
+
+extern "C" {
+
+void agh_default_params(agh_params* p)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->finger_width = 0.01;         // find_grasps.cpp:13
+  p->hand_outer_diameter = 0.09;  // find_grasps.cpp:14
+  p->hand_depth = 0.06;           // find_grasps.cpp:15
+  p->init_bite = 0.01;            // find_grasps.cpp:16
+  p->hand_height = 0.02;          // find_grasps.cpp:17
+  p->nn_radius_taubin = 0.03;     // hand_search.h:85
+  p->nn_radius_hands = 0.08;      // hand_search.h:85
+  p->nn_radius_normals = 0.01;    // hand_search.cpp:20
+  p->normals_mode = AGH_NORMALS_DETERMINISTIC;
+  p->rand_seed = 1;
+  p->device = 0;
+  p->profile = 0;
+}
+
+const char* agh_last_error(const agh_ctx* ctx)
+{
+  return ctx ? ctx->c.err.c_str() : g_create_error.c_str();
+}
+
+int agh_create(const agh_params* p, agh_ctx** out)
+{
+  if (!p || !out)
+    return AGH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+  {
+    g_create_error = "no HIP device is visible (this library has no CPU path)";
+    return AGH_ERR_NO_DEVICE;
+  }
+  if (p->device < 0 || p->device >= ndev)
+  {
+    g_create_error = "device ordinal out of range";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, p->device) != hipSuccess)
+  {
+    g_create_error = "hipGetDeviceProperties failed";
+    return AGH_ERR_HIP;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+  {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only";
+    return AGH_ERR_NO_DEVICE;
+  }
+  if (!(p->finger_width > 0) || !(p->hand_outer_diameter > p->finger_width) || !(p->hand_depth > 0) ||
+      !(p->nn_radius_taubin > 0) || !(p->nn_radius_hands > 0) || !(p->nn_radius_normals > 0))
+  {
+    g_create_error = "invalid hand geometry or radii";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  agh_ctx* ctx = new agh_ctx();
+  Ctx* c = &ctx->c;
+  c->p = *p;
+  c->device = p->device;
+  std::string gerr;
+  build_geometry(*p, &c->geom, &gerr);
+  if (!gerr.empty())
+  {
+    g_create_error = gerr;
+    delete ctx;
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  auto fail = [&](int rc) {
+    g_create_error = c->err;
+    agh_destroy(ctx);
+    return rc;
+  };
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess)
+  {
+    c->err = "hipSetDevice/hipStreamCreate failed";
+    return fail(AGH_ERR_HIP);
+  }
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_desc, 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) kCellCap + 1)) ||
+      (rc = dev_alloc(c, &c->d_cell_count, (size_t) kCellCap)) || (rc = dev_alloc(c, &c->d_block_sums, 4096)) ||
+      (rc = dev_alloc(c, &c->d_flags, 8)) || (rc = dev_alloc(c, &c->d_nout, 1)) ||
+      (rc = dev_alloc(c, &c->d_geom, 1)) || (rc = dev_alloc(c, &c->d_hog, 1)) ||
+      (rc = dev_alloc(c, &c->d_svm_w, 3528)))
+    return fail(rc);
+  HogTablesDev* ht = new HogTablesDev();
+  hog_tables_host(ht);
+  hipError_t e1 = hipMemcpy(c->d_hog, ht, sizeof(HogTablesDev), hipMemcpyHostToDevice);
+  delete ht;
+  hipError_t e2 = hipMemcpy(c->d_geom, &c->geom, sizeof(HandGeom), hipMemcpyHostToDevice);
+  hipError_t e3 = hipMemset(c->d_flags, 0, 8 * sizeof(int32_t));
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+  {
+    c->err = "uploading tables failed";
+    return fail(AGH_ERR_HIP);
+  }
+  *out = ctx;
+  return AGH_OK;
+}
+
+void agh_destroy(agh_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  Ctx* c = &ctx->c;
+  (void) hipSetDevice(c->device);
+  if (c->stream)
+    (void) hipStreamSynchronize(c->stream);
+  void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
+    c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
+    c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
+    c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep };
+  for (void* p : ptrs)
+    if (p)
+      (void) hipFree(p);
+  for (hipEvent_t e : c->ev)
+    (void) hipEventDestroy(e);
+  if (c->stream)
+    (void) hipStreamDestroy(c->stream);
+  delete ctx;
+}
+
+int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
+  int64_t n, void* hip_stream)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !d_xyz))
+  {
+    c->err = "agh_set_cloud: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  c->n = n;
+  c->d_xyz = d_xyz;
+  c->stride_floats = stride_bytes / 4;
+  c->d_cam = d_cam_source;
+  c->has_normals = false;
+  if (n > c->grid_cap)
+  {
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_cell_of, (size_t) n)) || (rc = dev_alloc(c, &c->d_sorted, (size_t) n)))
+      return rc;
+    c->grid_cap = n;
+  }
+  timing_begin(c, st);
+  int rc = grid_build(c, st);
+  timing_mark(c, "grid_build", st);
+  if (rc != AGH_OK)
+  {
+    c->err = "grid build launch failed";
+    return rc;
+  }
+  c->has_cloud = true;
+  c->last_nout = -1;
+  return AGH_OK;
+}
+
+int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, int64_t n)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz))
+  {
+    c->err = "agh_set_cloud: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n > c->own_cap)
+  {
+    int rc;
+    if ((rc = dev_alloc(c, &c->own_xyz, (size_t) n * 3)) || (rc = dev_alloc(c, &c->own_cam, (size_t) n)))
+      return rc;
+    c->own_cap = n;
+  }
+  if (n > 0)
+  {
+    HIPCHK(c, hipMemcpy2DAsync(c->own_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
+                c->stream));
+    if (cam_source)
+      HIPCHK(c, hipMemcpyAsync(c->own_cam, cam_source, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    else
+      HIPCHK(c, hipMemsetAsync(c->own_cam, 0, sizeof(int32_t) * n, c->stream));
+  }
+  int rc = agh_set_cloud_device(ctx, c->own_xyz, 12, c->own_cam, n, nullptr);
+  if (rc != AGH_OK)
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AGH_OK;
+}
+
+int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->has_cloud)
+  {
+    c->err = "agh_find_hands: no cloud set";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (n_samples < 0 || n_samples > (1 << 24) || (n_samples > 0 && (!d_sample_idx || !d_out)) || !d_n_out || cap < 0)
+  {
+    c->err = "agh_find_hands: bad arguments";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  const int64_t S = n_samples;
+  const int64_t chunk = 16384;  // all-points pass batch
+  int rc = ensure_call_buffers(c, std::max<int64_t>(S, calculates_antipodal ? std::min<int64_t>(c->n, chunk) : 0));
+  if (rc != AGH_OK)
+    return rc;
+  const bool rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50;
+  if (rand_mode)
+  {
+    rc = ensure_draws(c, 50 * (S + (calculates_antipodal ? c->n : 0)), st);
+    if (rc != AGH_OK)
+      return rc;
+  }
+  timing_begin(c, st);
+  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
+  c->last_s = S;
+  c->last_nout = -1;
+  c->last_cap = cap;
+  c->d_out_last = d_out;
+  c->d_nout_last = d_n_out;
+  if (S == 0 || c->n == 0)
+  {
+    HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
+    c->last_s = 0;
+    return AGH_OK;
+  }
+  if (calculates_antipodal)
+  {
+    // hand_search.cpp:13-26: cloud_normals_ zeroed, then findQuadrics over ALL points with r = 0.01
+    if (c->n > c->normals_cap)
+    {
+      if ((rc = dev_alloc(c, &c->d_normals, (size_t) c->n * 3)))
+        return rc;
+      c->normals_cap = c->n;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_normals, 0, sizeof(double) * 3 * c->n, st));
+    for (int64_t b0 = 0; b0 < c->n; b0 += chunk)
+    {
+      const int nb = (int) std::min<int64_t>(chunk, c->n - b0);
+      hipLaunchKernelGGL(k_iota, dim3((nb + 255) / 256), dim3(256), 0, st, c->d_samples, (int) b0, nb);
+      rc = taubin_frames(c, c->d_samples, nb, c->p.nn_radius_normals, c->d_frames, c->d_nt, true, st);
+      if (rc != AGH_OK)
+      {
+        c->err = "normals pass launch failed";
+        return rc;
+      }
+    }
+    c->has_normals = true;
+  }
+  rc = taubin_frames(c, d_sample_idx, S, c->p.nn_radius_taubin, c->d_frames, c->d_nt, calculates_antipodal != 0, st);
+  if (rc != AGH_OK)
+  {
+    c->err = "taubin launch failed";
+    return rc;
+  }
+  rc = hand_sweep(c, d_sample_idx, S, calculates_antipodal != 0, st);
+  if (rc != AGH_OK)
+  {
+    c->err = "hand sweep launch failed";
+    return rc;
+  }
+  rc = compact_hypotheses(c, S, d_out, cap, d_n_out, st);
+  if (rc != AGH_OK)
+  {
+    c->err = "compaction launch failed";
+    return rc;
+  }
+  return AGH_OK;
+}
+
+static int check_flags(Ctx* c, hipStream_t st)
+{
+  int32_t flags[8];
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (flags[0] & 1)
+  {
+    c->err = "a point neighbourhood exceeds the kernels' LDS capacity (taubin: 2048 neighbours, hand sweep: 6144 "
+             "cropped points); voxelise the cloud (localization.cpp:43) or reduce the radii";
+    return AGH_ERR_CAPACITY;
+  }
+  if (flags[0] & 2)
+  {
+    c->err = "output buffer too small for the hypotheses found";
+    return AGH_ERR_CAPACITY;
+  }
+  return AGH_OK;
+}
+
+int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out)
+{
+  if (!ctx || !n_out)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  *n_out = 0;
+  if (!c->has_cloud)
+  {
+    c->err = "agh_find_hands: no cloud set";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (n_samples < 0 || (n_samples > 0 && !sample_idx) || cap < 0 || (cap > 0 && !out))
+  {
+    c->err = "agh_find_hands: bad arguments";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  for (int64_t i = 0; i < n_samples; i++)
+    if (sample_idx[i] < 0 || sample_idx[i] >= c->n)
+    {
+      c->err = "agh_find_hands: sample index out of range";
+      return AGH_ERR_INVALID_ARGUMENT;
+    }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_call_buffers(c, n_samples);
+  if (rc != AGH_OK)
+    return rc;
+  // own sample buffer (d_samples doubles as the iota scratch of the normals pass)
+  int32_t* d_idx = nullptr;
+  HIPCHK(c, hipMalloc((void**) &d_idx, sizeof(int32_t) * std::max<int64_t>(n_samples, 1)));
+  if (n_samples > 0)
+    HIPCHK(c, hipMemcpyAsync(d_idx, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
+  rc = agh_find_hands_device(ctx, d_idx, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
+    c->stream);
+  if (rc == AGH_OK)
+    rc = check_flags(c, c->stream);
+  (void) hipStreamSynchronize(c->stream);
+  (void) hipFree(d_idx);
+  if (rc != AGH_OK)
+    return rc;
+  int64_t n = 0;
+  HIPCHK(c, hipMemcpy(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost));
+  c->last_nout = n;
+  *n_out = n;
+  if (n > cap)
+  {
+    c->err = "output buffer too small for the hypotheses found";
+    return AGH_ERR_CAPACITY;
+  }
+  if (n > 0)
+    HIPCHK(c, hipMemcpy(out, c->d_out_own, sizeof(agh_hypothesis) * n, hipMemcpyDeviceToHost));
+  return AGH_OK;
+}
+
+int agh_synchronize(agh_ctx* ctx)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  return check_flags(c, c->stream);
+}
+
+int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap)
+{
+  if (!ctx || !out)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  const int64_t n = std::min<int64_t>(cap, c->last_s);
+  HIPCHK(c, hipDeviceSynchronize());
+  if (n > 0)
+    HIPCHK(c, hipMemcpy(out, c->d_frames, sizeof(agh_frame) * n, hipMemcpyDeviceToHost));
+  return (int) n;
+}
+
+int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, int64_t cap)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  const int64_t n = std::min<int64_t>(cap, c->last_s);
+  HIPCHK(c, hipDeviceSynchronize());
+  if (n > 0 && n_taubin)
+    HIPCHK(c, hipMemcpy(n_taubin, c->d_nt, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (n > 0 && n_hands)
+    HIPCHK(c, hipMemcpy(n_hands, c->d_nh, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return (int) n;
+}
+
+int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points)
+{
+  if (!ctx || !normals)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->has_normals)
+  {
+    c->err = "no normals: the last agh_find_hands call did not use calculates_antipodal";
+    return AGH_ERR_STATE;
+  }
+  const int64_t n = std::min<int64_t>(cap_points, c->n);
+  HIPCHK(c, hipDeviceSynchronize());
+  if (n > 0)
+    HIPCHK(c, hipMemcpy(normals, c->d_normals, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  return (int) n;
+}
+
+int agh_get_timing(agh_ctx* ctx, agh_timing* out)
+{
+  if (!ctx || !out)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  std::memset(out, 0, sizeof(*out));
+  if (!c->p.profile || c->ev_used < 2)
+    return AGH_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev[c->ev_used - 1]));
+  int k = 0;
+  for (int i = 1; i < c->ev_used && k < AGH_TIMING_SLOTS; i++)
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) != hipSuccess)
+      ms = 0.f;
+    // merge repeated names (the normals pass runs the taubin kernels once per batch)
+    int slot = -1;
+    for (int j = 0; j < k; j++)
+      if (std::strcmp(out->name[j], c->ev_name[i]) == 0)
+        slot = j;
+    if (slot < 0)
+    {
+      slot = k++;
+      out->name[slot] = c->ev_name[i];
+    }
+    out->ms[slot] += ms;
+    out->total_ms += ms;
+  }
+  out->n = k;
+  return AGH_OK;
+}
+
+int64_t agh_selftest_math(agh_ctx* ctx, int64_t n, uint64_t seed)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  return selftest_math(&ctx->c, n, seed);
+}
+
+}  // extern "C"

@@ -1,0 +1,558 @@
+// hand_sweep.hip -- K2: hand-frame transform + RotatingHand/FingerHand occupancy sweep, and K4: compaction.
+//
+// Reference path (src/agile_grasp/...): HandSearch::findHands (private) hand_search.cpp:116-206 (OMP loop B) ->
+// kdtree.radiusSearch r=0.08 (147) -> RotatingHand::transformPoints rotating_hand.cpp:19-75 ->
+// RotatingHand::evaluateHand 78-177 -> FingerHand::evaluateFingers/evaluateHand/deepenHand/evaluateGraspParameters
+// finger_hand.cpp:20-233 -> Antipodal::evaluateGrasp antipodal.cpp:12-86; image of Learning::convertToImage
+// learning.cpp:320-365.
+//
+// One 256-thread workgroup per sample.  The ball's grid rows are read with coalesced float4 loads, filtered with the
+// FLANN float32 distance, rotated into the hand frame in fp64 and cropped to |z| < hand_height straight into an LDS
+// tile (x', y' as double2 + point id).  The reference then re-scans the cropped points for each of 20 finger slots at
+// each of up to 11 bite depths in each of 8 orientations.  Here every point is classified ONCE per orientation:
+//   region  = its position among the <= 40 sorted slot thresholds {fs_i, fs_i + w} (exact fp64 comparisons), and
+//   depth   = how many bite depths d_k are <= y,
+// and one LDS atomic OR records (region, depth) in an 81 x 16 bit table.  "Some point in gap i has y < d_k" and
+// "some point beside slot i has y < d_k" are then range-ORs over that table, so evaluateFingers / evaluateHand /
+// deepenHand become integer logic on one lane -- bit-identical to the literal sweep (all comparisons are the
+// reference's own `<` / `>` on the same doubles; see tests/test_oracle.py::test_reduction_form_equals_literal_sweep).
+// A second pass over the LDS tile (only for orientations that produced a hand) yields the grasp width, the
+// points-in-box count, the antipodal counts and the 80x100 occupancy image.
+#include "agh_internal.h"
+
+namespace agh
+{
+
+struct OriState
+{
+  double T[3][3];  // frame_ * rot^T
+  double approach[3], binormal[3];
+  double cs, sn;
+  double ymin, ymax;
+  int rejected;
+  int has_hand;
+  int e;
+  int last;
+};
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int CAPC>
+__global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
+  const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
+  int S, float r2f, double rpad, int first_class, const double* __restrict__ normals, double img_cell,
+  int32_t* __restrict__ nh, int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots,
+  uint32_t* __restrict__ images)
+{
+  __shared__ double2 pts[CAPC];
+  __shared__ unsigned pid[CAPC];
+  __shared__ RowTable rt;
+  __shared__ HandGeom G;
+  __shared__ double thr_s[64];
+  __shared__ OriState ori[8];
+  __shared__ unsigned regmask[8][44];
+  __shared__ unsigned img[8][kImageWords + 2];
+  __shared__ int cnt_ball, cnt_crop;
+
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!first_class && status[s] != kStatusOverflow)
+    return;
+  const agh_frame F = frames[s];
+  if (!F.valid)
+  {
+    if (tid < 8)
+    {
+      agh_hypothesis h;
+      memset(&h, 0, sizeof(h));
+      h.sample = s;
+      h.orientation = tid;
+      slots[(int64_t) s * 8 + tid] = h;
+    }
+    if (tid == 0)
+    {
+      nh[s] = 0;
+      status[s] = kStatusDegenerate;
+    }
+    return;
+  }
+  // stage the geometry tables in LDS
+  for (int k = tid; k < (int) (sizeof(HandGeom) / 4); k += 256)
+    ((unsigned*) &G)[k] = ((const unsigned*) geom_p)[k];
+  if (tid == 0)
+  {
+    cnt_ball = 0;
+    cnt_crop = 0;
+  }
+  for (int k = tid; k < 8 * 44; k += 256)
+    (&regmask[0][0])[k] = 0u;
+  for (int k = tid; k < 8 * (kImageWords + 2); k += 256)
+    (&img[0][0])[k] = 0u;
+  const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
+  build_rows(gv, sx, sy, sz, rpad, rt);  // ends with barriers: G and counters are visible afterwards
+  if (tid < 64)
+    thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
+  if (rt.bad)
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusRows;
+      nh[s] = 0;
+    }
+    return;
+  }
+  // frame_ << normal, normal x axis, axis (rotating_hand.cpp:24-25); column r of fr is fr[.][r]
+  double fr[3][3];
+  {
+    const double* nm = F.normal;
+    const double* ax = F.axis;
+    const double nxa[3] = { nm[1] * ax[2] - nm[2] * ax[1], nm[2] * ax[0] - nm[0] * ax[2], nm[0] * ax[1] - nm[1] * ax[0] };
+    for (int r = 0; r < 3; r++)
+    {
+      fr[r][0] = nm[r];
+      fr[r][1] = nxa[r];
+      fr[r][2] = ax[r];
+    }
+  }
+  const double hh = G.hand_height;
+  // ---- gather, FLANN filter, hand-frame transform, crop (rotating_hand.cpp:26,37-51) ----
+  const int total = rt.total;
+  for (int j0 = 0; j0 < total; j0 += 256)
+  {
+    const int j = j0 + tid;
+    bool inball = false, keep = false;
+    double tx = 0.0, ty = 0.0;
+    unsigned w = 0;
+    if (j < total)
+    {
+      const float4 p = gv.sorted[row_lookup(rt, j)];
+      const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
+      inball = d2 < r2f;
+      if (inball)
+      {
+        const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
+        tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+        ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+        const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
+        keep = (tz > -1.0 * hh) && (tz < hh);
+        w = __float_as_uint(p.w);
+      }
+    }
+    const unsigned long long mb = __ballot(inball), mk = __ballot(keep);
+    int base = 0;
+    if (lane == 0)
+    {
+      if (mb)
+        atomicAdd(&cnt_ball, __popcll(mb));
+      if (mk)
+        base = atomicAdd(&cnt_crop, __popcll(mk));
+    }
+    base = __shfl(base, 0);
+    if (keep)
+    {
+      const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
+      if (k < CAPC)
+      {
+        pts[k] = make_double2(tx, ty);
+        pid[k] = w;
+      }
+    }
+  }
+  __syncthreads();
+  const int nc = cnt_crop;
+  if (nc > CAPC)
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusOverflow;
+      nh[s] = cnt_ball;
+    }
+    return;
+  }
+  // ---- orientation setup (rotating_hand.cpp:86-104) ----
+  if (tid < 8)
+  {
+    const int o = tid;
+    OriState& O = ori[o];
+    const double cs = G.cos_a[o], sn = G.sin_a[o];
+    const double rot[3][3] = { { cs, -1.0 * sn, 0.0 }, { sn, cs, 0.0 }, { 0.0, 0.0, 1.0 } };
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        O.T[i][j] = (fr[i][0] * rot[j][0] + fr[i][1] * rot[j][1]) + fr[i][2] * rot[j][2];  // frame_ * rot^T
+    double cams[2][3];
+    for (int c = 0; c < 2; c++)
+      for (int r = 0; r < 3; r++)
+        cams[c][r] = G.cam_origin[c][r] - F.sample[r];
+    for (int i = 0; i < 3; i++)
+    {
+      O.approach[i] = (O.T[i][0] * 0.0 + O.T[i][1] * 1.0) + O.T[i][2] * 0.0;
+      O.binormal[i] = (O.T[i][0] * 1.0 + O.T[i][1] * 0.0) + O.T[i][2] * 0.0;
+    }
+    const double d0 = (O.approach[0] * cams[0][0] + O.approach[1] * cams[0][1]) + O.approach[2] * cams[0][2];
+    const double d1 = (O.approach[0] * cams[1][0] + O.approach[1] * cams[1][1]) + O.approach[2] * cams[1][2];
+    O.rejected = ((d0 > 0 && d1 > 0) || nc == 0) ? 1 : 0;
+    O.cs = cs;
+    O.sn = sn;
+    O.has_hand = 0;
+    O.e = -1;
+    O.last = 0;
+    O.ymin = 0.0;
+    O.ymax = 0.0;
+  }
+  __syncthreads();
+  const int K = G.n_depths;
+  // ---- pass 1: classify every cropped point once per orientation ----
+  for (int oo = 0; oo < 2; oo++)
+  {
+    const int o = wave + 4 * oo;
+    if (ori[o].rejected)
+      continue;
+    const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
+    double ymin = INFINITY, ymax = -INFINITY;
+    for (int t = lane; t < nc; t += 64)
+    {
+      const double2 p = pts[t];
+      const double xr = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
+      const double yr = sn * p.x + cs * p.y;
+      ymin = fmin(ymin, yr);
+      ymax = fmax(ymax, yr);
+      int yk = 0;
+      for (int k = 0; k < K; k++)
+        yk += (yr >= G.depths[k]) ? 1 : 0;  // y < d_k  <=>  k >= yk
+      if (yk < K)
+      {
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (thr_s[c + step - 1] < xr)
+            c += step;
+        const int e = (thr_s[c] == xr) ? 1 : 0;  // c <= n_thr <= 40 < 64
+        const int key = 2 * c + e;
+        atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
+      }
+    }
+    ymin = wave_min_f64(ymin);
+    ymax = wave_max_f64(ymax);
+    if (lane == 0)
+    {
+      ori[o].ymin = ymin;
+      ori[o].ymax = ymax;
+    }
+  }
+  __syncthreads();
+  // ---- finger / hand / deepen logic on one lane per orientation (finger_hand.cpp:20-115,173-233) ----
+  if (tid < 8 && !ori[tid].rejected)
+  {
+    const int o = tid;
+    const double ymin = ori[o].ymin;
+    unsigned gapbits[20], sidebits[20];
+    const int R = 2 * G.n_thr + 1;
+    for (int i = 0; i < 20; i++)
+    {
+      const int lo = G.lo_idx[i], hi = G.hi_idx[i];
+      unsigned gb = 0, sb = 0;
+      for (int key = 2 * lo + 2; key <= 2 * hi; key++)
+        gb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
+      if (i <= 10)  // the reference's `i <= m / 2` (finger_hand.cpp:72): slot 10 uses the right-side rule
+      {
+        for (int key = 2 * hi + 2; key < R; key++)
+          sb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
+      }
+      else
+      {
+        for (int key = 0; key <= 2 * lo; key++)
+          sb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
+      }
+      gapbits[i] = gb;
+      sidebits[i] = sb;
+    }
+    int e = -1, last = 0;
+    for (int k = 0; k < K; k++)
+    {
+      const unsigned upto = (2u << k) - 1u;  // depth classes 0..k  <=>  y < d_k
+      unsigned hand = 0;
+      const bool collide = (ymin < G.depths[k]) && (ymin < G.backs[k]);  // finger_hand.cpp:29-42
+      if (!collide)
+      {
+        unsigned fingers = 0;
+        for (int i = 0; i < 20; i++)
+          if (!(gapbits[i] & upto) && (sidebits[i] & upto))
+            fingers |= 1u << i;
+        hand = fingers & (fingers >> 10) & 0x3ffu;
+      }
+      if (k == 0)
+      {
+        if (!hand)
+          break;
+        const int cnt = __popc(hand);
+        int pick = (int) ceil(cnt / 2.0) - 1;  // finger_hand.cpp:190
+        unsigned hm = hand;
+        while (pick-- > 0)
+          hm &= hm - 1u;
+        e = __ffs(hm) - 1;
+      }
+      else
+      {
+        if (!((hand >> e) & 1u))
+          break;
+        last = k;
+      }
+    }
+    ori[o].has_hand = (e >= 0) ? 1 : 0;
+    ori[o].e = e;
+    ori[o].last = last;
+  }
+  __syncthreads();
+  // ---- pass 2: grasp parameters, box, antipodal counts, image (rotating_hand.cpp:111-170) ----
+  const int cam_s = cam_source ? (cam_source[samples[s]] & 1) : 0;  // hands_cam_source(i) = pts_cam_source(indices[i])
+  for (int oo = 0; oo < 2; oo++)
+  {
+    const int o = wave + 4 * oo;
+    agh_hypothesis h;
+    memset(&h, 0, sizeof(h));
+    h.sample = s;
+    h.orientation = o;
+    if (ori[o].rejected || !ori[o].has_hand)
+    {
+      if (lane == 0)
+        slots[(int64_t) s * 8 + o] = h;
+      continue;
+    }
+    const OriState& O = ori[o];
+    const int e = O.e, last = O.last;
+    const double cs = O.cs, ms = -1.0 * O.sn, sn = O.sn;
+    const double left = G.fs[e], right = G.fs[10 + e];
+    const double hor_pos = (G.hand_outer_diameter / 2.0) + (G.fs[e] / 1);  // finger_hand.cpp:127-132, one-hot hand_
+    double surface[3], bottom[3];
+    for (int i = 0; i < 3; i++)
+    {
+      surface[i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;  // rotating_hand.cpp:118-121
+      bottom[i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymax) + O.T[i][2] * 0.0;
+    }
+    double s2c[3];
+    for (int i = 0; i < 3; i++)
+      s2c[i] = (surface[i] + F.sample[i]) - G.cam_origin[cam_s][i];  // learning.cpp:382-383
+    const bool pos_x = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
+    const double box_y = G.boxy[last];
+    const double bite = G.init_bite;
+    double wmin = 100000.0, wmax = -100000.0;
+    int nbox = 0, numl = 0, numr = 0;
+    for (int t = lane; t < nc; t += 64)
+    {
+      const double2 p = pts[t];
+      const double xr = cs * p.x + ms * p.y;
+      const double yr = sn * p.x + cs * p.y;
+      if (yr < bite && xr > left && xr < right)  // finger_hand.cpp:158-167
+      {
+        wmin = fmin(wmin, xr);
+        wmax = fmax(wmax, xr);
+      }
+      if (yr < box_y)  // rotating_hand.cpp:125-130
+      {
+        nbox++;
+        const double bx = xr - surface[0];  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
+        const double by = yr - surface[1];
+        const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
+        const double vy = (by - 0.0) / img_cell;
+        int hc = (int) floor(hx), vc = (int) floor(vy);
+        hc = min(99, max(0, hc));
+        vc = min(79, max(0, vc));
+        const int bit = (79 - vc) * 100 + hc;
+        atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
+        if (normals)
+        {
+          const double* nn = normals + 3 * (int64_t) (pid[t] >> 1);
+          const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
+          const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
+          const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
+          const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
+          numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
+          numr += (nxr > G.cos_antipodal) ? 1 : 0;
+        }
+      }
+    }
+    wmin = wave_min_f64(wmin);
+    wmax = wave_max_f64(wmax);
+    nbox = wave_sum_i32(nbox);
+    numl = wave_sum_i32(numl);
+    numr = wave_sum_i32(numr);
+    for (int i = 0; i < 3; i++)
+    {
+      h.axis[i] = F.axis[i];
+      h.approach[i] = O.approach[i];
+      h.binormal[i] = O.binormal[i];
+      h.bottom[i] = bottom[i] + F.sample[i];  // rotating_hand.cpp:153-154
+      h.surface[i] = surface[i] + F.sample[i];
+    }
+    h.width = wmax - wmin;
+    h.cam_source = cam_s;
+    h.n_in_box = nbox;
+    const bool full = numl > 6 && numr > 6;
+    const bool half = numl > 6 || numr > 6;
+    h.half_antipodal = (half || full) ? 1 : 0;
+    h.full_antipodal = full ? 1 : 0;
+    h.valid = 1;
+    h.finger_index = e;
+    h.depth_index = last;
+    if (lane == 0)
+      slots[(int64_t) s * 8 + o] = h;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int k = lane; k < kImageWords; k += 64)
+      images[((int64_t) s * 8 + o) * kImageWords + k] = img[o][k];
+  }
+  if (tid == 0)
+  {
+    nh[s] = cnt_ball;
+    status[s] = kStatusOk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4: concatenate the per-sample lists in sample order (hand_search.cpp:194-200): scan of the slot valid flags.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_sums(const agh_hypothesis* __restrict__ slots, int n,
+  int* __restrict__ block_sums)
+{
+  __shared__ int ws[4];
+  const int i0 = blockIdx.x * 1024 + threadIdx.x * 4;
+  int sum = 0;
+  for (int k = 0; k < 4; k++)
+    if (i0 + k < n)
+      sum += slots[i0 + k].valid ? 1 : 0;
+  sum = wave_sum_i32(sum);
+  if ((threadIdx.x & 63) == 0)
+    ws[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sums, int nb, int64_t* __restrict__ n_out)
+{
+  // nb <= 4096: serial chunks of 256 with a wave scan
+  __shared__ int ws[4];
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256)
+  {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nb ? block_sums[i] : 0;
+    int inc = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+    if (lane == 63)
+      ws[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++)
+      base += ws[k];
+    const int tot = ws[0] + ws[1] + ws[2] + ws[3];
+    if (i < nb)
+      block_sums[i] = carry + base + inc - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    *n_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __restrict__ slots, int n,
+  const int* __restrict__ block_sums, agh_hypothesis* __restrict__ out, int64_t cap, int32_t* __restrict__ slot_of_hyp,
+  int32_t* __restrict__ flags)
+{
+  __shared__ int ws[4];
+  const int i0 = blockIdx.x * 1024 + threadIdx.x * 4;
+  int v[4], sum = 0;
+  for (int k = 0; k < 4; k++)
+  {
+    v[k] = (i0 + k < n && slots[i0 + k].valid) ? 1 : 0;
+    sum += v[k];
+  }
+  int inc = sum;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o)
+      inc += t;
+  }
+  if (lane == 63)
+    ws[w] = inc;
+  __syncthreads();
+  int pos = block_sums[blockIdx.x] + inc - sum;
+  for (int k = 0; k < w; k++)
+    pos += ws[k];
+  for (int k = 0; k < 4; k++)
+    if (v[k])
+    {
+      if (pos < cap)
+      {
+        out[pos] = slots[i0 + k];
+        slot_of_hyp[pos] = i0 + k;
+      }
+      else
+        atomicOr(&flags[0], 2);
+      pos++;
+    }
+}
+
+int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st)
+{
+  if (S == 0)
+    return AGH_OK;
+  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
+  const double radius = c->p.nn_radius_hands;
+  const float r2f = static_cast<float>(radius * radius);
+  const double rpad = radius * 1.0001 + 1e-6;
+  const double img_cell = (0.05 - (-0.05)) / (double) 100;  // learning.cpp:324
+  const int Si = (int) S;
+  const HandGeom* dg = c->d_geom;
+  const double* nrm = use_normals ? c->d_normals : nullptr;
+  hipLaunchKernelGGL(k_hand_sweep<2048>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
+    rpad, 1, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images);
+  hipLaunchKernelGGL(k_hand_sweep<6144>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
+    rpad, 0, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images);
+  timing_mark(c, "hand_sweep", st);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st)
+{
+  const int n = (int) (S * 8);
+  const int nb = (n + 1023) / 1024;
+  if (n == 0)
+  {
+    hipMemsetAsync(d_nout, 0, sizeof(int64_t), st);
+    return AGH_OK;
+  }
+  hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
+  hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout);
+  hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
+    c->d_slot_index, c->d_flags);
+  timing_mark(c, "compact", st);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+}  // namespace agh

@@ -1,0 +1,836 @@
+// taubin.hip -- K1: radius-neighbour gather + Taubin quadric fit + local Darboux frame, per sample.
+//
+// Reference path (src/agile_grasp/...): HandSearch::findQuadrics hand_search.cpp:65-113 (OMP loop A) ->
+// kdtree.radiusSearch (85) -> Quadric::fitQuadric quadric.cpp:14-157 -> findTaubinNormalAxis 159-251 ->
+// findAverageNormalAxis 263-305.
+//
+// Three kernels, one launch each per batch of samples:
+//   k_taubin_moments<CAP>  one 256-thread workgroup per sample: coalesced float4 reads of the cell-sorted cloud
+//                          for the <= 16 grid rows the ball touches, FLANN float32 distance filter, LDS compaction,
+//                          LDS bitonic sort into the radius search's (d2, index) order, then the 37 distinct sums
+//                          behind M and N accumulated SEQUENTIALLY in that order (64-neighbour chunks: all four
+//                          waves form the products, 37 lanes run the 37 dependent add chains) -- the same fp64
+//                          operation order as the reference loop, so the sums are bit-identical to the CPU path.
+//   k_taubin_eigen         four samples per wave, 9 lanes each: builds M, N, reduces the 10x10 pencil to the 9x9
+//                          symmetric-definite problem, Cholesky + cyclic Jacobi in LDS (same rotation order and
+//                          arithmetic as the CPU path), smallest eigenpair -> quadric parameters.
+//   k_taubin_frame         one workgroup per sample: quadric-gradient normals, the 3x3 scatter of normals
+//                          (sequential sums again) and its Jacobi eigenvectors on wave 0 while the other waves
+//                          already run the n x n (n_i . n_j)^6 column sums; argmax, projection, camera orientation.
+// No MFMA: fp64 separately-rounded mul/add is required for bit parity (MFMA fuses), and the work is LDS/VALU bound.
+#include "agh_internal.h"
+
+namespace agh
+{
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1a
+// ---------------------------------------------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
+  const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
+  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride)
+{
+  __shared__ float4 stage[CAP];
+  __shared__ unsigned long long key[CAP];
+  __shared__ unsigned short slot[CAP];
+  __shared__ double termbuf[64 * kNumSums];
+  __shared__ RowTable rt;
+  __shared__ int count;
+
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!first_class && status[s] != kStatusOverflow)
+    return;  // an earlier (smaller) capacity class already handled this sample
+  const float* qp = xyz + (int64_t) samples[s] * stride;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  if (tid == 0)
+    count = 0;
+  build_rows(gv, qx, qy, qz, rpad, rt);
+  if (rt.bad)
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusRows;
+      nt[s] = 0;
+    }
+    return;
+  }
+  // ---- gather + FLANN distance filter + compaction into LDS ----
+  const int total = rt.total;
+  for (int j0 = 0; j0 < total; j0 += 256)
+  {
+    const int j = j0 + tid;
+    bool pass = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d2 = 0.f;
+    if (j < total)
+    {
+      p = gv.sorted[row_lookup(rt, j)];
+      d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
+      pass = d2 < r2f;
+    }
+    const unsigned long long m = __ballot(pass);
+    int base = 0;
+    if (lane == 0 && m)
+      base = atomicAdd(&count, __popcll(m));
+    base = __shfl(base, 0);
+    if (pass)
+    {
+      const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (k < CAP)
+      {
+        stage[k] = p;
+        key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
+        slot[k] = (unsigned short) k;
+      }
+    }
+  }
+  __syncthreads();
+  const int n = count;
+  if (n > CAP)
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusOverflow;
+      nt[s] = n;
+    }
+    return;
+  }
+  // ---- bitonic sort of (key, slot): ascending (d2, index) = FLANN's sorted radius-search order ----
+  int P = 1;
+  while (P < n)
+    P <<= 1;
+  for (int i = n + tid; i < P; i += 256)
+  {
+    key[i] = ~0ull;
+    slot[i] = 0;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1)
+    {
+      for (int i = tid; i < P; i += 256)
+      {
+        const int ixj = i ^ j;
+        if (ixj > i)
+        {
+          const unsigned long long a = key[i], b = key[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up)
+          {
+            key[i] = b;
+            key[ixj] = a;
+            const unsigned short sa = slot[i], sb = slot[ixj];
+            slot[i] = sb;
+            slot[ixj] = sa;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- sorted neighbour list to global (consumed by k_taubin_frame) ----
+  for (int i = tid; i < n; i += 256)
+    nbr[(int64_t) s * nbr_stride + i] = stage[slot[i]];
+  // ---- 37 sequential sums (quadric.cpp:40-131) ----
+  double acc = 0.0;
+  for (int c0 = 0; c0 < n; c0 += 64)
+  {
+    const int rows = min(64, n - c0);
+    if (lane < rows)
+    {
+      const float4 p = stage[slot[c0 + lane]];
+      const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
+      const double x2 = x * x, y2 = y * y, z2 = z * z;
+      const double xy = x * y, yz = y * z, xz = x * z;
+      double* t = &termbuf[lane * kNumSums];
+      if (wave == 0)
+      {
+        t[0] = x2 * x2;
+        t[1] = x2 * y2;
+        t[2] = x2 * z2;
+        t[3] = x2 * xy;
+        t[4] = x2 * yz;
+        t[5] = x2 * xz;
+        t[6] = x2 * x;
+        t[7] = x2 * y;
+        t[8] = x2 * z;
+        t[9] = x2;
+      }
+      else if (wave == 1)
+      {
+        t[10] = y2 * y2;
+        t[11] = y2 * z2;
+        t[12] = y2 * xy;
+        t[13] = y2 * yz;
+        t[14] = y2 * xz;
+        t[15] = y2 * x;
+        t[16] = y2 * y;
+        t[17] = y2 * z;
+        t[18] = y2;
+      }
+      else if (wave == 2)
+      {
+        t[19] = z2 * z2;
+        t[20] = z2 * xy;
+        t[21] = z2 * yz;
+        t[22] = z2 * xz;
+        t[23] = z2 * x;
+        t[24] = z2 * y;
+        t[25] = z2 * z;
+        t[26] = z2;
+        t[27] = x * yz;
+      }
+      else
+      {
+        t[28] = xy;
+        t[29] = yz;
+        t[30] = xz;
+        t[31] = x;
+        t[32] = y;
+        t[33] = z;
+        t[34] = x2 + y2;
+        t[35] = y2 + z2;
+        t[36] = x2 + z2;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < kNumSums)
+      for (int k = 0; k < rows; k++)
+        acc += termbuf[k * kNumSums + lane];
+    __syncthreads();
+  }
+  if (wave == 0 && lane < kNumSums)
+    sums[(int64_t) s * kSumStride + lane] = acc;
+  if (tid == 0)
+  {
+    nt[s] = n;
+    status[s] = kStatusOk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1b: quadric.cpp:134-153 + solveGeneralizedEigenProblem (330-363) as a 9x9 symmetric-definite reduction.
+// 4 samples per 64-thread workgroup, 16 lanes per sample (9 active).  Mirrors oracle solve_taubin()/jacobi_sym<9>.
+// ---------------------------------------------------------------------------------------------------------------
+struct EigSmem
+{
+  double M[10][10];
+  double N[10][10];
+  double A[9][9];  // S, then C, then the Jacobi iterate
+  double L[9][9];
+  double Y[9][9];
+  double V[9][9];
+  double off;
+  int fail;
+};
+
+__global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
+  const int32_t* __restrict__ status, int S, double* __restrict__ eig)
+{
+  __shared__ EigSmem sm[4];
+  const int lane = threadIdx.x, gl = lane & 15, grp = lane >> 4;
+  const int s = blockIdx.x * 4 + grp;
+  const bool live = s < S && status[s] == kStatusOk;
+  EigSmem& E = sm[grp];
+  const double n = live ? (double) nt[s] : 1.0;
+  if (gl == 0)
+  {
+    E.fail = live ? 0 : 1;
+    double sv[kNumSums];
+    for (int k = 0; k < kNumSums; k++)
+      sv[k] = live ? sums[(int64_t) s * kSumStride + k] : 0.0;
+    for (int i = 0; i < 10; i++)
+      for (int j = 0; j < 10; j++)
+      {
+        E.M[i][j] = 0.0;
+        E.N[i][j] = 0.0;
+      }
+    // upper triangle of M (quadric.cpp:40-100)
+    for (int j = 0; j < 10; j++)
+      E.M[0][j] = sv[j];
+    for (int j = 1; j < 10; j++)
+      E.M[1][j] = sv[10 + j - 1];
+    for (int j = 2; j < 10; j++)
+      E.M[2][j] = sv[19 + j - 2];
+    E.M[3][8] = sv[27];
+    E.M[3][9] = sv[28];
+    E.M[4][9] = sv[29];
+    E.M[5][9] = sv[30];
+    E.M[6][9] = sv[31];
+    E.M[7][9] = sv[32];
+    E.M[8][9] = sv[33];
+    E.M[3][3] = E.M[0][1];
+    E.M[5][5] = E.M[0][2];
+    E.M[3][5] = E.M[0][4];
+    E.M[3][6] = E.M[0][7];
+    E.M[5][6] = E.M[0][8];
+    E.M[6][6] = E.M[0][9];
+    E.M[4][4] = E.M[1][2];
+    E.M[3][4] = E.M[1][5];
+    E.M[3][7] = E.M[1][6];
+    E.M[4][7] = E.M[1][8];
+    E.M[7][7] = E.M[1][9];
+    E.M[4][5] = E.M[2][3];
+    E.M[5][8] = E.M[2][6];
+    E.M[4][8] = E.M[2][7];
+    E.M[8][8] = E.M[2][9];
+    E.M[4][6] = E.M[3][8];
+    E.M[5][7] = E.M[3][8];
+    E.M[6][7] = E.M[3][9];
+    E.M[7][8] = E.M[4][9];
+    E.M[6][8] = E.M[5][9];
+    E.M[9][9] = n;
+    // N (quadric.cpp:103-131): every entry except (3,3),(4,4),(5,5) is an exact power-of-two multiple of an M sum
+    E.N[0][0] = 4.0 * sv[9];
+    E.N[0][3] = 2.0 * sv[28];
+    E.N[0][5] = 2.0 * sv[30];
+    E.N[0][6] = 2.0 * sv[31];
+    E.N[1][1] = 4.0 * sv[18];
+    E.N[1][3] = 2.0 * sv[28];
+    E.N[1][4] = 2.0 * sv[29];
+    E.N[1][7] = 2.0 * sv[32];
+    E.N[2][2] = 4.0 * sv[26];
+    E.N[2][4] = 2.0 * sv[29];
+    E.N[2][5] = 2.0 * sv[30];
+    E.N[2][8] = 2.0 * sv[33];
+    E.N[3][3] = sv[34];
+    E.N[3][4] = sv[30];
+    E.N[3][5] = sv[29];
+    E.N[3][6] = sv[32];
+    E.N[3][7] = sv[31];
+    E.N[4][4] = sv[35];
+    E.N[4][5] = sv[28];
+    E.N[4][7] = sv[33];
+    E.N[4][8] = sv[32];
+    E.N[5][5] = sv[36];
+    E.N[5][6] = sv[33];
+    E.N[5][8] = sv[31];
+    E.N[6][6] = n;
+    E.N[7][7] = n;
+    E.N[8][8] = n;
+    for (int i = 0; i < 10; i++)
+      for (int j = i + 1; j < 10; j++)
+      {
+        E.M[j][i] = E.M[i][j];
+        E.N[j][i] = E.N[i][j];
+      }
+  }
+  __syncthreads();
+  const bool row = gl < 9;
+  const int i = gl;
+  if (row)
+    for (int j = 0; j < 9; j++)
+    {
+      E.A[i][j] = E.M[i][j] - (E.M[i][9] * E.M[j][9]) / n;
+      E.L[i][j] = 0.0;
+    }
+  __syncthreads();
+  // Cholesky N9 = L L^T
+  for (int j = 0; j < 9; j++)
+  {
+    if (gl == j)
+    {
+      double sum = E.N[j][j];
+      for (int k = 0; k < j; k++)
+        sum -= E.L[j][k] * E.L[j][k];
+      if (!(sum > 0.0))
+      {
+        E.fail = 1;
+        sum = 1.0;
+      }
+      E.L[j][j] = sqrt(sum);
+    }
+    __syncthreads();
+    if (row && i > j)
+    {
+      double s2 = E.N[i][j];
+      for (int k = 0; k < j; k++)
+        s2 -= E.L[i][k] * E.L[j][k];
+      E.L[i][j] = s2 / E.L[j][j];
+    }
+    __syncthreads();
+  }
+  // Y = L^-1 S (lane = column)
+  if (row)
+  {
+    const int j = gl;
+    for (int r = 0; r < 9; r++)
+    {
+      double s2 = E.A[r][j];
+      for (int k = 0; k < r; k++)
+        s2 -= E.L[r][k] * E.Y[k][j];
+      E.Y[r][j] = s2 / E.L[r][r];
+    }
+  }
+  __syncthreads();
+  // C = Y L^-T (lane = row), lower triangle mirrored
+  if (row)
+    for (int j = 0; j < 9; j++)
+    {
+      double s2 = E.Y[i][j];
+      for (int k = 0; k < j; k++)
+        s2 -= E.A[i][k] * E.L[j][k];
+      E.A[i][j] = s2 / E.L[j][j];
+    }
+  __syncthreads();
+  if (row)
+    for (int j = i + 1; j < 9; j++)
+      E.A[i][j] = E.A[j][i];
+  if (row)
+    for (int j = 0; j < 9; j++)
+      E.V[i][j] = (i == j) ? 1.0 : 0.0;
+  __syncthreads();
+  // cyclic Jacobi (oracle jacobi_sym<9>)
+  for (int sweep = 0; sweep < 30; sweep++)
+  {
+    if (gl == 0)
+    {
+      double off = 0.0;
+      for (int p = 0; p < 8; p++)
+        for (int q = p + 1; q < 9; q++)
+          off += E.A[p][q] * E.A[p][q];
+      E.off = off;
+    }
+    __syncthreads();
+    const bool active = E.off != 0.0;
+    if (!__any(active))
+      break;
+    for (int p = 0; p < 8; p++)
+      for (int q = p + 1; q < 9; q++)
+      {
+        const double apq = E.A[p][q];
+        const double app = E.A[p][p], aqq = E.A[q][q];
+        const double akp = row ? E.A[i][p] : 0.0, akq = row ? E.A[i][q] : 0.0;
+        const double vkp = row ? E.V[i][p] : 0.0, vkq = row ? E.V[i][q] : 0.0;
+        __syncthreads();
+        bool rot = active && (apq != 0.0);
+        bool zero_only = false;
+        const double aabs = fabs(apq);
+        if (rot && sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+        {
+          zero_only = true;
+          rot = false;
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+        if (theta < 0.0)
+          t = -t;
+        const double c = 1.0 / sqrt(t * t + 1.0);
+        const double sn = t * c;
+        if (zero_only && gl == 0)
+        {
+          E.A[p][q] = 0.0;
+          E.A[q][p] = 0.0;
+        }
+        if (rot)
+        {
+          if (gl == 0)
+          {
+            E.A[p][p] = app - t * apq;
+            E.A[q][q] = aqq + t * apq;
+            E.A[p][q] = 0.0;
+            E.A[q][p] = 0.0;
+          }
+          if (row)
+          {
+            if (i != p && i != q)
+            {
+              const double np_ = c * akp - sn * akq;
+              const double nq_ = sn * akp + c * akq;
+              E.A[i][p] = np_;
+              E.A[p][i] = np_;
+              E.A[i][q] = nq_;
+              E.A[q][i] = nq_;
+            }
+            E.V[i][p] = c * vkp - sn * vkq;
+            E.V[i][q] = sn * vkp + c * vkq;
+          }
+        }
+        __syncthreads();
+      }
+  }
+  __syncthreads();
+  if (gl == 0 && s < S)
+  {
+    double* out = eig + (int64_t) s * 12;
+    if (E.fail)
+    {
+      for (int k = 0; k < 12; k++)
+        out[k] = 0.0;
+    }
+    else
+    {
+      int mi = 0;
+      for (int k = 1; k < 9; k++)
+        if (E.A[k][k] < E.A[mi][mi])
+          mi = k;
+      double v[10];
+      for (int r = 8; r >= 0; r--)
+      {
+        double s2 = E.V[r][mi];
+        for (int k = r + 1; k < 9; k++)
+          s2 -= E.L[k][r] * v[k];
+        v[r] = s2 / E.L[r][r];
+      }
+      double bv = 0.0;
+      for (int k = 0; k < 9; k++)
+        bv += E.M[k][9] * v[k];
+      v[9] = -bv / n;
+      for (int k = 3; k < 6; k++)
+        v[k] *= 0.5;  // quadric.cpp:153
+      for (int k = 0; k < 10; k++)
+        out[k] = v[k];
+      out[10] = E.A[mi][mi];
+      out[11] = 1.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1c
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void jacobi3_serial(double A[3][3], double V[3][3], double d[3])
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; sweep++)
+  {
+    double off = 0.0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++)
+        off += A[p][q] * A[p][q];
+    if (off == 0.0)
+      break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++)
+      {
+        const double apq = A[p][q];
+        if (apq == 0.0)
+          continue;
+        const double app = A[p][p], aqq = A[q][q];
+        const double aabs = fabs(apq);
+        if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+        {
+          A[p][q] = 0.0;
+          A[q][p] = 0.0;
+          continue;
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+        if (theta < 0.0)
+          t = -t;
+        const double c = 1.0 / sqrt(t * t + 1.0);
+        const double s = t * c;
+        A[p][p] = app - t * apq;
+        A[q][q] = aqq + t * apq;
+        A[p][q] = 0.0;
+        A[q][p] = 0.0;
+        for (int k = 0; k < 3; k++)
+        {
+          if (k == p || k == q)
+            continue;
+          const double akp = A[k][p], akq = A[k][q];
+          const double np_ = c * akp - s * akq;
+          const double nq_ = s * akp + c * akq;
+          A[k][p] = np_;
+          A[p][k] = np_;
+          A[k][q] = nq_;
+          A[q][k] = nq_;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++)
+    d[i] = A[i][i];
+}
+
+template <int CAP>
+__global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
+  const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
+  const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
+  const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
+  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out)
+{
+  __shared__ double nx[CAP], ny[CAP], nz[CAP];
+  __shared__ int camcnt[2];
+  __shared__ int next_col;
+  __shared__ double sM3[6];
+  __shared__ double sAxis[3];
+  __shared__ double wbest[4];
+  __shared__ int wbest_j[4];
+
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = nt[s];
+  const double* ev = eig + (int64_t) s * 12;
+  const bool valid = status[s] == kStatusOk && ev[11] != 0.0 && n <= CAP;
+  const float* qp = xyz + (int64_t) samples[s] * stride;
+  if (!valid)
+  {
+    if (tid == 0)
+    {
+      agh_frame f;
+      for (int k = 0; k < 3; k++)
+      {
+        f.sample[k] = (double) qp[k];
+        f.normal[k] = f.axis[k] = f.binormal[k] = 0.0;
+      }
+      for (int k = 0; k < 10; k++)
+        f.params[k] = 0.0;
+      f.eigenvalue = 0.0;
+      f.n_nb = n;
+      f.majority_cam = 0;
+      f.max_index = 0;
+      f.valid = 0;
+      frames[s] = f;
+    }
+    return;
+  }
+  // quadric.cpp:162-170
+  const double a = ev[0], b = ev[1], c = ev[2];
+  const double d = 2.0 * ev[3], e = 2.0 * ev[4], f = 2.0 * ev[5];
+  const double g = ev[6], h = ev[7], i9 = ev[8];
+  const bool sub = rand_mode && n > 50;  // quadric.cpp:177-193
+  const int ks = sub ? 50 : n;
+  if (tid < 2)
+    camcnt[tid] = 0;
+  if (tid == 0)
+    next_col = 0;
+  __syncthreads();
+  const float4* nb = nbr + (int64_t) s * nbr_stride;
+  for (int t = tid; t < ks; t += 256)
+  {
+    const int pick = sub ? (draws[draw_ofs[s] + t] % n) : t;
+    const float4 p = nb[pick];
+    const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
+    const double fx = (((2.0 * a) * x + d * y) + f * z) + g;  // quadric.cpp:238-247
+    const double fy = (((2.0 * b) * y + d * x) + e * z) + h;
+    const double fz = (((2.0 * c) * z + e * y) + f * x) + i9;
+    const double mag = sqrt((fx * fx + fy * fy) + fz * fz);
+    nx[t] = fx / mag;
+    ny[t] = fy / mag;
+    nz[t] = fz / mag;
+    atomicAdd(&camcnt[__float_as_uint(p.w) & 1u], 1);  // quadric.cpp:215-226
+  }
+  __syncthreads();
+  // ---- wave 0: M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
+  if (wave == 0)
+  {
+    if (lane < 6)
+    {
+      const int r = (lane < 3) ? 0 : (lane < 5 ? 1 : 2);
+      const int q = (lane < 3) ? lane : (lane < 5 ? lane - 2 : 2);
+      const double* pr = (r == 0) ? nx : (r == 1 ? ny : nz);
+      const double* pq = (q == 0) ? nx : (q == 1 ? ny : nz);
+      double acc = 0.0;
+      for (int t = 0; t < ks; t++)
+        acc += pr[t] * pq[t];
+      sM3[lane] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0)
+    {
+      double A[3][3] = { { sM3[0], sM3[1], sM3[2] }, { sM3[1], sM3[3], sM3[4] }, { sM3[2], sM3[4], sM3[5] } };
+      double V[3][3], dd[3];
+      jacobi3_serial(A, V, dd);
+      int mi = 0;
+      for (int r = 1; r < 3; r++)
+        if (dd[r] < dd[mi])
+          mi = r;
+      sAxis[0] = V[0][mi];
+      sAxis[1] = V[1][mi];
+      sAxis[2] = V[2][mi];
+    }
+  }
+  // ---- all waves: column sums of ((normals^T normals)^6) (quadric.cpp:283-284), 64 columns per grab ----
+  double best = -1.0;
+  int best_j = 0x7fffffff;
+  for (;;)
+  {
+    int c0 = 0;
+    if (lane == 0)
+      c0 = atomicAdd(&next_col, 64);
+    c0 = __shfl(c0, 0);
+    if (c0 >= ks)
+      break;
+    const int j = c0 + lane;
+    const bool have = j < ks;
+    const double jx = have ? nx[j] : 0.0, jy = have ? ny[j] : 0.0, jz = have ? nz[j] : 0.0;
+    double acc = 0.0;
+    for (int t = 0; t < ks; t++)
+    {
+      const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
+      const double g2 = gdot * gdot;
+      acc += (g2 * g2) * g2;
+    }
+    if (have && (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff))
+    {
+      best = acc;
+      best_j = j;
+    }
+  }
+  // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum)
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    const double ob = __shfl_down(best, o);
+    const int oj = __shfl_down(best_j, o);
+    const bool take = (oj != 0x7fffffff) && (best_j == 0x7fffffff || ob > best || (ob == best && oj < best_j));
+    if (take)
+    {
+      best = ob;
+      best_j = oj;
+    }
+  }
+  if (lane == 0)
+  {
+    wbest[wave] = best;
+    wbest_j[wave] = best_j;
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    for (int w = 1; w < 4; w++)
+    {
+      const double ob = wbest[w];
+      const int oj = wbest_j[w];
+      const bool take = (oj != 0x7fffffff) && (best_j == 0x7fffffff || ob > best || (ob == best && oj < best_j));
+      if (take)
+      {
+        best = ob;
+        best_j = oj;
+      }
+    }
+    const int max_index = best_j;
+    double axis[3] = { sAxis[0], sAxis[1], sAxis[2] };
+    const double nm[3] = { nx[max_index], ny[max_index], nz[max_index] };
+    // normal = normalise((I - a a^T) n_max) (quadric.cpp:285-288)
+    double np_[3];
+    for (int r = 0; r < 3; r++)
+    {
+      double pr[3];
+      for (int q = 0; q < 3; q++)
+        pr[q] = ((r == q) ? 1.0 : 0.0) - axis[r] * axis[q];
+      np_[r] = (pr[0] * nm[0] + pr[1] * nm[1]) + pr[2] * nm[2];
+    }
+    const double nn = sqrt((np_[0] * np_[0] + np_[1] * np_[1]) + np_[2] * np_[2]);
+    double normal[3] = { np_[0] / nn, np_[1] / nn, np_[2] / nn };
+    double binormal[3] = { axis[1] * normal[2] - axis[2] * normal[1], axis[2] * normal[0] - axis[0] * normal[2],
+      axis[0] * normal[1] - axis[1] * normal[0] };  // quadric.cpp:291
+    const int maj = (camcnt[1] > camcnt[0]) ? 1 : 0;
+    const double sample[3] = { (double) qp[0], (double) qp[1], (double) qp[2] };
+    const double s2s[3] = { sample[0] - (maj ? cam1x : cam0x), sample[1] - (maj ? cam1y : cam0y),
+      sample[2] - (maj ? cam1z : cam0z) };
+    if ((normal[0] * s2s[0] + normal[1] * s2s[1]) + normal[2] * s2s[2] > 0)
+      for (int r = 0; r < 3; r++)
+        normal[r] *= -1.0;
+    if ((binormal[0] * s2s[0] + binormal[1] * s2s[1]) + binormal[2] * s2s[2] > 0)
+      for (int r = 0; r < 3; r++)
+        binormal[r] *= -1.0;
+    axis[0] = normal[1] * binormal[2] - normal[2] * binormal[1];  // quadric.cpp:304
+    axis[1] = normal[2] * binormal[0] - normal[0] * binormal[2];
+    axis[2] = normal[0] * binormal[1] - normal[1] * binormal[0];
+    agh_frame fr;
+    for (int r = 0; r < 3; r++)
+    {
+      fr.sample[r] = sample[r];
+      fr.normal[r] = normal[r];
+      fr.axis[r] = axis[r];
+      fr.binormal[r] = binormal[r];
+    }
+    for (int k = 0; k < 10; k++)
+      fr.params[k] = ev[k];
+    fr.eigenvalue = ev[10];
+    fr.n_nb = n;
+    fr.majority_cam = maj;
+    fr.max_index = max_index;
+    fr.valid = 1;
+    frames[s] = fr;
+    if (normals_out)
+    {
+      double* o = normals_out + 3 * (int64_t) samples[s];  // cloud_normals_.col(indices[i]) (hand_search.cpp:102)
+      o[0] = normal[0];
+      o[1] = normal[1];
+      o[2] = normal[2];
+    }
+  }
+}
+
+// RAND50: sample i consumes 50 draws iff its neighbourhood has more than 50 points, in sample order.
+__global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
+  int32_t* __restrict__ total_io)
+{
+  // single wave: chunked inclusive scan; *total_io carries the draws consumed by earlier passes of this call
+  const int lane = threadIdx.x;
+  int carry = *total_io;
+  for (int c0 = 0; c0 < S; c0 += 64)
+  {
+    const int i = c0 + lane;
+    const int v = (i < S && nt[i] > 50) ? 50 : 0;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+    if (i < S)
+      draw_ofs[i] = carry + inc - v;
+    carry += __shfl(inc, 63);
+  }
+  if (lane == 0)
+    *total_io = carry;
+}
+
+__global__ void k_flag_overflow(const int32_t* __restrict__ status, int S, int32_t* __restrict__ flags)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S && (status[i] == kStatusOverflow || status[i] == kStatusRows))
+    atomicOr(&flags[0], 1);
+}
+
+int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
+  bool write_normals, hipStream_t st)
+{
+  if (S == 0)
+    return AGH_OK;
+  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
+  const float r2f = static_cast<float>(radius * radius);  // pcl::KdTreeFLANN::radiusSearch squares in double, casts
+  const double rpad = radius * 1.0001 + 1e-6;
+  const int Si = (int) S;
+  // capacity classes: smallest first; later classes only touch samples flagged kStatusOverflow
+  const bool small_first = radius <= 0.015;
+  bool first = true;
+  if (small_first)
+  {
+    hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+    first = false;
+  }
+  hipLaunchKernelGGL(k_taubin_moments<1024>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+  hipLaunchKernelGGL(k_taubin_moments<2048>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+  timing_mark(c, "taubin_moments", st);
+  hipLaunchKernelGGL(k_flag_overflow, dim3((Si + 255) / 256), dim3(256), 0, st, c->d_status, Si, c->d_flags);
+  hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig);
+  timing_mark(c, "taubin_eigen", st);
+  const int rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50 ? 1 : 0;
+  if (rand_mode)
+    hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
+  const double* co = &c->p.cam_origin[0][0];
+  hipLaunchKernelGGL(k_taubin_frame<2048>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
+    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr);
+  timing_mark(c, "taubin_frame", st);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+}  // namespace agh

@@ -1,0 +1,159 @@
+/*
+ * agh.h -- C ABI of libagile_grasp_hip.so, the MI355X-native (gfx950) grasp-hypothesis search.
+ *
+ * This is the drop-in boundary for agile_grasp's per-sample hot path.  The reference has no FFI; the seam is
+ * a set of C++ methods (paths relative to the reference repository):
+ *
+ *   agh_create / agh_destroy        <- HandSearch::HandSearch(...)               include/agile_grasp/hand_search.h:77-85
+ *   agh_set_cloud[_device]          <- kd-tree build inside HandSearch::findHands src/agile_grasp/hand_search.cpp:10-11
+ *   agh_find_hands[_device]         <- HandSearch::findHands(cloud, pts_cam_source, indices, ...)
+ *                                                                                 include/agile_grasp/hand_search.h:101-104,
+ *                                                                                 src/agile_grasp/hand_search.cpp:4-62
+ *   agh_load_svm[_file]             <- CvSVM::load in Learning::classify          src/agile_grasp/learning.cpp:185
+ *   agh_classify                    <- Learning::classify(hands, svm, cam_pos)    include/agile_grasp/learning.h:122-123,
+ *                                                                                 src/agile_grasp/learning.cpp:165-247
+ *   agh_hypothesis                  <- GraspHypothesis                            include/agile_grasp/grasp_hypothesis.h:46-231
+ *
+ * The header-only C++ adapter in include/agile_grasp_amd/ keeps the reference's class and method names on top of
+ * this ABI.  Conventions: every function returns AGH_OK (0) or a negative agh_status; no
+ * exception crosses the ABI; all buffers are caller-owned; one context per host thread; a context owns its HIP
+ * stream unless a stream is passed in.  There is NO CPU fallback: without a usable HIP device agh_create fails.
+ */
+#ifndef AGH_H
+#define AGH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGH_VERSION 1
+
+typedef enum agh_status
+{
+  AGH_OK = 0,
+  AGH_ERR_INVALID_ARGUMENT = -1,
+  AGH_ERR_NO_DEVICE = -2,       /* no HIP device / wrong architecture: the product path never falls back to the CPU */
+  AGH_ERR_HIP = -3,             /* a HIP runtime call failed; see agh_last_error */
+  AGH_ERR_CAPACITY = -4,        /* output buffer too small, or a neighbourhood exceeds the kernels' LDS capacity */
+  AGH_ERR_NO_CLOUD = -5,
+  AGH_ERR_NO_SVM = -6,
+  AGH_ERR_IO = -7,
+  AGH_ERR_STATE = -8
+} agh_status;
+
+#define AGH_NORMALS_DETERMINISTIC 0 /* Quadric(is_deterministic = true): all neighbours (quadric.cpp:194-212) */
+#define AGH_NORMALS_RAND50 1        /* HandSearch default: 50 draws of glibc rand() % n in sample order (quadric.cpp:177-193) */
+
+typedef struct agh_params
+{
+  double finger_width;        /* find_grasps.cpp:13 */
+  double hand_outer_diameter; /* find_grasps.cpp:14 */
+  double hand_depth;          /* find_grasps.cpp:15 */
+  double hand_height;         /* find_grasps.cpp:17 */
+  double init_bite;           /* find_grasps.cpp:16 */
+  double nn_radius_taubin;    /* hand_search.h:85 (0.03) */
+  double nn_radius_hands;     /* hand_search.h:85 (0.08) */
+  double nn_radius_normals;   /* hand_search.cpp:20 (0.01) */
+  double cam_origin[2][3];    /* translations of cam_tf_left / cam_tf_right (hand_search.cpp:72-74) */
+  int32_t normals_mode;       /* AGH_NORMALS_* */
+  uint32_t rand_seed;         /* srand() seed for AGH_NORMALS_RAND50 */
+  int32_t device;             /* HIP device ordinal */
+  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing) */
+} agh_params;
+
+/* One grasp hypothesis, fixed size (160 B).  The variable-size points_for_learning_ of the reference
+ * (grasp_hypothesis.h:220) stays on the device as an 80x100 occupancy image consumed by agh_classify. */
+typedef struct agh_hypothesis
+{
+  double axis[3];      /* getAxis() */
+  double approach[3];  /* getApproach() */
+  double binormal[3];  /* getBinormal() */
+  double bottom[3];    /* getGraspBottom() */
+  double surface[3];   /* getGraspSurface() */
+  double width;        /* getGraspWidth() */
+  int32_t sample;      /* position in the sample-index list */
+  int32_t orientation; /* 0..7, angle = -pi + k*pi/4 (rotating_hand.cpp:13-15) */
+  int32_t cam_source;  /* getCamSource() */
+  int32_t n_in_box;    /* columns of points_for_learning_ */
+  uint8_t half_antipodal, full_antipodal; /* isHalfAntipodal(), isFullAntipodal() */
+  uint8_t svm_keep;    /* set by agh_classify: 1 iff CvSVM::predict == 1 (learning.cpp:225-227) */
+  uint8_t valid;
+  int32_t finger_index; /* eroded hand index (finger_hand.cpp:190) */
+  int32_t depth_index;  /* successful deepen steps (finger_hand.cpp:204-225) */
+  int32_t pad_;
+} agh_hypothesis;
+
+/* Per-sample local frame (Quadric's results: quadric.h getters) -- for stage-wise parity tests and plotting. */
+typedef struct agh_frame
+{
+  double sample[3];
+  double normal[3];
+  double axis[3];
+  double binormal[3];
+  double params[10];
+  double eigenvalue;
+  int32_t n_nb;
+  int32_t majority_cam;
+  int32_t max_index;
+  int32_t valid;
+} agh_frame;
+
+/* Kernel times of the last find_hands call, milliseconds, measured with HIP events on the context's stream. */
+#define AGH_TIMING_SLOTS 16
+typedef struct agh_timing
+{
+  float ms[AGH_TIMING_SLOTS];
+  const char* name[AGH_TIMING_SLOTS];
+  int32_t n;
+  float total_ms;
+} agh_timing;
+
+typedef struct agh_ctx agh_ctx;
+
+void agh_default_params(agh_params* p);
+int agh_create(const agh_params* p, agh_ctx** out);
+void agh_destroy(agh_ctx* ctx);
+const char* agh_last_error(const agh_ctx* ctx); /* ctx may be NULL: error of the last failed agh_create */
+
+/* Upload (host pointers) or adopt (device pointers) a cloud and build the uniform search grid on the GPU.
+ * xyz: x,y,z float32 at byte offset 0 of each point; stride_bytes = 12 (packed) or 32 (pcl::PointXYZRGBA).
+ * cam_source: 0/1 per point (Eigen::VectorXi pts_cam_source), may be NULL (all 0). */
+int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, int64_t n);
+int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
+  int64_t n, void* hip_stream);
+
+/* HandSearch::findHands for explicit sample indices.  out receives <= 8*n_samples records, sample-major and
+ * orientation-ascending (the reference's concatenation order, hand_search.cpp:194-200). */
+int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out);
+/* Same, everything device-resident and asynchronous on hip_stream (NULL = the context's stream):
+ * d_out has room for cap records, *d_n_out (device int64) receives the count. */
+int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
+
+/* Linear SVM (one weight vector of 3528 floats + rho), from memory or from an OpenCV YAML file. */
+int agh_load_svm(agh_ctx* ctx, const float* weights, int32_t n_weights, double rho);
+int agh_load_svm_file(agh_ctx* ctx, const char* path);
+/* Learning::classify on the hypotheses of the last agh_find_hands* call: keep[i] = 1 iff kept.  Also sets
+ * svm_keep in the device-side records; keep may be NULL for the device variant. */
+int agh_classify(agh_ctx* ctx, uint8_t* keep, int64_t cap, int64_t* n_kept);
+int agh_classify_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream);
+
+/* Introspection for parity tests / plotting (host buffers). */
+int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap);
+int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, int64_t cap);
+int agh_get_images(agh_ctx* ctx, uint8_t* images, int64_t cap_hyp); /* cap_hyp x 8000 bytes, 80 rows x 100 cols */
+int agh_get_hog(agh_ctx* ctx, float* desc, double* sums, int64_t cap_hyp); /* cap_hyp x 3528 floats (+ SVM sums) */
+int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points);  /* cloud_normals_ (3 doubles per point) */
+int agh_get_timing(agh_ctx* ctx, agh_timing* out);
+int agh_synchronize(agh_ctx* ctx);
+/* Device self-test of the IEEE assumptions the parity contract rests on (fp64 div/sqrt, fp32 div/sqrt correctly
+ * rounded, no FMA contraction): returns the number of mismatches against host arithmetic on n random inputs. */
+int64_t agh_selftest_math(agh_ctx* ctx, int64_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGH_H */
