@@ -163,7 +163,7 @@ class Context:
     def set_cloud(self, xyz: np.ndarray, cam: np.ndarray | None):
         xyz = np.ascontiguousarray(xyz, np.float32)
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
-        stride = xyz.strides[0]
+        stride = xyz.shape[1] * 4  # (numpy reports arbitrary strides for empty arrays)
         camp = None
         if cam is not None:
             cam = np.ascontiguousarray(cam, np.int32)

@@ -145,6 +145,9 @@ struct Ctx
   uint8_t* d_keep = nullptr;
   int64_t keep_cap = 0;
 
+  int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep
+  int debug_stop_moments = 0;  // AGH_DEBUG_STOP_MOMENTS
+
   // timing
   std::vector<hipEvent_t> ev;
   std::vector<const char*> ev_name;
@@ -254,7 +257,15 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
   __syncthreads();
 }
 
-// Candidate j of the query -> position in the sorted array.
+// Candidate j of the query -> position in the sorted array, for a thread whose j only grows: r is its row cursor.
+__device__ __forceinline__ int row_advance(const RowTable& rt, int j, int& r)
+{
+  while (j >= rt.prefix[r + 1])
+    r++;
+  return rt.begin[r] + (j - rt.prefix[r]);
+}
+
+// Candidate j of the query -> position in the sorted array (binary search).
 __device__ __forceinline__ int row_lookup(const RowTable& rt, int j)
 {
   int lo = 0, hi = rt.nrows;  // find the largest r with prefix[r] <= j

@@ -20,6 +20,7 @@ using namespace agh;
 namespace
 {
 thread_local std::string g_create_error;
+constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
 
 #define HIPCHK(ctx, expr)                                                                             \
   do                                                                                                  \
@@ -157,7 +158,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_status, cap)))
     return rc;
-  c->nbr_stride = 2048;
+  c->nbr_stride = 4096;
   if ((rc = dev_alloc(c, &c->d_nbr, cap * c->nbr_stride)))
     return rc;
   if ((rc = dev_alloc(c, &c->d_eig, cap * 12)))
@@ -206,10 +207,13 @@ __global__ void k_iota(int32_t* out, int base, int n)
 
 void timing_begin(Ctx* c, hipStream_t st)
 {
-  c->ev_used = 0;
-  c->ev_name.clear();
   if (!c->p.profile)
     return;
+  if (c->ev_used > 60000)  // nobody is reading the timings: start over instead of growing without bound
+  {
+    c->ev_used = 0;
+    c->ev_name.clear();
+  }
   timing_mark(c, "start", st);
 }
 
@@ -295,6 +299,10 @@ int agh_create(const agh_params* p, agh_ctx** out)
   Ctx* c = &ctx->c;
   c->p = *p;
   c->device = p->device;
+  if (const char* e = std::getenv("AGH_DEBUG_STOP_SWEEP"))
+    c->debug_stop_sweep = std::atoi(e);
+  if (const char* e = std::getenv("AGH_DEBUG_STOP_MOMENTS"))
+    c->debug_stop_moments = std::atoi(e);
   std::string gerr;
   build_geometry(*p, &c->geom, &gerr);
   if (!gerr.empty())
@@ -448,7 +456,7 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   const int64_t S = n_samples;
-  const int64_t chunk = 16384;  // all-points pass batch
+  const int64_t chunk = kNormalsChunk;  // all-points pass batch
   int rc = ensure_call_buffers(c, std::max<int64_t>(S, calculates_antipodal ? std::min<int64_t>(c->n, chunk) : 0));
   if (rc != AGH_OK)
     return rc;
@@ -501,11 +509,21 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
     c->err = "taubin launch failed";
     return rc;
   }
+  if (c->debug_stop_moments)
+  {
+    HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
+    return AGH_OK;
+  }
   rc = hand_sweep(c, d_sample_idx, S, calculates_antipodal != 0, st);
   if (rc != AGH_OK)
   {
     c->err = "hand sweep launch failed";
     return rc;
+  }
+  if (c->debug_stop_sweep)
+  {
+    HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
+    return AGH_OK;
   }
   rc = compact_hypotheses(c, S, d_out, cap, d_n_out, st);
   if (rc != AGH_OK)
@@ -523,8 +541,8 @@ static int check_flags(Ctx* c, hipStream_t st)
   HIPCHK(c, hipStreamSynchronize(st));
   if (flags[0] & 1)
   {
-    c->err = "a point neighbourhood exceeds the kernels' LDS capacity (taubin: 2048 neighbours, hand sweep: 6144 "
-             "cropped points); voxelise the cloud (localization.cpp:43) or reduce the radii";
+    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
+             "voxelise the cloud (localization.cpp:43) or reduce the radii";
     return AGH_ERR_CAPACITY;
   }
   if (flags[0] & 2)
@@ -559,7 +577,8 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
       return AGH_ERR_INVALID_ARGUMENT;
     }
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = ensure_call_buffers(c, n_samples);
+  // size the buffers for everything the device call will need, so that it does not reallocate d_out_own under us
+  int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
   if (rc != AGH_OK)
     return rc;
   // own sample buffer (d_samples doubles as the iota scratch of the normals pass)
@@ -644,6 +663,8 @@ int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points)
 
 int agh_get_timing(agh_ctx* ctx, agh_timing* out)
 {
+  // Sums the kernel times of every call since the previous agh_get_timing (segments between consecutive HIP
+  // events recorded on the launch stream; a "start" event opens each call), then forgets them.
   if (!ctx || !out)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
@@ -652,18 +673,21 @@ int agh_get_timing(agh_ctx* ctx, agh_timing* out)
     return AGH_OK;
   HIPCHK(c, hipEventSynchronize(c->ev[c->ev_used - 1]));
   int k = 0;
-  for (int i = 1; i < c->ev_used && k < AGH_TIMING_SLOTS; i++)
+  for (int i = 1; i < c->ev_used; i++)
   {
+    if (std::strcmp(c->ev_name[i], "start") == 0)
+      continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]) != hipSuccess)
       ms = 0.f;
-    // merge repeated names (the normals pass runs the taubin kernels once per batch)
     int slot = -1;
     for (int j = 0; j < k; j++)
       if (std::strcmp(out->name[j], c->ev_name[i]) == 0)
         slot = j;
     if (slot < 0)
     {
+      if (k >= AGH_TIMING_SLOTS)
+        continue;
       slot = k++;
       out->name[slot] = c->ev_name[i];
     }
@@ -671,6 +695,8 @@ int agh_get_timing(agh_ctx* ctx, agh_timing* out)
     out->total_ms += ms;
   }
   out->n = k;
+  c->ev_used = 0;
+  c->ev_name.clear();
   return AGH_OK;
 }
 

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int
       mx[a] = fmaxf(mx[a], p[a]);
     }
   }
+  __shared__ float smn[4][3], smx[4][3];
   for (int a = 0; a < 3; a++)
     for (int o = 32; o > 0; o >>= 1)
     {
@@ -40,9 +41,18 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int
   if ((threadIdx.x & 63) == 0)
     for (int a = 0; a < 3; a++)
     {
-      atomicMin(&d->bbox[a], enc_float(mn[a]));
-      atomicMax(&d->bbox[3 + a], enc_float(mx[a]));
+      smn[threadIdx.x >> 6][a] = mn[a];
+      smx[threadIdx.x >> 6][a] = mx[a];
     }
+  __syncthreads();
+  if (threadIdx.x < 3)  // one atomic pair per block and axis: same-address atomics cost ~12 ns each
+  {
+    const int a = threadIdx.x;
+    const float lo = fminf(fminf(smn[0][a], smn[1][a]), fminf(smn[2][a], smn[3][a]));
+    const float hi = fmaxf(fmaxf(smx[0][a], smx[1][a]), fmaxf(smx[2][a], smx[3][a]));
+    atomicMin(&d->bbox[a], enc_float(lo));
+    atomicMax(&d->bbox[3 + a], enc_float(hi));
+  }
 }
 
 __global__ void k_desc_finish(GridDesc* d, double base_cell, int64_t n)
@@ -202,7 +212,7 @@ int grid_build(Ctx* c, hipStream_t st)
   hipMemsetAsync(c->d_cell_count, 0, sizeof(int) * kCellCap, st);
   hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(1), 0, st, c->d_desc);
   if (n > 0)
-    hipLaunchKernelGGL(k_bbox, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc);
+    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblk, 128)), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc);
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
   hipLaunchKernelGGL(k_desc_finish, dim3(1), dim3(1), 0, st, c->d_desc, base_cell, n);

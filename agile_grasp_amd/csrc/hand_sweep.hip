@@ -54,27 +54,31 @@ __device__ __forceinline__ int wave_sum_i32(int v)
   return v;
 }
 
-template <int CAPC>
+constexpr int kTile = 1536;  // cropped points staged in LDS at a time (24 KiB of double2 + 6 KiB of ids): 3 blocks/CU
+
+__device__ __forceinline__ unsigned lowmask(int n)
+{
+  return n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+}
+
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
-  int S, float r2f, double rpad, int first_class, const double* __restrict__ normals, double img_cell,
-  int32_t* __restrict__ nh, int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots,
-  uint32_t* __restrict__ images)
+  int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
+  int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop)
 {
-  __shared__ double2 pts[CAPC];
-  __shared__ unsigned pid[CAPC];
+  __shared__ double2 pts[kTile];
+  __shared__ unsigned pid[kTile];
   __shared__ RowTable rt;
   __shared__ HandGeom G;
   __shared__ double thr_s[64];
   __shared__ OriState ori[8];
   __shared__ unsigned regmask[8][44];
+  __shared__ unsigned pre_s[4][88], suf_s[4][88];
   __shared__ unsigned img[8][kImageWords + 2];
-  __shared__ int cnt_ball, cnt_crop;
+  __shared__ int cnt_ball, cnt_crop, any_hand;
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (!first_class && status[s] != kStatusOverflow)
-    return;
   const agh_frame F = frames[s];
   if (!F.valid)
   {
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   {
     cnt_ball = 0;
     cnt_crop = 0;
+    any_hand = 0;
   }
   for (int k = tid; k < 8 * 44; k += 256)
     (&regmask[0][0])[k] = 0u;
@@ -132,60 +137,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     }
   }
   const double hh = G.hand_height;
-  // ---- gather, FLANN filter, hand-frame transform, crop (rotating_hand.cpp:26,37-51) ----
   const int total = rt.total;
-  for (int j0 = 0; j0 < total; j0 += 256)
-  {
-    const int j = j0 + tid;
-    bool inball = false, keep = false;
-    double tx = 0.0, ty = 0.0;
-    unsigned w = 0;
-    if (j < total)
-    {
-      const float4 p = gv.sorted[row_lookup(rt, j)];
-      const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
-      inball = d2 < r2f;
-      if (inball)
-      {
-        const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
-        tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
-        ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
-        const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
-        keep = (tz > -1.0 * hh) && (tz < hh);
-        w = __float_as_uint(p.w);
-      }
-    }
-    const unsigned long long mb = __ballot(inball), mk = __ballot(keep);
-    int base = 0;
-    if (lane == 0)
-    {
-      if (mb)
-        atomicAdd(&cnt_ball, __popcll(mb));
-      if (mk)
-        base = atomicAdd(&cnt_crop, __popcll(mk));
-    }
-    base = __shfl(base, 0);
-    if (keep)
-    {
-      const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
-      if (k < CAPC)
-      {
-        pts[k] = make_double2(tx, ty);
-        pid[k] = w;
-      }
-    }
-  }
-  __syncthreads();
-  const int nc = cnt_crop;
-  if (nc > CAPC)
-  {
-    if (tid == 0)
-    {
-      status[s] = kStatusOverflow;
-      nh[s] = cnt_ball;
-    }
-    return;
-  }
   // ---- orientation setup (rotating_hand.cpp:86-104) ----
   if (tid < 8)
   {
@@ -207,7 +159,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     }
     const double d0 = (O.approach[0] * cams[0][0] + O.approach[1] * cams[0][1]) + O.approach[2] * cams[0][2];
     const double d1 = (O.approach[0] * cams[1][0] + O.approach[1] * cams[1][1]) + O.approach[2] * cams[1][2];
-    O.rejected = ((d0 > 0 && d1 > 0) || nc == 0) ? 1 : 0;
+    O.rejected = (d0 > 0 && d1 > 0) ? 1 : 0;  // rotating_hand.cpp:99-102
     O.cs = cs;
     O.sn = sn;
     O.has_hand = 0;
@@ -216,201 +168,367 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     O.ymin = 0.0;
     O.ymax = 0.0;
   }
-  __syncthreads();
+  if (debug_stop == 1)
+    return;
+
+  // One batch of 512 candidates (two per thread, both loads in flight together): FLANN filter, hand-frame
+  // transform, crop (rotating_hand.cpp:26,37-51), append to the LDS tile.
+  int row_cur = 0;
+  auto batch = [&](int j0, bool count_ball) {
+    float4 pp[2];
+    bool have[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+    {
+      const int j = j0 + u * 256 + tid;
+      have[u] = j < total;
+      if (have[u])
+        pp[u] = gv.sorted[row_advance(rt, j, row_cur)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+    {
+      bool inball = false, keep = false;
+      double tx = 0.0, ty = 0.0;
+      unsigned w = 0;
+      if (have[u])
+      {
+        const float4 p = pp[u];
+        const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
+        inball = d2 < r2f;
+        if (inball)
+        {
+          const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
+          tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+          ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+          const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
+          keep = (tz > -1.0 * hh) && (tz < hh);
+          w = __float_as_uint(p.w);
+        }
+      }
+      const unsigned long long mk = __ballot(keep);
+      int base = 0;
+      if (count_ball)
+      {
+        const unsigned long long mb = __ballot(inball);
+        if (lane == 0 && mb)
+          atomicAdd(&cnt_ball, __popcll(mb));
+      }
+      if (lane == 0 && mk)
+        base = atomicAdd(&cnt_crop, __popcll(mk));
+      base = __shfl(base, 0);
+      if (keep)
+      {
+        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
+        pts[k] = make_double2(tx, ty);
+        pid[k] = w;
+      }
+    }
+  };
+  // Fill the LDS tile from candidate j0 on; returns the tile's point count (block-uniform).
+  auto fill = [&](int& j0, bool count_ball) -> int {
+    for (;;)
+    {
+      __syncthreads();
+      const int c = cnt_crop;
+      __syncthreads();
+      const int m = (kTile - c) / 512;  // batches that are certain to fit
+      if (m == 0 || j0 >= total)
+        return c;
+      for (int b = 0; b < m && j0 < total; b++, j0 += 512)
+        batch(j0, count_ball);
+    }
+  };
+
   const int K = G.n_depths;
-  // ---- pass 1: classify every cropped point once per orientation ----
+  // ---- pass A: classify every cropped point once per orientation (tiles of kTile points) ----
+  double ymin_w[2] = { INFINITY, INFINITY }, ymax_w[2] = { -INFINITY, -INFINITY };
+  int j0 = 0, ntiles = 0, nc = 0;
+  for (;;)
+  {
+    nc = fill(j0, true);
+    if (debug_stop == 2)
+      return;
+    for (int oo = 0; oo < 2; oo++)
+    {
+      const int o = wave + 4 * oo;
+      if (ori[o].rejected)
+        continue;
+      const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
+      double ymin = ymin_w[oo], ymax = ymax_w[oo];
+      const double d_first = G.depths[0];
+      for (int t0 = lane; t0 < nc; t0 += 256)
+      {
+        // four independent points per lane so that the dependent LDS look-ups below overlap
+        double xr[4], yr[4];
+        int yk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+          const int t = t0 + 64 * u;
+          const bool act = t < nc;
+          const double2 p = pts[act ? t : 0];
+          xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
+          yr[u] = act ? (sn * p.x + cs * p.y) : INFINITY;
+          if (act)
+          {
+            ymin = fmin(ymin, yr[u]);
+            ymax = fmax(ymax, yr[u]);
+          }
+          // depth class yk = #{k : d_k <= y}  (y < d_k  <=>  k >= yk): arithmetic guess, then exact fix-up on the table
+          int g = (int) fmin(fmax(floor((yr[u] - d_first) * 200.0) + 1.0, 0.0), (double) K);
+          while (g > 0 && yr[u] < G.depths[g - 1])
+            g--;
+          while (g < K && yr[u] >= G.depths[g])
+            g++;
+          yk[u] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (yk[u] < K)
+          {
+            int c = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+              if (thr_s[c + step - 1] < xr[u])
+                c += step;
+            const int e = (thr_s[c] == xr[u]) ? 1 : 0;  // c <= n_thr <= 40 < 64
+            const int key = 2 * c + e;
+            atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk[u]));
+          }
+      }
+      ymin_w[oo] = ymin;
+      ymax_w[oo] = ymax;
+    }
+    ntiles++;
+    if (j0 >= total)
+      break;
+    __syncthreads();
+    if (tid == 0)
+      cnt_crop = 0;
+  }
+  if (debug_stop == 3)
+    return;
+  // ---- finger / hand / deepen logic, wave-parallel (finger_hand.cpp:20-115,173-233) ----
+  // lane = region key for the prefix / suffix ORs, lane = finger slot for the finger masks, lane = depth for the
+  // back-of-hand collision test.  All integer logic on the (region, depth) bit table.
+  const int R = 2 * G.n_thr + 1;
   for (int oo = 0; oo < 2; oo++)
   {
     const int o = wave + 4 * oo;
     if (ori[o].rejected)
       continue;
-    const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
-    double ymin = INFINITY, ymax = -INFINITY;
-    for (int t = lane; t < nc; t += 64)
+    const double ymin = wave_min_f64(ymin_w[oo]);
+    const double ymax = wave_max_f64(ymax_w[oo]);
+    auto half = [&](int key) -> unsigned { return (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu; };
+    const unsigned v0 = lane < R ? half(lane) : 0u;
+    const unsigned v1 = (64 + lane) < R ? half(64 + lane) : 0u;
+    unsigned p0 = v0, p1 = v1, s0 = v0, s1 = v1;
+    for (int d = 1; d < 64; d <<= 1)
     {
-      const double2 p = pts[t];
-      const double xr = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
-      const double yr = sn * p.x + cs * p.y;
-      ymin = fmin(ymin, yr);
-      ymax = fmax(ymax, yr);
-      int yk = 0;
-      for (int k = 0; k < K; k++)
-        yk += (yr >= G.depths[k]) ? 1 : 0;  // y < d_k  <=>  k >= yk
-      if (yk < K)
+      const unsigned a = __shfl_up(p0, d), b = __shfl_up(p1, d);
+      const unsigned c2 = __shfl_down(s0, d), e2 = __shfl_down(s1, d);
+      if (lane >= d)
       {
-        int c = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (thr_s[c + step - 1] < xr)
-            c += step;
-        const int e = (thr_s[c] == xr) ? 1 : 0;  // c <= n_thr <= 40 < 64
-        const int key = 2 * c + e;
-        atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
+        p0 |= a;
+        p1 |= b;
+      }
+      if (lane + d < 64)
+      {
+        s0 |= c2;
+        s1 |= e2;
       }
     }
-    ymin = wave_min_f64(ymin);
-    ymax = wave_max_f64(ymax);
+    p1 |= __shfl(p0, 63);
+    s0 |= __shfl(s1, 0);
+    pre_s[wave][lane] = p0;
+    suf_s[wave][lane] = s0;
+    if (lane < 24)
+    {
+      pre_s[wave][64 + lane] = p1;
+      suf_s[wave][64 + lane] = s1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    unsigned Fm = 0;
+    if (lane < 20)
+    {
+      const int lo = G.lo_idx[lane], hi = G.hi_idx[lane];
+      unsigned gap = 0;
+      for (int key = 2 * lo + 2; key <= 2 * hi; key++)  // points with fs_i < x < fs_i + w
+        gap |= half(key);
+      unsigned side;
+      if (lane <= 10)  // the reference's `i <= m / 2` (finger_hand.cpp:72): slot 10 uses the right-side rule
+        side = (2 * hi + 2 < R) ? suf_s[wave][2 * hi + 2] : 0u;  // x > fs_i + w
+      else
+        side = pre_s[wave][2 * lo];  // x < fs_i
+      const int mingap = gap ? (__ffs(gap) - 1) : 32, minside = side ? (__ffs(side) - 1) : 32;
+      // finger_i at depth k  <=>  no gap point with y < d_k  and  some side point with y < d_k
+      Fm = lowmask(min(mingap, K)) & ~lowmask(minside);
+    }
+    const bool collide = lane < K && (ymin < G.depths[lane]) && (ymin < G.backs[lane]);  // finger_hand.cpp:29-42
+    const unsigned Cm = (unsigned) __ballot(collide);
+    const unsigned Fpair = __shfl(Fm, (lane + 10) & 63);
+    const unsigned H = (lane < 10) ? (Fm & Fpair & ~Cm & lowmask(K)) : 0u;  // hand_j over depths
+    const unsigned hand0 = (unsigned) __ballot((H & 1u) != 0);
+    int e = -1, last = 0;
+    if (hand0)
+    {
+      const int cnt = __popc(hand0);
+      int pick = (cnt + 1) / 2 - 1;  // ceil(cnt / 2.0) - 1 (finger_hand.cpp:190)
+      unsigned hm = hand0;
+      while (pick-- > 0)
+        hm &= hm - 1u;
+      e = __ffs(hm) - 1;
+      const unsigned He = __shfl(H, e);
+      last = __ffs(~(He >> 1)) - 1;  // consecutive depths 1.. at which hand_e still exists (finger_hand.cpp:204-225)
+    }
     if (lane == 0)
     {
       ori[o].ymin = ymin;
       ori[o].ymax = ymax;
+      ori[o].has_hand = (e >= 0) ? 1 : 0;
+      ori[o].e = e;
+      ori[o].last = last;
+      if (e >= 0)
+        any_hand = 1;
     }
   }
   __syncthreads();
-  // ---- finger / hand / deepen logic on one lane per orientation (finger_hand.cpp:20-115,173-233) ----
-  if (tid < 8 && !ori[tid].rejected)
-  {
-    const int o = tid;
-    const double ymin = ori[o].ymin;
-    unsigned gapbits[20], sidebits[20];
-    const int R = 2 * G.n_thr + 1;
-    for (int i = 0; i < 20; i++)
-    {
-      const int lo = G.lo_idx[i], hi = G.hi_idx[i];
-      unsigned gb = 0, sb = 0;
-      for (int key = 2 * lo + 2; key <= 2 * hi; key++)
-        gb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
-      if (i <= 10)  // the reference's `i <= m / 2` (finger_hand.cpp:72): slot 10 uses the right-side rule
-      {
-        for (int key = 2 * hi + 2; key < R; key++)
-          sb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
-      }
-      else
-      {
-        for (int key = 0; key <= 2 * lo; key++)
-          sb |= (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu;
-      }
-      gapbits[i] = gb;
-      sidebits[i] = sb;
-    }
-    int e = -1, last = 0;
-    for (int k = 0; k < K; k++)
-    {
-      const unsigned upto = (2u << k) - 1u;  // depth classes 0..k  <=>  y < d_k
-      unsigned hand = 0;
-      const bool collide = (ymin < G.depths[k]) && (ymin < G.backs[k]);  // finger_hand.cpp:29-42
-      if (!collide)
-      {
-        unsigned fingers = 0;
-        for (int i = 0; i < 20; i++)
-          if (!(gapbits[i] & upto) && (sidebits[i] & upto))
-            fingers |= 1u << i;
-        hand = fingers & (fingers >> 10) & 0x3ffu;
-      }
-      if (k == 0)
-      {
-        if (!hand)
-          break;
-        const int cnt = __popc(hand);
-        int pick = (int) ceil(cnt / 2.0) - 1;  // finger_hand.cpp:190
-        unsigned hm = hand;
-        while (pick-- > 0)
-          hm &= hm - 1u;
-        e = __ffs(hm) - 1;
-      }
-      else
-      {
-        if (!((hand >> e) & 1u))
-          break;
-        last = k;
-      }
-    }
-    ori[o].has_hand = (e >= 0) ? 1 : 0;
-    ori[o].e = e;
-    ori[o].last = last;
-  }
-  __syncthreads();
-  // ---- pass 2: grasp parameters, box, antipodal counts, image (rotating_hand.cpp:111-170) ----
+  if (debug_stop == 4)
+    return;
+  // ---- pass B: grasp parameters, box, antipodal counts, image (rotating_hand.cpp:111-170) ----
   const int cam_s = cam_source ? (cam_source[samples[s]] & 1) : 0;  // hands_cam_source(i) = pts_cam_source(indices[i])
+  double wmin_w[2] = { 100000.0, 100000.0 }, wmax_w[2] = { -100000.0, -100000.0 };
+  int nbox_w[2] = { 0, 0 }, numl_w[2] = { 0, 0 }, numr_w[2] = { 0, 0 };
+  double surf_w[2][3], bot_w[2][3];
+  bool posx_w[2] = { false, false };
+  for (int oo = 0; oo < 2; oo++)
+  {
+    const OriState& O = ori[wave + 4 * oo];
+    const int e = O.e < 0 ? 0 : O.e;
+    const double hor_pos = (G.hand_outer_diameter / 2.0) + (G.fs[e] / 1);  // finger_hand.cpp:127-132, one-hot hand_
+    double s2c[3];
+    for (int i = 0; i < 3; i++)
+    {
+      surf_w[oo][i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;  // rotating_hand.cpp:118-121
+      bot_w[oo][i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymax) + O.T[i][2] * 0.0;
+      s2c[i] = (surf_w[oo][i] + F.sample[i]) - G.cam_origin[cam_s][i];  // learning.cpp:382-383
+    }
+    posx_w[oo] = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
+  }
+  if (any_hand)
+  {
+    const bool refill = ntiles > 1;  // a single tile is still resident in LDS
+    if (refill)
+    {
+      __syncthreads();
+      if (tid == 0)
+        cnt_crop = 0;
+      j0 = 0;
+      row_cur = 0;
+    }
+    for (;;)
+    {
+      if (refill)
+        nc = fill(j0, false);
+      for (int oo = 0; oo < 2; oo++)
+      {
+        const int o = wave + 4 * oo;
+        const OriState& O = ori[o];
+        if (O.rejected || !O.has_hand)
+          continue;
+        const int e = O.e, last = O.last;
+        const double cs = O.cs, ms = -1.0 * O.sn, sn = O.sn;
+        const double left = G.fs[e], right = G.fs[10 + e];
+        const double box_y = G.boxy[last];
+        const double bite = G.init_bite;
+        const double sfx = surf_w[oo][0], sfy = surf_w[oo][1];
+        const bool pos_x = posx_w[oo];
+        double wmin = wmin_w[oo], wmax = wmax_w[oo];
+        int nbox = 0, numl = 0, numr = 0;
+        for (int t = lane; t < nc; t += 64)
+        {
+          const double2 p = pts[t];
+          const double xr = cs * p.x + ms * p.y;
+          const double yr = sn * p.x + cs * p.y;
+          if (yr < bite && xr > left && xr < right)  // finger_hand.cpp:158-167
+          {
+            wmin = fmin(wmin, xr);
+            wmax = fmax(wmax, xr);
+          }
+          if (yr < box_y)  // rotating_hand.cpp:125-130
+          {
+            nbox++;
+            const double bx = xr - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
+            const double by = yr - sfy;
+            const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
+            const double vy = (by - 0.0) / img_cell;
+            int hc = (int) floor(hx), vc = (int) floor(vy);
+            hc = min(99, max(0, hc));
+            vc = min(79, max(0, vc));
+            const int bit = (79 - vc) * 100 + hc;
+            atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
+            if (normals)
+            {
+              const double* nn = normals + 3 * (int64_t) (pid[t] >> 1);
+              const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
+              const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
+              const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
+              const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
+              numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
+              numr += (nxr > G.cos_antipodal) ? 1 : 0;
+            }
+          }
+        }
+        wmin_w[oo] = wmin;
+        wmax_w[oo] = wmax;
+        nbox_w[oo] += nbox;
+        numl_w[oo] += numl;
+        numr_w[oo] += numr;
+      }
+      if (!refill || j0 >= total)
+        break;
+      __syncthreads();
+      if (tid == 0)
+        cnt_crop = 0;
+    }
+  }
+  // ---- results ----
   for (int oo = 0; oo < 2; oo++)
   {
     const int o = wave + 4 * oo;
+    const OriState& O = ori[o];
     agh_hypothesis h;
     memset(&h, 0, sizeof(h));
     h.sample = s;
     h.orientation = o;
-    if (ori[o].rejected || !ori[o].has_hand)
+    if (O.rejected || !O.has_hand)
     {
       if (lane == 0)
         slots[(int64_t) s * 8 + o] = h;
       continue;
     }
-    const OriState& O = ori[o];
-    const int e = O.e, last = O.last;
-    const double cs = O.cs, ms = -1.0 * O.sn, sn = O.sn;
-    const double left = G.fs[e], right = G.fs[10 + e];
-    const double hor_pos = (G.hand_outer_diameter / 2.0) + (G.fs[e] / 1);  // finger_hand.cpp:127-132, one-hot hand_
-    double surface[3], bottom[3];
-    for (int i = 0; i < 3; i++)
-    {
-      surface[i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;  // rotating_hand.cpp:118-121
-      bottom[i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymax) + O.T[i][2] * 0.0;
-    }
-    double s2c[3];
-    for (int i = 0; i < 3; i++)
-      s2c[i] = (surface[i] + F.sample[i]) - G.cam_origin[cam_s][i];  // learning.cpp:382-383
-    const bool pos_x = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
-    const double box_y = G.boxy[last];
-    const double bite = G.init_bite;
-    double wmin = 100000.0, wmax = -100000.0;
-    int nbox = 0, numl = 0, numr = 0;
-    for (int t = lane; t < nc; t += 64)
-    {
-      const double2 p = pts[t];
-      const double xr = cs * p.x + ms * p.y;
-      const double yr = sn * p.x + cs * p.y;
-      if (yr < bite && xr > left && xr < right)  // finger_hand.cpp:158-167
-      {
-        wmin = fmin(wmin, xr);
-        wmax = fmax(wmax, xr);
-      }
-      if (yr < box_y)  // rotating_hand.cpp:125-130
-      {
-        nbox++;
-        const double bx = xr - surface[0];  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
-        const double by = yr - surface[1];
-        const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
-        const double vy = (by - 0.0) / img_cell;
-        int hc = (int) floor(hx), vc = (int) floor(vy);
-        hc = min(99, max(0, hc));
-        vc = min(79, max(0, vc));
-        const int bit = (79 - vc) * 100 + hc;
-        atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
-        if (normals)
-        {
-          const double* nn = normals + 3 * (int64_t) (pid[t] >> 1);
-          const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
-          const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
-          const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
-          const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
-          numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
-          numr += (nxr > G.cos_antipodal) ? 1 : 0;
-        }
-      }
-    }
-    wmin = wave_min_f64(wmin);
-    wmax = wave_max_f64(wmax);
-    nbox = wave_sum_i32(nbox);
-    numl = wave_sum_i32(numl);
-    numr = wave_sum_i32(numr);
+    const double wmin = wave_min_f64(wmin_w[oo]), wmax = wave_max_f64(wmax_w[oo]);
+    const int nbox = wave_sum_i32(nbox_w[oo]), numl = wave_sum_i32(numl_w[oo]), numr = wave_sum_i32(numr_w[oo]);
     for (int i = 0; i < 3; i++)
     {
       h.axis[i] = F.axis[i];
       h.approach[i] = O.approach[i];
       h.binormal[i] = O.binormal[i];
-      h.bottom[i] = bottom[i] + F.sample[i];  // rotating_hand.cpp:153-154
-      h.surface[i] = surface[i] + F.sample[i];
+      h.bottom[i] = bot_w[oo][i] + F.sample[i];  // rotating_hand.cpp:153-154
+      h.surface[i] = surf_w[oo][i] + F.sample[i];
     }
     h.width = wmax - wmin;
     h.cam_source = cam_s;
     h.n_in_box = nbox;
     const bool full = numl > 6 && numr > 6;
-    const bool half = numl > 6 || numr > 6;
-    h.half_antipodal = (half || full) ? 1 : 0;
+    const bool half_a = numl > 6 || numr > 6;
+    h.half_antipodal = (half_a || full) ? 1 : 0;
     h.full_antipodal = full ? 1 : 0;
     h.valid = 1;
-    h.finger_index = e;
-    h.depth_index = last;
+    h.finger_index = O.e;
+    h.depth_index = O.last;
     if (lane == 0)
       slots[(int64_t) s * 8 + o] = h;
     __builtin_amdgcn_wave_barrier();
@@ -530,10 +648,8 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const int Si = (int) S;
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
-  hipLaunchKernelGGL(k_hand_sweep<2048>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-    rpad, 1, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images);
-  hipLaunchKernelGGL(k_hand_sweep<6144>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-    rpad, 0, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images);
+  hipLaunchKernelGGL(k_hand_sweep, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f, rpad, nrm,
+    img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep);
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -326,6 +326,7 @@ int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st)
 {
   if (n_hyp_cap <= 0)
     return AGH_OK;
+  timing_mark(c, "start", st);
   hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n_hyp_cap), dim3(256), 0, st, c->d_images, c->d_slot_index, c->d_nout_last,
     c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out);
   timing_mark(c, "hog_svm", st);

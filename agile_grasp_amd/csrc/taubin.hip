@@ -7,7 +7,7 @@
 // Three kernels, one launch each per batch of samples:
 //   k_taubin_moments<CAP>  one 256-thread workgroup per sample: coalesced float4 reads of the cell-sorted cloud
 //                          for the <= 16 grid rows the ball touches, FLANN float32 distance filter, LDS compaction,
-//                          LDS bitonic sort into the radius search's (d2, index) order, then the 37 distinct sums
+//                          LDS bucket sort into the radius search's (d2, index) order, then the 37 distinct sums
 //                          behind M and N accumulated SEQUENTIALLY in that order (64-neighbour chunks: all four
 //                          waves form the products, 37 lanes run the 37 dependent add chains) -- the same fp64
 //                          operation order as the reference loop, so the sums are bit-identical to the CPU path.
@@ -23,20 +23,24 @@
 namespace agh
 {
 
+constexpr int kSortBins = 256;  // distance buckets of the neighbour sort (= workgroup size)
+
 // ---------------------------------------------------------------------------------------------------------------
 // K1a
 // ---------------------------------------------------------------------------------------------------------------
 template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
-  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride)
+  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop)
 {
   __shared__ float4 stage[CAP];
   __shared__ unsigned long long key[CAP];
   __shared__ unsigned short slot[CAP];
+  __shared__ unsigned short perm[CAP];
   __shared__ double termbuf[64 * kNumSums];
   __shared__ RowTable rt;
   __shared__ int count;
+  __shared__ int hist[kSortBins + 1], fillc[kSortBins], wsum[4];
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,6 +50,11 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   if (tid == 0)
     count = 0;
+  for (int k = tid; k < kSortBins; k += 256)
+  {
+    hist[k] = 0;
+    fillc[k] = 0;
+  }
   build_rows(gv, qx, qy, qz, rpad, rt);
   if (rt.bad)
   {
@@ -56,8 +65,10 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     }
     return;
   }
+  const float binscale = (float) kSortBins / r2f;  // monotone map of d2 in [0, r2f) onto the sort bins
   // ---- gather + FLANN distance filter + compaction into LDS ----
   const int total = rt.total;
+  int row_cur = 0;
   for (int j0 = 0; j0 < total; j0 += 256)
   {
     const int j = j0 + tid;
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     float d2 = 0.f;
     if (j < total)
     {
-      p = gv.sorted[row_lookup(rt, j)];
+      p = gv.sorted[row_advance(rt, j, row_cur)];
       d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
       pass = d2 < r2f;
     }
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
       {
         stage[k] = p;
         key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
-        slot[k] = (unsigned short) k;
+        atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
       }
     }
   }
@@ -97,38 +108,54 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     }
     return;
   }
-  // ---- bitonic sort of (key, slot): ascending (d2, index) = FLANN's sorted radius-search order ----
-  int P = 1;
-  while (P < n)
-    P <<= 1;
-  for (int i = n + tid; i < P; i += 256)
+  if (debug_stop == 1)
+    return;
+  // ---- sort into FLANN's sorted radius-search order: ascending (d2, index) ----
+  // Distance-bucket counting sort (d2 is ~uniform over the ball's bins for surface data), then an exact rank inside
+  // each bucket by comparing the full 64-bit keys (d2 bits, index) -- a few comparisons per point, three barriers.
   {
-    key[i] = ~0ull;
-    slot[i] = 0;
+    const int lane_ = tid & 63, w_ = tid >> 6;
+    const int v = hist[tid];  // kSortBins == blockDim.x
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up(inc, o);
+      if (lane_ >= o)
+        inc += t;
+    }
+    if (lane_ == 63)
+      wsum[w_] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w_; k++)
+      base += wsum[k];
+    hist[tid] = base + inc - v;  // exclusive start of bin tid
+    if (tid == 0)
+      hist[kSortBins] = n;
+    __syncthreads();
+  }
+  for (int k = tid; k < n; k += 256)
+  {
+    const float d2 = __uint_as_float((unsigned) (key[k] >> 32));
+    const int b = min(kSortBins - 1, (int) (d2 * binscale));
+    perm[hist[b] + atomicAdd(&fillc[b], 1)] = (unsigned short) k;
   }
   __syncthreads();
-  for (int k = 2; k <= P; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1)
-    {
-      for (int i = tid; i < P; i += 256)
-      {
-        const int ixj = i ^ j;
-        if (ixj > i)
-        {
-          const unsigned long long a = key[i], b = key[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up)
-          {
-            key[i] = b;
-            key[ixj] = a;
-            const unsigned short sa = slot[i], sb = slot[ixj];
-            slot[i] = sb;
-            slot[ixj] = sa;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  for (int g = tid; g < n; g += 256)
+  {
+    const int k = perm[g];
+    const unsigned long long mine = key[k];
+    const float d2 = __uint_as_float((unsigned) (mine >> 32));
+    const int b = min(kSortBins - 1, (int) (d2 * binscale));
+    const int bs = hist[b], be = hist[b + 1];
+    int rank = bs;
+    for (int g2 = bs; g2 < be; g2++)
+      rank += (key[perm[g2]] < mine) ? 1 : 0;
+    slot[rank] = (unsigned short) k;
+  }
+  __syncthreads();
+  if (debug_stop == 2)
+    return;
   // ---- sorted neighbour list to global (consumed by k_taubin_frame) ----
   for (int i = tid; i < n; i += 256)
     nbr[(int64_t) s * nbr_stride + i] = stage[slot[i]];
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
-  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out)
+  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin)
 {
   __shared__ double nx[CAP], ny[CAP], nz[CAP];
   __shared__ int camcnt[2];
@@ -570,7 +597,12 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nt[s];
   const double* ev = eig + (int64_t) s * 12;
-  const bool valid = status[s] == kStatusOk && ev[11] != 0.0 && n <= CAP;
+  const bool ok = status[s] == kStatusOk && ev[11] != 0.0;
+  // capacity classes: this instantiation owns the valid samples with nmin < n <= CAP; the first one (nmin == 0) also
+  // writes the records of invalid samples
+  if (ok ? (n <= nmin || n > CAP) : (nmin != 0))
+    return;
+  const bool valid = ok;
   const float* qp = xyz + (int64_t) samples[s] * stride;
   if (!valid)
   {
@@ -811,14 +843,18 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
     first = false;
   }
   hipLaunchKernelGGL(k_taubin_moments<1024>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
   hipLaunchKernelGGL(k_taubin_moments<2048>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride);
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
+  hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
   timing_mark(c, "taubin_moments", st);
+  if (c->debug_stop_moments)
+    return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
   hipLaunchKernelGGL(k_flag_overflow, dim3((Si + 255) / 256), dim3(256), 0, st, c->d_status, Si, c->d_flags);
   hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig);
   timing_mark(c, "taubin_eigen", st);
@@ -828,7 +864,10 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   const double* co = &c->p.cam_origin[0][0];
   hipLaunchKernelGGL(k_taubin_frame<2048>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0);
+  hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
+    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 2048);
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

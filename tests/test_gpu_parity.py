@@ -1,0 +1,273 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Tolerance: none.  Integer fields, labels, images and every floating-point field (fp64 frames / hypotheses, fp32 HOG
+descriptors, fp64 SVM sums) are compared with exact equality -- the kernels evaluate the oracle's operation order
+without FMA contraction, and agh_selftest_math checks the IEEE assumptions on the device.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FLOAT_FIELDS = ("axis", "approach", "binormal", "bottom", "surface", "width")
+INT_FIELDS = ("sample", "orientation", "cam_source", "n_in_box", "half_antipodal", "full_antipodal", "valid",
+              "finger_index", "depth_index")
+
+
+def _ctx(sc, **kw):
+    from agile_grasp_amd import binding
+
+    return binding.Context(sc.cam_origins, **kw)
+
+
+def assert_hyps_equal(got, ref):
+    assert len(got) == len(ref)
+    for f in INT_FIELDS + FLOAT_FIELDS:
+        assert np.array_equal(got[f], ref[f]), f
+
+
+def assert_frames_equal(got, ref):
+    for f in ("valid", "n_nb", "majority_cam", "max_index", "sample", "params", "eigenvalue", "normal", "axis",
+              "binormal"):
+        assert np.array_equal(got[f], ref[f]), f
+
+
+def test_device_arithmetic_is_ieee_identical(tiny_scene):
+    ctx = _ctx(tiny_scene)
+    assert ctx.selftest_math(1 << 21, seed=7) == 0
+
+
+@pytest.mark.parametrize("scene_name", ["tiny", "small"])
+def test_full_path_bit_exact(scene_name, svm_model):
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config(scene_name)
+    w, rho = svm_model
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    nt, nh = ctx.neighbor_counts()
+    assert np.array_equal(nt, ref["frames"]["n_nb"]) and np.array_equal(nh, ref["nh"])
+    assert len(hyps) > 10
+    assert_hyps_equal(hyps, ref["hyps"])
+    assert np.array_equal(ctx.images(), ref["images"])
+    ctx.load_svm(w, rho)
+    keep = ctx.classify()
+    desc, sums = ctx.hog()
+    okeep, osums = O.classify(ref["images"], w, rho)
+    assert np.array_equal(desc, np.stack([O.hog(i) for i in ref["images"]]))
+    assert np.array_equal(sums, osums) and np.array_equal(keep, okeep)
+    assert 0 < keep.sum() < keep.size
+
+
+def test_svm_file_loader_matches_memory_loader(tiny_scene, svm_model):
+    sc = tiny_scene
+    w, rho = svm_model
+    a, b = _ctx(sc), _ctx(sc)
+    for c in (a, b):
+        c.set_cloud(sc.xyz, sc.cam)
+        c.find_hands(sc.samples)
+    a.load_svm(w, rho)
+    b.load_svm_file(os.path.join(GOLD, "svm_032015_linear_20_20_same"))
+    assert np.array_equal(a.hog()[1], b.hog()[1])
+
+
+def test_antipodal_pass_bit_exact(tiny_scene):
+    """calculates_antipodal: normals for ALL points (r = 0.01) then Antipodal::evaluateGrasp labels."""
+    from oracle import oracle_py as O
+
+    sc = tiny_scene
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    sub = sc.samples[:40]
+    hyps = ctx.find_hands(sub, calculates_antipodal=True)
+    p = O.default_params(sc.cam_origins)
+    ref = O.find_hands(p, sc.xyz, sc.cam, sub, calculates_antipodal=True)
+    assert_hyps_equal(hyps, ref["hyps"])
+    assert hyps["half_antipodal"].any()
+    # the per-point normals themselves
+    allp = np.arange(sc.n, dtype=np.int32)
+    fr = O.fit_frames(p, sc.xyz, sc.cam, allp, 0.01)
+    exp = np.where(fr["valid"][:, None] != 0, fr["normal"], 0.0)
+    f2 = O.fit_frames(p, sc.xyz, sc.cam, sub, 0.03)
+    exp[sub] = np.where(f2["valid"][:, None] != 0, f2["normal"], exp[sub])  # hand_search.cpp:102 in the sample pass
+    assert np.array_equal(ctx.normals(), exp)
+
+
+def test_rand50_mode_bit_exact(tiny_scene):
+    """HandSearch's default (uses_determinstic_normal_estimation_ = false): 50 glibc rand() draws per sample."""
+    from agile_grasp_amd import binding
+    from oracle import oracle_py as O
+
+    sc = tiny_scene
+    for seed in (1, 42):
+        ctx = _ctx(sc, normals_mode=binding.NORMALS_RAND50, rand_seed=seed)
+        ctx.set_cloud(sc.xyz, sc.cam)
+        hyps = ctx.find_hands(sc.samples)
+        p = O.default_params(sc.cam_origins, normals_mode=O.NORMALS_RAND50, rand_seed=seed)
+        ref = O.find_hands(p, sc.xyz, sc.cam, sc.samples)
+        assert_frames_equal(ctx.frames(), ref["frames"])
+        assert_hyps_equal(hyps, ref["hyps"])
+
+
+def test_pointxyzrgba_stride(tiny_scene):
+    """pcl::PointXYZRGBA layout: 32-byte points, xyz at offset 0 (agh_set_cloud stride_bytes = 32)."""
+    sc = tiny_scene
+    a, b = _ctx(sc), _ctx(sc)
+    a.set_cloud(sc.xyz, sc.cam)
+    wide = np.zeros((sc.n, 8), np.float32)
+    wide[:, :3] = sc.xyz
+    wide[:, 3:] = 7.0
+    b.set_cloud(wide, sc.cam)
+    assert a.find_hands(sc.samples).tobytes() == b.find_hands(sc.samples).tobytes()
+
+
+def test_sharding_and_order_properties(small_scene):
+    """Samples are independent: a slice of the samples gives the slice of the results (basis of the multi-GPU
+    sharding), a permutation of the samples permutes them, and a repeat call is byte-identical."""
+    sc = small_scene
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    full = ctx.find_hands(sc.samples)
+    again = ctx.find_hands(sc.samples)
+    assert full.tobytes() == again.tobytes()
+    half = sc.samples.size // 2
+    a = ctx.find_hands(sc.samples[:half])
+    b = ctx.find_hands(sc.samples[half:])
+    b["sample"] += half
+    assert np.concatenate([a, b]).tobytes() == full.tobytes()
+    perm = np.random.default_rng(0).permutation(sc.samples.size)
+    shuf = ctx.find_hands(sc.samples[perm])
+    shuf["sample"] = perm[shuf["sample"]]
+    order = np.lexsort((shuf["orientation"], shuf["sample"]))
+    assert shuf[order].tobytes() == full.tobytes()
+
+
+def test_edge_cases(tiny_scene):
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctx = _ctx(sc)
+    with pytest.raises(binding.AghError) as e:
+        ctx.find_hands(sc.samples)
+    assert e.value.code == -5  # AGH_ERR_NO_CLOUD
+    ctx.set_cloud(sc.xyz, sc.cam)
+    assert len(ctx.find_hands(np.zeros(0, np.int32))) == 0  # empty sample list
+    with pytest.raises(binding.AghError) as e:
+        ctx.find_hands(np.array([sc.n], np.int32))
+    assert e.value.code == -1
+    ctx.find_hands(sc.samples[:4])
+    with pytest.raises(binding.AghError) as e:
+        ctx.classify()
+    assert e.value.code == -6  # AGH_ERR_NO_SVM
+    # empty cloud, single isolated point, two far points: no hypotheses, no crash
+    ctx.set_cloud(np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+    assert len(ctx.find_hands(np.zeros(0, np.int32))) == 0
+    ctx.set_cloud(np.array([[0.5, 0.0, 0.0], [2.0, 2.0, 2.0]], np.float32), np.zeros(2, np.int32))
+    assert len(ctx.find_hands(np.array([0, 1], np.int32))) == 0
+    fr = ctx.frames()
+    assert (fr["valid"] == 0).all() and list(fr["n_nb"]) == [1, 1]
+    # duplicate samples are independent work items
+    ctx.set_cloud(sc.xyz, sc.cam)
+    s = np.array([sc.samples[3]] * 3, np.int32)
+    h = ctx.find_hands(s)
+    one = ctx.find_hands(s[:1])
+    assert len(h) == 3 * len(one)
+
+
+def test_capacity_overflow_is_loud():
+    """A non-voxelised blob with > 2048 neighbours in the Taubin ball must raise, never return partial results."""
+    from agile_grasp_amd import binding
+
+    rng = np.random.default_rng(0)
+    xyz = (rng.normal(0, 0.01, (6000, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
+    ctx = binding.Context(np.zeros((2, 3)))
+    ctx.set_cloud(xyz, np.zeros(6000, np.int32))
+    with pytest.raises(binding.AghError) as e:
+        ctx.find_hands(np.arange(4, dtype=np.int32))
+    assert e.value.code == -4  # AGH_ERR_CAPACITY
+
+
+def test_large_neighbourhood_classes(tiny_scene):
+    """Neighbourhoods between 1024 and 2048 points go through the second LDS capacity class."""
+    from oracle import oracle_py as O
+
+    rng = np.random.default_rng(3)
+    n = 30000
+    # a dense curved sheet: ~1500 neighbours within 3 cm
+    u, v = rng.uniform(-0.08, 0.08, n), rng.uniform(-0.08, 0.08, n)
+    xyz = np.stack([0.7 + u, v, 0.1 * u * u - 0.2 * v * v + rng.normal(0, 3e-4, n)], 1).astype(np.float32)
+    cam = (rng.random(n) < 0.5).astype(np.int32)
+    cams = tiny_scene.cam_origins
+    from agile_grasp_amd import binding
+
+    ctx = binding.Context(cams)
+    ctx.set_cloud(xyz, cam)
+    d = np.linalg.norm(xyz - np.array([0.7, 0, 0], np.float32), axis=1)
+    samples = np.sort(np.argsort(d)[:6]).astype(np.int32)
+    hyps = ctx.find_hands(samples)
+    ref = O.find_hands(O.default_params(cams), xyz, cam, samples)
+    assert ref["frames"]["n_nb"].max() > 1024
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert_hyps_equal(hyps, ref["hyps"])
+
+
+def test_device_resident_api_matches_host_api(tiny_scene, svm_model):
+    import torch
+
+    sc = tiny_scene
+    w, rho = svm_model
+    host = _ctx(sc)
+    host.set_cloud(sc.xyz, sc.cam)
+    ref = host.find_hands(sc.samples)
+    host.load_svm(w, rho)
+    ref_keep = host.classify()
+    dev = _ctx(sc)
+    dev.load_svm(w, rho)
+    xyz_t = torch.from_numpy(sc.xyz).cuda()
+    cam_t = torch.from_numpy(sc.cam).cuda()
+    s_t = torch.from_numpy(sc.samples).cuda()
+    out_t = torch.zeros(8 * sc.samples.size * 160, dtype=torch.uint8, device="cuda")
+    n_t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    keep_t = torch.zeros(8 * sc.samples.size, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        dev.set_cloud_torch(xyz_t, cam_t, stream=st)
+        dev.find_hands_torch(s_t, out_t, n_t, stream=st)
+        dev.classify_torch(keep_t, stream=st)
+    torch.cuda.synchronize()
+    n = int(n_t.item())
+    from agile_grasp_amd import binding
+
+    got = np.frombuffer(out_t.cpu().numpy().tobytes(), dtype=binding.HYP_DTYPE)[:n]
+    assert n == len(ref)
+    for f in INT_FIELDS + FLOAT_FIELDS:
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(keep_t.cpu().numpy()[:n], ref_keep)
+    assert np.array_equal(got["svm_keep"], ref_keep)
+
+
+def test_full_size_c2_against_oracle(svm_model):
+    """BASELINE config C2/C3 (300k points, 2000 samples): whole result list bit-identical to the oracle."""
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config("C2")
+    w, rho = svm_model
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ctx.load_svm(w, rho)
+    keep = ctx.classify()
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert_hyps_equal(hyps, ref["hyps"])
+    okeep, _ = O.classify(ref["images"], w, rho)
+    assert np.array_equal(keep, okeep)
+    assert len(hyps) > 300
