@@ -147,6 +147,7 @@ struct Ctx
 
   int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep
   int debug_stop_moments = 0;  // AGH_DEBUG_STOP_MOMENTS
+  int debug_stop_frame = 0;    // AGH_DEBUG_STOP_FRAME
 
   // timing
   std::vector<hipEvent_t> ev;

@@ -303,6 +303,8 @@ int agh_create(const agh_params* p, agh_ctx** out)
     c->debug_stop_sweep = std::atoi(e);
   if (const char* e = std::getenv("AGH_DEBUG_STOP_MOMENTS"))
     c->debug_stop_moments = std::atoi(e);
+  if (const char* e = std::getenv("AGH_DEBUG_STOP_FRAME"))
+    c->debug_stop_frame = std::atoi(e);
   std::string gerr;
   build_geometry(*p, &c->geom, &gerr);
   if (!gerr.empty())
@@ -509,7 +511,7 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
     c->err = "taubin launch failed";
     return rc;
   }
-  if (c->debug_stop_moments)
+  if (c->debug_stop_moments || (c->debug_stop_frame && c->debug_stop_frame < 5))
   {
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     return AGH_OK;

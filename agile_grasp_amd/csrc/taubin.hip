@@ -223,8 +223,21 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     }
     __syncthreads();
     if (wave == 0 && lane < kNumSums)
-      for (int k = 0; k < rows; k++)
+    {
+      int k = 0;
+      for (; k + 8 <= rows; k += 8)  // 8 LDS loads in flight; the adds stay in neighbour order
+      {
+        double v_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          v_[u] = termbuf[(k + u) * kNumSums + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          acc += v_[u];
+      }
+      for (; k < rows; k++)
         acc += termbuf[k * kNumSums + lane];
+    }
     __syncthreads();
   }
   if (wave == 0 && lane < kNumSums)
@@ -517,6 +530,13 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 // K1c
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max_f64_(double v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
 __device__ inline void jacobi3_serial(double A[3][3], double V[3][3], double d[3])
 {
   for (int i = 0; i < 3; i++)
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
-  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin)
+  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop)
 {
   __shared__ double nx[CAP], ny[CAP], nz[CAP];
   __shared__ int camcnt[2];
@@ -592,6 +612,10 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   __shared__ double sAxis[3];
   __shared__ double wbest[4];
   __shared__ int wbest_j[4];
+  __shared__ double sT[4][28];
+  __shared__ double wmax_s[4];
+  __shared__ unsigned short cand[CAP];
+  __shared__ int ncand;
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -634,7 +658,10 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   if (tid < 2)
     camcnt[tid] = 0;
   if (tid == 0)
+  {
     next_col = 0;
+    ncand = 0;
+  }
   __syncthreads();
   const float4* nb = nbr + (int64_t) s * nbr_stride;
   for (int t = tid; t < ks; t += 256)
@@ -652,7 +679,124 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
     atomicAdd(&camcnt[__float_as_uint(p.w) & 1u], 1);  // quadric.cpp:215-226
   }
   __syncthreads();
-  // ---- wave 0: M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
+  if (debug_stop == 1)
+    return;
+  // ---- argmax_j sum_i (n_i . n_j)^6 (quadric.cpp:283-284) by filter-and-refine ----
+  // The reference needs only the ARGMAX of the n column sums.  (1) A cheap estimate of every column sum:
+  //   sum_i (n_i . n_j)^6 = sum_{a+b+c=6} 6!/(a!b!c!) T_abc jx^a jy^b jz^c,   T_abc = sum_i nx_i^a ny_i^b nz_i^c,
+  // i.e. 28 moments of the normals (O(n)) instead of n^2 dot products; its rounding error is < 3e-12 n.
+  // (2) Every column whose estimate is within delta = 1e-9 n + 1e-7 max of the best estimate -- hundreds of times
+  // the error bound, so the true (sequentially rounded) maximum and all its exact ties are among them -- gets the
+  // reference's exact sequential sum; the argmax (first index on ties) is taken over those.  The result is the
+  // same index the exhaustive n^2 evaluation yields (asserted against the exhaustive oracle by the parity tests).
+  {
+    double T[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++)
+      T[k] = 0.0;
+    for (int t = tid; t < ks; t += 256)
+    {
+      const double x = nx[t], y = ny[t], z = nz[t];
+      double px[7], py[7], pz[7];
+      px[0] = py[0] = pz[0] = 1.0;
+#pragma unroll
+      for (int k = 1; k < 7; k++)
+      {
+        px[k] = px[k - 1] * x;
+        py[k] = py[k - 1] * y;
+        pz[k] = pz[k - 1] * z;
+      }
+      int k = 0;
+#pragma unroll
+      for (int a = 6; a >= 0; a--)
+#pragma unroll
+        for (int b = 6 - a; b >= 0; b--)
+          T[k++] += (px[a] * py[b]) * pz[6 - a - b];
+    }
+#pragma unroll
+    for (int k = 0; k < 28; k++)
+    {
+      double v = T[k];
+      for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+      T[k] = v;
+    }
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 28; k++)
+        sT[wave][k] = T[k];
+  }
+  __syncthreads();
+  double est[CAP / 256];
+  double est_max = -1.0;
+  {
+    // multinomial-weighted moments, identical in every thread
+    double W[28];
+    {
+      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
+      int k = 0;
+      for (int a = 6; a >= 0; a--)
+        for (int b = 6 - a; b >= 0; b--)
+        {
+          const double tsum = ((sT[0][k] + sT[1][k]) + sT[2][k]) + sT[3][k];
+          W[k] = tsum * (fact[6] / ((fact[a] * fact[b]) * fact[6 - a - b]));
+          k++;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < CAP / 256; m++)
+    {
+      const int j = tid + 256 * m;
+      double e_ = -2.0;
+      if (j < ks)
+      {
+        const double x = nx[j], y = ny[j], z = nz[j];
+        double px[7], py[7], pz[7];
+        px[0] = py[0] = pz[0] = 1.0;
+        for (int k = 1; k < 7; k++)
+        {
+          px[k] = px[k - 1] * x;
+          py[k] = py[k - 1] * y;
+          pz[k] = pz[k - 1] * z;
+        }
+        e_ = 0.0;
+        int k = 0;
+        for (int a = 6; a >= 0; a--)
+          for (int b = 6 - a; b >= 0; b--)
+            e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
+        if (!(e_ == e_))
+          e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
+      }
+      est[m] = e_;
+      est_max = fmax(est_max, e_);
+    }
+  }
+  est_max = wave_max_f64_(est_max);
+  if (lane == 0)
+    wmax_s[wave] = est_max;
+  __syncthreads();
+  est_max = fmax(fmax(wmax_s[0], wmax_s[1]), fmax(wmax_s[2], wmax_s[3]));
+  {
+    const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
+#pragma unroll
+    for (int m = 0; m < CAP / 256; m++)
+    {
+      const int j = tid + 256 * m;
+      const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
+      const unsigned long long mk = __ballot(is_c);
+      int base = 0;
+      if (lane == 0 && mk)
+        base = atomicAdd(&ncand, __popcll(mk));
+      base = __shfl(base, 0);
+      if (is_c)
+        cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
+    }
+  }
+  __syncthreads();
+  const int ncnd = ncand;
+  if (debug_stop == 2)
+    return;
+  // ---- wave 0 (the other waves go straight to the exact column sums below): M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
   if (wave == 0)
   {
     if (lane < 6)
@@ -662,7 +806,21 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
       const double* pr = (r == 0) ? nx : (r == 1 ? ny : nz);
       const double* pq = (q == 0) ? nx : (q == 1 ? ny : nz);
       double acc = 0.0;
-      for (int t = 0; t < ks; t++)
+      int t = (debug_stop == 5 || debug_stop == 7) ? ks : 0;
+      for (; t + 8 <= ks; t += 8)  // loads of 8 neighbours in flight; the adds stay in index order
+      {
+        double a_[8], b_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+          a_[u] = pr[t + u];
+          b_[u] = pq[t + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          acc += a_[u] * b_[u];
+      }
+      for (; t < ks; t++)
         acc += pr[t] * pq[t];
       sM3[lane] = acc;
     }
@@ -672,7 +830,15 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
     {
       double A[3][3] = { { sM3[0], sM3[1], sM3[2] }, { sM3[1], sM3[3], sM3[4] }, { sM3[2], sM3[4], sM3[5] } };
       double V[3][3], dd[3];
-      jacobi3_serial(A, V, dd);
+      if (debug_stop == 6 || debug_stop == 7)
+      {
+        for (int r = 0; r < 3; r++)
+          for (int q = 0; q < 3; q++)
+            V[r][q] = (r == q) ? 1.0 : 0.0;
+        dd[0] = dd[1] = dd[2] = 0.0;
+      }
+      else
+        jacobi3_serial(A, V, dd);
       int mi = 0;
       for (int r = 1; r < 3; r++)
         if (dd[r] < dd[mi])
@@ -682,7 +848,9 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
       sAxis[2] = V[2][mi];
     }
   }
-  // ---- all waves: column sums of ((normals^T normals)^6) (quadric.cpp:283-284), 64 columns per grab ----
+  if (debug_stop == 3)
+    return;
+  // exact sequential sums of the candidate columns, 64 per grab
   double best = -1.0;
   int best_j = 0x7fffffff;
   for (;;)
@@ -691,13 +859,28 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
     if (lane == 0)
       c0 = atomicAdd(&next_col, 64);
     c0 = __shfl(c0, 0);
-    if (c0 >= ks)
+    if (c0 >= ncnd)
       break;
-    const int j = c0 + lane;
-    const bool have = j < ks;
+    const bool have = c0 + lane < ncnd;
+    const int j = have ? (int) cand[c0 + lane] : 0;
     const double jx = have ? nx[j] : 0.0, jy = have ? ny[j] : 0.0, jz = have ? nz[j] : 0.0;
     double acc = 0.0;
-    for (int t = 0; t < ks; t++)
+    int t = 0;
+    for (; t + 4 <= ks; t += 4)
+    {
+      double g6[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+        const double gdot = (nx[t + u] * jx + ny[t + u] * jy) + nz[t + u] * jz;
+        const double g2 = gdot * gdot;
+        g6[u] = (g2 * g2) * g2;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        acc += g6[u];
+    }
+    for (; t < ks; t++)
     {
       const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
       const double g2 = gdot * gdot;
@@ -709,6 +892,8 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
       best_j = j;
     }
   }
+  if (debug_stop == 4)
+    return;
   // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum)
   for (int o = 32; o > 0; o >>= 1)
   {
@@ -862,12 +1047,17 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (rand_mode)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
   const double* co = &c->p.cam_origin[0][0];
+  // capacity classes of the frame kernel (LDS = 24 B per normal): most neighbourhoods fit the 1024 class, which
+  // leaves room for 4 blocks per CU; the larger classes only run for the samples that need them
+  hipLaunchKernelGGL(k_taubin_frame<1024>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
+    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame);
   hipLaunchKernelGGL(k_taubin_frame<2048>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1024, c->debug_stop_frame);
   hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 2048);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 2048, c->debug_stop_frame);
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

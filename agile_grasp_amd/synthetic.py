@@ -38,6 +38,25 @@ def camera_origins() -> np.ndarray:
     return np.stack([left[:3, 3], right[:3, 3]]).astype(np.float64)
 
 
+# The reference voxelises in the frame the cloud arrives in (a camera optical frame, localization.cpp:43), in which a
+# table top is tilted.  An axis-aligned table would put every table point of a camera on ONE lattice level, i.e. make
+# two thirds of the neighbourhoods exactly planar and the Taubin constraint matrix singular -- not what real clouds
+# look like.  The whole scene (points and camera origins alike) is therefore expressed in a frame tilted by a fixed
+# rotation about the scene pivot before the per-camera voxel snap.
+_PIVOT = np.array([0.9, 0.0, -0.1])
+
+
+def _tilt() -> np.ndarray:
+    ax, ay = np.deg2rad(33.0), np.deg2rad(-19.0)
+    rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    return ry @ rx
+
+
+def to_scene_frame(p: np.ndarray) -> np.ndarray:
+    return (p - _PIVOT) @ _tilt().T + _PIVOT
+
+
 @dataclasses.dataclass
 class Scene:
     xyz: np.ndarray  # (N, 3) float32
@@ -132,7 +151,7 @@ def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, 
     lx, ly = np.sqrt(table_area * aspect), np.sqrt(table_area / aspect)
     for _ in range(6):
         table = (0.5, 0.5 + lx, -ly / 2, ly / 2, -0.10)
-        raw = _surface_points(np.random.default_rng(seed), table, n_objects, 0.0015)
+        raw = to_scene_frame(_surface_points(np.random.default_rng(seed), table, n_objects, 0.0015))
         clouds = []
         crng = np.random.default_rng(seed + 7919)
         for _cam in range(views):
@@ -152,7 +171,8 @@ def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, 
         keep_idx = np.sort(rng.permutation(total)[:n_points])
         xyz, cam = xyz[keep_idx], cam[keep_idx]
     samples = np.sort(rng.permutation(n_points)[:n_samples]).astype(np.int32)
-    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), camera_origins(), samples, seed, name)
+    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), to_scene_frame(camera_origins()), samples, seed,
+                 name)
 
 
 # BASELINE.json configs made concrete

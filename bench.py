@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--normals", default="det", choices=["det", "rand50"])
     ap.add_argument("--cpu-samples", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,7 +82,7 @@ def main():
     sc = synthetic.config(base) if not distributed else synthetic.config(f"C5_{rank}") if base == "C2" else \
         synthetic.make_scene(1_000_000, 8000, seed=40 + rank, two_view=True, n_objects=48, name=f"C4_{rank}")
     normals_mode = binding.NORMALS_RAND50 if args.normals == "rand50" else binding.NORMALS_DETERMINISTIC
-    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=True)
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=not args.no_events)
     svm = None
     if classify:
         z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))

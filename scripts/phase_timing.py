@@ -12,7 +12,7 @@ out_t = torch.zeros(8 * S * 160, dtype=torch.uint8, device="cuda"); n_t = torch.
 st = torch.cuda.current_stream().cuda_stream
 
 def run(env):
-    for k in ("AGH_DEBUG_STOP_SWEEP", "AGH_DEBUG_STOP_MOMENTS"):
+    for k in ("AGH_DEBUG_STOP_SWEEP", "AGH_DEBUG_STOP_MOMENTS", "AGH_DEBUG_STOP_FRAME"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctx = binding.Context(sc.cam_origins, profile=True)
@@ -30,3 +30,5 @@ for stop in (1, 2, 3, 4):
     print("sweep stop", stop, run({"AGH_DEBUG_STOP_SWEEP": str(stop)}).get("hand_sweep"))
 for stop in (1, 2):
     print("moments stop", stop, run({"AGH_DEBUG_STOP_MOMENTS": str(stop)}).get("taubin_moments"))
+for stop in (1, 2, 3, 4, 5, 6, 7):
+    print("frame stop", stop, run({"AGH_DEBUG_STOP_FRAME": str(stop)}).get("taubin_frame"))
