@@ -1,0 +1,73 @@
+// grasp_hypothesis.h -- GraspHypothesis with the reference's accessors (include/agile_grasp/grasp_hypothesis.h:46-231)
+// on top of the fixed-size agh_hypothesis record of the C ABI.
+#ifndef AGILE_GRASP_AMD_GRASP_HYPOTHESIS_H
+#define AGILE_GRASP_AMD_GRASP_HYPOTHESIS_H
+
+#include <iostream>
+#include <vector>
+
+#include "../agh.h"
+#include "types.h"
+
+namespace agile_grasp_amd
+{
+
+class GraspHypothesis
+{
+public:
+  GraspHypothesis() : cam_source_(-1), grasp_width_(0), full_antipodal_(false), half_antipodal_(false), device_index_(-1),
+    n_points_for_learning_(0)
+  {
+  }
+
+  /** Built from one record of agh_find_hands; device_index = its position in that call's result list. */
+  GraspHypothesis(const agh_hypothesis& h, long device_index)
+    : axis_(make_vec3(h.axis[0], h.axis[1], h.axis[2])), approach_(make_vec3(h.approach[0], h.approach[1], h.approach[2])),
+      binormal_(make_vec3(h.binormal[0], h.binormal[1], h.binormal[2])),
+      grasp_bottom_(make_vec3(h.bottom[0], h.bottom[1], h.bottom[2])),
+      grasp_surface_(make_vec3(h.surface[0], h.surface[1], h.surface[2])), cam_source_(h.cam_source),
+      grasp_width_(h.width), full_antipodal_(h.full_antipodal != 0), half_antipodal_(h.half_antipodal != 0),
+      device_index_(device_index), n_points_for_learning_(h.n_in_box)
+  {
+  }
+
+  void print()  // grasp_hypothesis.cpp:3-11
+  {
+    std::cout << "axis: " << axis_(0) << " " << axis_(1) << " " << axis_(2) << std::endl;
+    std::cout << "approach: " << approach_(0) << " " << approach_(1) << " " << approach_(2) << std::endl;
+    std::cout << "binormal: " << binormal_(0) << " " << binormal_(1) << " " << binormal_(2) << std::endl;
+    std::cout << "grasp width: " << grasp_width_ << std::endl;
+    std::cout << "grasp surface: " << grasp_surface_(0) << " " << grasp_surface_(1) << " " << grasp_surface_(2) << std::endl;
+    std::cout << "grasp bottom: " << grasp_bottom_(0) << " " << grasp_bottom_(1) << " " << grasp_bottom_(2) << std::endl;
+  }
+
+  const Vector3d& getApproach() const { return approach_; }
+  const Vector3d& getAxis() const { return axis_; }
+  const Vector3d& getBinormal() const { return binormal_; }
+  bool isFullAntipodal() const { return full_antipodal_; }
+  const Vector3d& getGraspBottom() const { return grasp_bottom_; }
+  const Vector3d& getGraspSurface() const { return grasp_surface_; }
+  double getGraspWidth() const { return grasp_width_; }
+  bool isHalfAntipodal() const { return half_antipodal_; }
+  int getCamSource() const { return cam_source_; }
+  void setFullAntipodal(bool b) { full_antipodal_ = b; }
+  void setHalfAntipodal(bool b) { half_antipodal_ = b; }
+  void setGraspWidth(double w) { grasp_width_ = w; }
+
+  /** Number of columns the reference's points_for_learning_ would have (grasp_hypothesis.h:220).  The points
+   *  themselves stay on the GPU as the 80x100 occupancy image that Learning::classify consumes. */
+  int getNumPointsForLearning() const { return n_points_for_learning_; }
+  /** Position of this hypothesis in the device-side result list of the HandSearch call that produced it. */
+  long getDeviceIndex() const { return device_index_; }
+
+private:
+  Vector3d axis_, approach_, binormal_, grasp_bottom_, grasp_surface_;
+  int cam_source_;
+  double grasp_width_;
+  bool full_antipodal_, half_antipodal_;
+  long device_index_;
+  int n_points_for_learning_;
+};
+
+}  // namespace agile_grasp_amd
+#endif

@@ -1,0 +1,184 @@
+// hand_search.h -- HandSearch with the reference's constructor and findHands signature
+// (include/agile_grasp/hand_search.h:77-85, 101-104) running on the MI355X through the agh C ABI.
+//
+// Differences a maintainer should know (all documented in DESIGN.md / INTEGRATION.md):
+//  * no Plot member (hand_search.h:145 pulls in ROS + PCL visualisation); cloud_plot and plots_hands are accepted and
+//    ignored;
+//  * both camera poses are needed (the reference's HandSearch never initialises cam_tf_right_, hand_search.h:77-85):
+//    pass it with setCamTfRight(), as Localization holds it (localization.h:343);
+//  * uses_determinstic_normal_estimation_ (hand_search.h:84, hard-wired false) is exposed by
+//    setDeterministicNormalEstimation(); `false` reproduces the reference's 50 x rand() % n subsample for ONE thread;
+//  * explicit `indices` define hands_cam_source(i) = pts_cam_source(indices[i]) (the reference reads an empty vector
+//    there, hand_search.cpp:166); an empty `indices` draws num_samples indices with std::rand-free selection sampling
+//    seeded by setSampleSeed() instead of pcl::RandomSample's time seed (hand_search.cpp:36-39).
+//  * errors follow the reference's convention: a message on std::cout and an empty vector.
+#ifndef AGILE_GRASP_AMD_HAND_SEARCH_H
+#define AGILE_GRASP_AMD_HAND_SEARCH_H
+
+#include <cstdint>
+#include <iostream>
+#include <vector>
+
+#include "../agh.h"
+#include "grasp_hypothesis.h"
+#include "types.h"
+
+namespace agile_grasp_amd
+{
+
+class HandSearch
+{
+public:
+  HandSearch(double finger_width, double hand_outer_diameter, double hand_depth, double hand_height, double init_bite,
+    int num_threads, int num_samples, const Matrix4d& cam_tf_left, bool plots_hands)
+    : ctx_(nullptr), cam_tf_left_(cam_tf_left), cam_tf_right_(cam_tf_left), num_threads_(num_threads),
+      num_samples_(num_samples), plots_hands_(plots_hands), deterministic_(false), sample_seed_(1), device_(0),
+      dirty_(true)
+  {
+    agh_default_params(&params_);
+    params_.finger_width = finger_width;
+    params_.hand_outer_diameter = hand_outer_diameter;
+    params_.hand_depth = hand_depth;
+    params_.hand_height = hand_height;
+    params_.init_bite = init_bite;
+    (void) num_threads_;
+    (void) plots_hands_;
+  }
+  ~HandSearch() { agh_destroy(ctx_); }
+  HandSearch(const HandSearch&) = delete;
+  HandSearch& operator=(const HandSearch&) = delete;
+
+  void setCamTfRight(const Matrix4d& cam_tf_right)
+  {
+    cam_tf_right_ = cam_tf_right;
+    dirty_ = true;
+  }
+  void setDeterministicNormalEstimation(bool b)
+  {
+    deterministic_ = b;
+    dirty_ = true;
+  }
+  void setRandSeed(unsigned seed)  // srand() seed of the 50-point normal subsample (glibc default: 1)
+  {
+    params_.rand_seed = seed;
+    dirty_ = true;
+  }
+  void setSampleSeed(std::uint64_t seed) { sample_seed_ = seed; }
+  void setDevice(int device)
+  {
+    device_ = device;
+    dirty_ = true;
+  }
+  agh_ctx* context() { return ctx_; }
+
+  std::vector<GraspHypothesis> findHands(const PointCloud::Ptr cloud, const VectorXi& pts_cam_source,
+    const std::vector<int>& indices, const PointCloud::Ptr cloud_plot, bool calculates_antipodal, bool uses_clustering)
+  {
+    (void) cloud_plot;
+    (void) uses_clustering;
+    std::vector<GraspHypothesis> hand_list;
+    if (!cloud || cloud->size() == 0)
+    {
+      std::cout << "Input cloud is empty!\n";
+      return hand_list;
+    }
+    if (!ensureContext())
+      return hand_list;
+    const std::int64_t n = (std::int64_t) cloud->size();
+    std::vector<std::int32_t> cam((std::size_t) n, 0);
+    for (std::int64_t i = 0; i < n && i < (std::int64_t) pts_cam_source.size(); i++)
+      cam[(std::size_t) i] = pts_cam_source((std::size_t) i);
+    int rc = agh_set_cloud(ctx_, &cloud->points[0].x, (std::int64_t) sizeof(cloud->points[0]), cam.data(), n);
+    if (rc != AGH_OK)
+      return fail("agh_set_cloud");
+    std::vector<std::int32_t> idx;
+    if (indices.empty())
+    {
+      std::cout << "Generating uniform random indices ...\n";  // hand_search.cpp:34
+      idx = drawSamples(n);
+    }
+    else
+      idx.assign(indices.begin(), indices.end());
+    if (calculates_antipodal)
+      std::cout << "Calculating normals for all points\n";  // hand_search.cpp:19
+    std::cout << "Estimating local axes ...\nFinding hand poses ...\n";  // hand_search.cpp:52,58
+    std::vector<agh_hypothesis> out(8 * idx.size() + 1);
+    std::int64_t n_out = 0;
+    rc = agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
+      (std::int64_t) out.size(), &n_out);
+    if (rc != AGH_OK)
+      return fail("agh_find_hands");
+    hand_list.reserve((std::size_t) n_out);
+    for (std::int64_t i = 0; i < n_out; i++)
+      hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i));
+    std::cout << " Found " << hand_list.size() << " robot hand poses\n";  // hand_search.cpp:203
+    return hand_list;
+  }
+
+private:
+  std::vector<GraspHypothesis> fail(const char* what)
+  {
+    std::cout << " Error in " << what << ": " << agh_last_error(ctx_) << "\n";
+    return std::vector<GraspHypothesis>();
+  }
+
+  bool ensureContext()
+  {
+    if (ctx_ && !dirty_)
+      return true;
+    agh_destroy(ctx_);
+    ctx_ = nullptr;
+    for (int r = 0; r < 3; r++)
+    {
+      params_.cam_origin[0][r] = mat4(cam_tf_left_, r, 3);   // hand_search.cpp:72-74 -> quadric.cpp:8-11
+      params_.cam_origin[1][r] = mat4(cam_tf_right_, r, 3);
+    }
+    params_.normals_mode = deterministic_ ? AGH_NORMALS_DETERMINISTIC : AGH_NORMALS_RAND50;
+    params_.device = device_;
+    const int rc = agh_create(&params_, &ctx_);
+    if (rc != AGH_OK)
+    {
+      std::cout << " Error: cannot create the MI355X grasp-search context: " << agh_last_error(nullptr) << "\n";
+      ctx_ = nullptr;
+      return false;
+    }
+    dirty_ = false;
+    return true;
+  }
+
+  // Selection sampling of num_samples_ sorted indices (what pcl::RandomSample does, hand_search.cpp:36-39), with a
+  // splitmix64 stream instead of the time-seeded rand().
+  std::vector<std::int32_t> drawSamples(std::int64_t n)
+  {
+    std::vector<std::int32_t> idx;
+    std::uint64_t s = sample_seed_;
+    std::int64_t need = num_samples_ < n ? num_samples_ : n;
+    for (std::int64_t i = 0; i < n && need > 0; i++)
+    {
+      s += 0x9e3779b97f4a7c15ull;
+      std::uint64_t z = s;
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      z ^= z >> 31;
+      const double u = (double) (z >> 11) / 9007199254740992.0;
+      if (u * (double) (n - i) < (double) need)
+      {
+        idx.push_back((std::int32_t) i);
+        need--;
+      }
+    }
+    return idx;
+  }
+
+  agh_ctx* ctx_;
+  agh_params params_;
+  Matrix4d cam_tf_left_, cam_tf_right_;
+  int num_threads_, num_samples_;
+  bool plots_hands_, deterministic_;
+  std::uint64_t sample_seed_;
+  int device_;
+  bool dirty_;
+};
+
+}  // namespace agile_grasp_amd
+#endif
