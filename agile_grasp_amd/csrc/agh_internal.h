@@ -145,6 +145,7 @@ struct Ctx
   uint8_t* d_keep = nullptr;
   int64_t keep_cap = 0;
 
+  long long* d_dbg = nullptr;  // AGH_DEBUG_CLOCKS: per-sample phase timestamps of k_hand_sweep (dumped to a file)
   int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep
   int debug_stop_moments = 0;  // AGH_DEBUG_STOP_MOMENTS
   int debug_stop_frame = 0;    // AGH_DEBUG_STOP_FRAME
@@ -243,17 +244,33 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
     }
   }
   __syncthreads();
-  if (tid == 0)
+  if (tid < 64)  // wave 0: inclusive scan of the (<= 128) row lengths, two per lane
   {
-    int acc = 0;
-    rt.prefix[0] = 0;
     const int nr = rt.bad ? 0 : nrows;
-    for (int t = 0; t < nr; t++)
+    const int v0 = tid < nr ? rt.prefix[tid + 1] : 0;
+    const int v1 = (64 + tid) < nr ? rt.prefix[64 + tid + 1] : 0;
+    int i0 = v0, i1 = v1;
+    for (int o = 1; o < 64; o <<= 1)
     {
-      acc += rt.prefix[t + 1];
-      rt.prefix[t + 1] = acc;
+      const int a = __shfl_up(i0, o), b = __shfl_up(i1, o);
+      if (tid >= o)
+      {
+        i0 += a;
+        i1 += b;
+      }
     }
-    rt.total = acc;
+    const int t0 = __shfl(i0, 63);
+    i1 += t0;
+    if (tid < nr)
+      rt.prefix[tid + 1] = i0;
+    if ((64 + tid) < nr)
+      rt.prefix[64 + tid + 1] = i1;
+    const int tot = __shfl(i1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the grand total
+    if (tid == 0)
+    {
+      rt.prefix[0] = 0;
+      rt.total = tot;
+    }
   }
   __syncthreads();
 }

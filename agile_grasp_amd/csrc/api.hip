@@ -114,8 +114,8 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
   std::sort(t.begin(), t.end());
   t.erase(std::unique(t.begin(), t.end()), t.end());
   g->n_thr = (int) t.size();
-  for (int k = 0; k < g->n_thr; k++)
-    g->thr[k] = t[k];
+  for (int k = 0; k < 40; k++)
+    g->thr[k] = k < g->n_thr ? t[k] : INFINITY;  // padded: fixed-length straight-line comparisons in the kernel
   for (int i = 0; i < 20; i++)
   {
     g->lo_idx[i] = (int) (std::lower_bound(t.begin(), t.end(), g->fs[i]) - t.begin());
@@ -134,6 +134,8 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
     g->depths[k++] = d;
   }
   g->n_depths = k;
+  for (int i = k; i < 16; i++)
+    g->depths[i] = INFINITY;  // padded likewise
   for (int i = 0; i < k; i++)
   {
     g->backs[i] = -1.0 * (p.hand_depth - g->depths[i]);  // finger_hand.cpp:22
@@ -516,13 +518,15 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     return AGH_OK;
   }
+  if (std::getenv("AGH_DEBUG_CLOCKS") && !c->d_dbg)
+    (void) hipMalloc((void**) &c->d_dbg, sizeof(long long) * 8 * c->s_cap);
   rc = hand_sweep(c, d_sample_idx, S, calculates_antipodal != 0, st);
   if (rc != AGH_OK)
   {
     c->err = "hand sweep launch failed";
     return rc;
   }
-  if (c->debug_stop_sweep)
+  if (c->debug_stop_sweep && c->debug_stop_sweep < 10)
   {
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     return AGH_OK;
@@ -617,6 +621,16 @@ int agh_synchronize(agh_ctx* ctx)
   Ctx* c = &ctx->c;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
+  if (c->d_dbg && c->last_s > 0)  // development aid (AGH_DEBUG_CLOCKS): dump the phase timestamps
+  {
+    std::vector<long long> h((size_t) c->last_s * 8);
+    if (hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = std::fopen(std::getenv("AGH_DEBUG_CLOCKS"), "wb"))
+      {
+        std::fwrite(h.data(), 8, h.size(), f);
+        std::fclose(f);
+      }
+  }
   return check_flags(c, c->stream);
 }
 

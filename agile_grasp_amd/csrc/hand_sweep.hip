@@ -55,6 +55,7 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 }
 
 constexpr int kTile = 1536;  // cropped points staged in LDS at a time (24 KiB of double2 + 6 KiB of ids): 3 blocks/CU
+static_assert(kTile >= 1024, "a batch of 1024 candidates must fit an empty tile");
 
 __device__ __forceinline__ unsigned lowmask(int n)
 {
@@ -64,7 +65,7 @@ __device__ __forceinline__ unsigned lowmask(int n)
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
-  int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop)
+  int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg)
 {
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[kTile];
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
+  AGH_STAMP(0);
   const agh_frame F = frames[s];
   if (!F.valid)
   {
@@ -170,15 +173,16 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   }
   if (debug_stop == 1)
     return;
+  AGH_STAMP(1);
 
-  // One batch of 512 candidates (two per thread, both loads in flight together): FLANN filter, hand-frame
+  // One batch of 1024 candidates (four per thread, all loads in flight together): FLANN filter, hand-frame
   // transform, crop (rotating_hand.cpp:26,37-51), append to the LDS tile.
   int row_cur = 0;
   auto batch = [&](int j0, bool count_ball) {
-    float4 pp[2];
-    bool have[2];
+    float4 pp[4];
+    bool have[4];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 4; u++)
     {
       const int j = j0 + u * 256 + tid;
       have[u] = j < total;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         pp[u] = gv.sorted[row_advance(rt, j, row_cur)];
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 4; u++)
     {
       bool inball = false, keep = false;
       double tx = 0.0, ty = 0.0;
@@ -220,23 +224,53 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       if (keep)
       {
         const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
-        pts[k] = make_double2(tx, ty);
-        pid[k] = w;
+        if (k < kTile)
+        {
+          pts[k] = make_double2(tx, ty);
+          pid[k] = w;
+        }
       }
     }
   };
-  // Fill the LDS tile from candidate j0 on; returns the tile's point count (block-uniform).
+  // Fill the LDS tile from candidate j0 on; returns the tile's point count (block-uniform).  Batches that are certain to
+  // fit run back to back; once fewer than 1024 slots are left one more batch is tried optimistically (only ~1/6 of
+  // the candidates survive the ball + crop tests) and rolled back if it does not fit -- it is then redone in the
+  // next tile.  Typical neighbourhoods (~1400 cropped points) therefore take exactly one tile.
   auto fill = [&](int& j0, bool count_ball) -> int {
     for (;;)
     {
       __syncthreads();
       const int c = cnt_crop;
+      const int cb = cnt_ball;
       __syncthreads();
-      const int m = (kTile - c) / 512;  // batches that are certain to fit
-      if (m == 0 || j0 >= total)
+      if (j0 >= total)
         return c;
-      for (int b = 0; b < m && j0 < total; b++, j0 += 512)
-        batch(j0, count_ball);
+      const int m = (kTile - c) / 1024;
+      if (m > 0)
+      {
+        for (int b = 0; b < m && j0 < total; b++, j0 += 1024)
+          batch(j0, count_ball);
+        continue;
+      }
+      if (c > kTile - 128)
+        return c;
+      const int row_save = row_cur;
+      batch(j0, count_ball);  // writes beyond the tile are dropped inside
+      __syncthreads();
+      const int c2 = cnt_crop;
+      __syncthreads();
+      if (c2 > kTile)
+      {
+        if (tid == 0)
+        {
+          cnt_crop = c;  // roll back; this batch is redone in the next tile
+          cnt_ball = cb;
+        }
+        row_cur = row_save;  // the row cursor only moves forward: rewind it for the redo
+        __syncthreads();
+        return c;
+      }
+      j0 += 1024;
     }
   };
 
@@ -247,6 +281,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   for (;;)
   {
     nc = fill(j0, true);
+    if (ntiles == 0)
+      AGH_STAMP(2);
     if (debug_stop == 2)
       return;
     for (int oo = 0; oo < 2; oo++)
@@ -256,12 +292,12 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         continue;
       const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
       double ymin = ymin_w[oo], ymax = ymax_w[oo];
-      const double d_first = G.depths[0];
       for (int t0 = lane; t0 < nc; t0 += 256)
       {
-        // four independent points per lane so that the dependent LDS look-ups below overlap
+        // Four independent points per lane, straight-line code: the depth class and the region index are plain
+        // counts of `>=` / `<` against the (+inf padded) depth and threshold tables, which are wave-uniform and come
+        // from constant memory (scalar registers) -- no LDS round trips, no data-dependent loops.
         double xr[4], yr[4];
-        int yk[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
@@ -275,26 +311,33 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             ymin = fmin(ymin, yr[u]);
             ymax = fmax(ymax, yr[u]);
           }
-          // depth class yk = #{k : d_k <= y}  (y < d_k  <=>  k >= yk): arithmetic guess, then exact fix-up on the table
-          int g = (int) fmin(fmax(floor((yr[u] - d_first) * 200.0) + 1.0, 0.0), (double) K);
-          while (g > 0 && yr[u] < G.depths[g - 1])
-            g--;
-          while (g < K && yr[u] >= G.depths[g])
-            g++;
-          yk[u] = g;
+        }
+        int yk[4] = { 0, 0, 0, 0 }, cc[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < (debug_stop == 12 ? 0 : 16); k++)
+        {
+          const double dk = geom_p->depths[k];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            yk[u] += (yr[u] >= dk) ? 1 : 0;  // depth class: y < d_k  <=>  k >= yk
+        }
+#pragma unroll
+        for (int k = 0; k < (debug_stop == 11 ? 0 : 40); k++)
+        {
+          const double tk = geom_p->thr[k];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            cc[u] += (tk < xr[u]) ? 1 : 0;  // region: number of slot thresholds left of x
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (yk[u] < K)
           {
-            int c = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-              if (thr_s[c + step - 1] < xr[u])
-                c += step;
+            const int c = cc[u];
             const int e = (thr_s[c] == xr[u]) ? 1 : 0;  // c <= n_thr <= 40 < 64
             const int key = 2 * c + e;
-            atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk[u]));
+            if (debug_stop != 10)
+              atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk[u]));
           }
       }
       ymin_w[oo] = ymin;
@@ -307,6 +350,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     if (tid == 0)
       cnt_crop = 0;
   }
+  __syncthreads();
+  AGH_STAMP(3);
   if (debug_stop == 3)
     return;
   // ---- finger / hand / deepen logic, wave-parallel (finger_hand.cpp:20-115,173-233) ----
@@ -395,6 +440,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     }
   }
   __syncthreads();
+  AGH_STAMP(4);
   if (debug_stop == 4)
     return;
   // ---- pass B: grasp parameters, box, antipodal counts, image (rotating_hand.cpp:111-170) ----
@@ -494,6 +540,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         cnt_crop = 0;
     }
   }
+  __syncthreads();
+  AGH_STAMP(5);
   // ---- results ----
   for (int oo = 0; oo < 2; oo++)
   {
@@ -540,7 +588,13 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   {
     nh[s] = cnt_ball;
     status[s] = kStatusOk;
+    if (dbg)
+    {
+      dbg[(int64_t) s * 8 + 6] = wall_clock64();
+      dbg[(int64_t) s * 8 + 7] = ((long long) cnt_ball << 32) | (unsigned) total;
+    }
   }
+#undef AGH_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -649,7 +703,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
   hipLaunchKernelGGL(k_hand_sweep, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f, rpad, nrm,
-    img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep);
+    img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -1,0 +1,26 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["AGH_DEBUG_CLOCKS"] = "/tmp/agh_clocks.bin"
+if len(sys.argv) > 1:
+    os.environ["AGH_DEBUG_STOP_SWEEP"] = sys.argv[1]
+import numpy as np, torch
+from agile_grasp_amd import binding, synthetic
+sc = synthetic.config("C2")
+ctx = binding.Context(sc.cam_origins)
+ctx.set_cloud(sc.xyz, sc.cam)
+for _ in range(3):
+    h = ctx.find_hands(sc.samples)
+ctx.synchronize()
+d = np.fromfile("/tmp/agh_clocks.bin", np.int64).reshape(-1, 8)
+t = d[:, :7].astype(np.float64)
+ph = np.diff(t, axis=1)  # wall_clock64 ticks: 100 MHz on MI300-class
+names = ["setup", "gather", "passA", "finger", "passB", "write"]
+print("ticks are wall_clock64 units; per-WG phase durations (median / p90 / max):")
+for i, n in enumerate(names):
+    print(n, np.median(ph[:, i]), np.percentile(ph[:, i], 90), ph[:, i].max())
+tot = t[:, 6] - t[:, 0]
+print("total per WG median", np.median(tot), "p90", np.percentile(tot, 90), "max", tot.max())
+print("kernel span", t[:, 6].max() - t[:, 0].min(), "first start spread", np.percentile(t[:, 0] - t[:, 0].min(), [50, 90, 100]))
+cand = (d[:, 7] & 0xffffffff); ball = d[:, 7] >> 32
+print("candidates mean", cand.mean(), "ball mean", ball.mean())
