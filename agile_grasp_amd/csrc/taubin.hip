@@ -12,7 +12,7 @@
 //                          waves form the products, 37 lanes run the 37 dependent add chains) -- the same fp64
 //                          operation order as the reference loop, so the sums are bit-identical to the CPU path.
 //   k_taubin_eigen         four samples per wave, 9 lanes each: builds M, N, reduces the 10x10 pencil to the 9x9
-//                          symmetric-definite problem, Cholesky + cyclic Jacobi in LDS (same rotation order and
+//                          symmetric-definite problem, Cholesky + round-robin Jacobi in LDS (same rotation order and
 //                          arithmetic as the CPU path), smallest eigenpair -> quadric parameters.
 //   k_taubin_frame         one workgroup per sample: quadric-gradient normals, the 3x3 scatter of normals
 //                          (sequential sums again) and its Jacobi eigenvectors on wave 0 while the other waves
@@ -24,6 +24,7 @@ namespace agh
 {
 
 constexpr int kSortBins = 256;  // distance buckets of the neighbour sort (= workgroup size)
+constexpr int kChunk = 56;      // neighbours per summation chunk (56 x 37 doubles fit the sort scratch of the 1536 class)
 
 // ---------------------------------------------------------------------------------------------------------------
 // K1a
@@ -33,14 +34,22 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop)
 {
+  // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
+  // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
+  constexpr int kSortBytes = CAP * 8 + CAP * 2 + (kSortBins + 1) * 4 + kSortBins * 4;
+  constexpr int kTermBytes = kChunk * kNumSums * 8;
+  constexpr int kScratch = ((kSortBytes > kTermBytes ? kSortBytes : kTermBytes) + 15) & ~15;
   __shared__ float4 stage[CAP];
-  __shared__ unsigned long long key[CAP];
   __shared__ unsigned short slot[CAP];
-  __shared__ unsigned short perm[CAP];
-  __shared__ double termbuf[64 * kNumSums];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[kScratch];
   __shared__ RowTable rt;
   __shared__ int count;
-  __shared__ int hist[kSortBins + 1], fillc[kSortBins], wsum[4];
+  __shared__ int wsum[4];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(scratch);
+  unsigned short* perm = reinterpret_cast<unsigned short*>(scratch + CAP * 8);
+  int* hist = reinterpret_cast<int*>(scratch + CAP * 8 + CAP * 2);
+  int* fillc = hist + (kSortBins + 1);
+  double* termbuf = reinterpret_cast<double*>(scratch);
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,9 +170,9 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     nbr[(int64_t) s * nbr_stride + i] = stage[slot[i]];
   // ---- 37 sequential sums (quadric.cpp:40-131) ----
   double acc = 0.0;
-  for (int c0 = 0; c0 < n; c0 += 64)
+  for (int c0 = 0; c0 < n; c0 += kChunk)
   {
-    const int rows = min(64, n - c0);
+    const int rows = min(kChunk, n - c0);
     if (lane < rows)
     {
       const float4 p = stage[slot[c0 + lane]];
@@ -261,6 +270,8 @@ struct EigSmem
   double L[9][9];
   double Y[9][9];
   double V[9][9];
+  double cs[4][2];  // (c, s) of the four rotations of a Jacobi round
+  int flag[4];
   double off;
   int fail;
 };
@@ -421,7 +432,8 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
     for (int j = 0; j < 9; j++)
       E.V[i][j] = (i == j) ? 1.0 : 0.0;
   __syncthreads();
-  // cyclic Jacobi (oracle jacobi_sym<9>)
+  // round-robin Jacobi (oracle jacobi_rr9): 9 rounds of 4 disjoint rotations per sweep; lane = matrix row for the
+  // column phase and for V, lane = matrix column for the row phase
   for (int sweep = 0; sweep < 30; sweep++)
   {
     if (gl == 0)
@@ -436,59 +448,81 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
     const bool active = E.off != 0.0;
     if (!__any(active))
       break;
-    for (int p = 0; p < 8; p++)
-      for (int q = p + 1; q < 9; q++)
+    for (int r = 0; r < 9; r++)
+    {
+      // this lane's pair in round r: d = (gl - r) mod 9, partner = (r - d) mod 9, pair id k = min(d, 9 - d) in 1..4
+      const int dd = row ? (gl - r + 9) % 9 : 0;
+      const int kk = dd <= 4 ? dd : 9 - dd;  // 0: sits out
+      if (row && kk > 0 && dd <= 4)
       {
-        const double apq = E.A[p][q];
-        const double app = E.A[p][p], aqq = E.A[q][q];
-        const double akp = row ? E.A[i][p] : 0.0, akq = row ? E.A[i][q] : 0.0;
-        const double vkp = row ? E.V[i][p] : 0.0, vkq = row ? E.V[i][q] : 0.0;
-        __syncthreads();
-        bool rot = active && (apq != 0.0);
-        bool zero_only = false;
+        const int mate = (r + 9 - dd) % 9;
+        const int p = gl < mate ? gl : mate, q = gl < mate ? mate : gl;
+        const double apq = E.A[p][q], app = E.A[p][p], aqq = E.A[q][q];
         const double aabs = fabs(apq);
-        if (rot && sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+        double c = 1.0, sn = 0.0;
+        int flag = 0;  // 1 rotate, 2 zero only
+        if (active && apq != 0.0)
         {
-          zero_only = true;
-          rot = false;
-        }
-        const double theta = (aqq - app) / (2.0 * apq);
-        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-        if (theta < 0.0)
-          t = -t;
-        const double c = 1.0 / sqrt(t * t + 1.0);
-        const double sn = t * c;
-        if (zero_only && gl == 0)
-        {
-          E.A[p][q] = 0.0;
-          E.A[q][p] = 0.0;
-        }
-        if (rot)
-        {
-          if (gl == 0)
+          if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+            flag = 2;
+          else
           {
-            E.A[p][p] = app - t * apq;
-            E.A[q][q] = aqq + t * apq;
-            E.A[p][q] = 0.0;
-            E.A[q][p] = 0.0;
+            const double theta = (aqq - app) / (2.0 * apq);
+            double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+            if (theta < 0.0)
+              t = -t;
+            c = 1.0 / sqrt(t * t + 1.0);
+            sn = t * c;
+            flag = 1;
           }
-          if (row)
+        }
+        E.cs[kk - 1][0] = c;
+        E.cs[kk - 1][1] = sn;
+        E.flag[kk - 1] = flag;
+      }
+      __syncthreads();
+      if (row)  // columns: A <- A J, V <- V J (lane = row k)
+        for (int m = 0; m < 4; m++)
+          if (E.flag[m] == 1)
           {
-            if (i != p && i != q)
-            {
-              const double np_ = c * akp - sn * akq;
-              const double nq_ = sn * akp + c * akq;
-              E.A[i][p] = np_;
-              E.A[p][i] = np_;
-              E.A[i][q] = nq_;
-              E.A[q][i] = nq_;
-            }
+            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
+            const int p = a < b ? a : b, q = a < b ? b : a;
+            const double c = E.cs[m][0], sn = E.cs[m][1];
+            const double akp = E.A[i][p], akq = E.A[i][q];
+            E.A[i][p] = c * akp - sn * akq;
+            E.A[i][q] = sn * akp + c * akq;
+            const double vkp = E.V[i][p], vkq = E.V[i][q];
             E.V[i][p] = c * vkp - sn * vkq;
             E.V[i][q] = sn * vkp + c * vkq;
           }
-        }
-        __syncthreads();
+      __syncthreads();
+      if (row)  // rows: A <- J^T A (lane = column k)
+        for (int m = 0; m < 4; m++)
+          if (E.flag[m] == 1)
+          {
+            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
+            const int p = a < b ? a : b, q = a < b ? b : a;
+            const double c = E.cs[m][0], sn = E.cs[m][1];
+            const double apk = E.A[p][i], aqk = E.A[q][i];
+            E.A[p][i] = c * apk - sn * aqk;
+            E.A[q][i] = sn * apk + c * aqk;
+          }
+      __syncthreads();
+      if (row)
+      {
+        for (int m = 0; m < 4; m++)
+          if (E.flag[m] != 0)
+          {
+            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
+            const int p = a < b ? a : b, q = a < b ? b : a;
+            if (i == p)
+              E.A[p][q] = 0.0;
+          }
+        for (int j = i + 1; j < 9; j++)
+          E.A[j][i] = E.A[i][j];
       }
+      __syncthreads();
+    }
   }
   __syncthreads();
   if (gl == 0 && s < S)
@@ -1031,10 +1065,8 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
       r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
     first = false;
   }
-  hipLaunchKernelGGL(k_taubin_moments<1024>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+  hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
     r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
-  hipLaunchKernelGGL(k_taubin_moments<2048>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
     r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
   timing_mark(c, "taubin_moments", st);
@@ -1047,17 +1079,14 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (rand_mode)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
   const double* co = &c->p.cam_origin[0][0];
-  // capacity classes of the frame kernel (LDS = 24 B per normal): most neighbourhoods fit the 1024 class, which
-  // leaves room for 4 blocks per CU; the larger classes only run for the samples that need them
-  hipLaunchKernelGGL(k_taubin_frame<1024>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
+  // capacity classes (LDS = 24 B per normal): voxelised clouds fit the 1536 class (3-4 blocks per CU); the 4096 class
+  // only does work for the samples that need it
+  hipLaunchKernelGGL(k_taubin_frame<1536>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
     co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame);
-  hipLaunchKernelGGL(k_taubin_frame<2048>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
-    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1024, c->debug_stop_frame);
   hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 2048, c->debug_stop_frame);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1536, c->debug_stop_frame);
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -271,12 +271,98 @@ void jacobi_sym(double A[NN][NN], double V[NN][NN], double d[NN])
 }
 
 /* ---------------------------------------------------------------------------------------------------
+ * Round-robin ("parallel order", Brent-Luk) Jacobi for the symmetric 9x9 matrix of the reduced Taubin problem.
+ * Same rotations as jacobi_sym, but each sweep is organised in 9 rounds of 4 disjoint pairs
+ * {(r+k) mod 9, (r-k) mod 9 : k = 1..4} (index r sits out); the four rotations of a round are computed from the
+ * matrix at the start of the round and applied together: all column rotations (A <- A J), then all row rotations
+ * (A <- J^T A), the rotated off-diagonal entries are set to exactly 0 and the lower triangle is refreshed from the
+ * upper one.  Disjoint pairs touch disjoint columns / rows, so the order inside a phase is immaterial -- which is
+ * what lets the GPU run a round with one lane per row.  Stands in for LAPACK dggev's QZ (quadric.cpp:330-363).
+ * ------------------------------------------------------------------------------------------------- */
+void jacobi_rr9(double A[9][9], double V[9][9], double d[9])
+{
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++)
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; sweep++)
+  {
+    double off = 0.0;
+    for (int p = 0; p < 8; p++)
+      for (int q = p + 1; q < 9; q++)
+        off += A[p][q] * A[p][q];
+    if (off == 0.0)
+      break;
+    for (int r = 0; r < 9; r++)
+    {
+      int P[4], Q[4];
+      double C[4], S[4];
+      bool rot[4], zero[4];
+      for (int k = 1; k <= 4; k++)
+      {
+        const int a = (r + k) % 9, b = (r + 9 - k) % 9;
+        const int p = a < b ? a : b, q = a < b ? b : a;
+        P[k - 1] = p;
+        Q[k - 1] = q;
+        const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+        const double aabs = std::fabs(apq);
+        rot[k - 1] = false;
+        zero[k - 1] = false;
+        C[k - 1] = 1.0;
+        S[k - 1] = 0.0;
+        if (apq == 0.0)
+          continue;
+        if (sweep > 3 && (std::fabs(app) + aabs == std::fabs(app)) && (std::fabs(aqq) + aabs == std::fabs(aqq)))
+        {
+          zero[k - 1] = true;
+          continue;
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        if (theta < 0.0)
+          t = -t;
+        const double c = 1.0 / std::sqrt(t * t + 1.0);
+        C[k - 1] = c;
+        S[k - 1] = t * c;
+        rot[k - 1] = true;
+      }
+      for (int m = 0; m < 4; m++)  /* columns: A <- A J, V <- V J */
+        if (rot[m])
+          for (int k = 0; k < 9; k++)
+          {
+            const double akp = A[k][P[m]], akq = A[k][Q[m]];
+            A[k][P[m]] = C[m] * akp - S[m] * akq;
+            A[k][Q[m]] = S[m] * akp + C[m] * akq;
+            const double vkp = V[k][P[m]], vkq = V[k][Q[m]];
+            V[k][P[m]] = C[m] * vkp - S[m] * vkq;
+            V[k][Q[m]] = S[m] * vkp + C[m] * vkq;
+          }
+      for (int m = 0; m < 4; m++)  /* rows: A <- J^T A */
+        if (rot[m])
+          for (int k = 0; k < 9; k++)
+          {
+            const double apk = A[P[m]][k], aqk = A[Q[m]][k];
+            A[P[m]][k] = C[m] * apk - S[m] * aqk;
+            A[Q[m]][k] = S[m] * apk + C[m] * aqk;
+          }
+      for (int m = 0; m < 4; m++)
+        if (rot[m] || zero[m])
+          A[P[m]][Q[m]] = 0.0;
+      for (int i = 0; i < 9; i++)
+        for (int j = i + 1; j < 9; j++)
+          A[j][i] = A[i][j];
+    }
+  }
+  for (int i = 0; i < 9; i++)
+    d[i] = A[i][i];
+}
+
+/* ---------------------------------------------------------------------------------------------------
  * Quadric::solveGeneralizedEigenProblem + the eigenvalue selection of fitQuadric
  * (quadric.cpp:143-153, 330-363) -- dggev is THIRD PARTY.
  * N's 10th row/column is identically zero, so the pencil (M,N) has exactly one infinite eigenvalue and
  * the reference takes the smallest of "the first 9" = the smallest finite one (scipy/LAPACK places the
  * infinite one at index 9, see tests/golden).  Eliminating the 10th unknown (v10 = -b.v9/n) gives the
- * symmetric-definite 9x9 problem (A - b b^T/n) v = lambda N9 v, solved by Cholesky(N9) + Jacobi.
+ * symmetric-definite 9x9 problem (A - b b^T/n) v = lambda N9 v, solved by Cholesky(N9) + round-robin Jacobi.
  * The eigenvector's sign and scale are arbitrary in both solvers and cancel downstream
  * (quadric.cpp:246-247 normalises, 294-301 re-orients).
  * Returns false if N9 is not positive definite (degenerate neighbourhood) -- the reference would carry
@@ -334,7 +420,7 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
     for (int j = i + 1; j < 9; j++)
       C[i][j] = C[j][i];
   double V[9][9], d[9];
-  jacobi_sym<9>(C, V, d);
+  jacobi_rr9(C, V, d);
   int mi = 0;
   for (int i = 1; i < 9; i++)
     if (d[i] < d[mi])
