@@ -52,7 +52,15 @@ struct HandGeom
   double boxy[16];             // backs[k] + hand_depth (rotating_hand.cpp:127)
   int n_depths;
   double cos_antipodal;        // cos(20 deg) (antipodal.cpp:16)
+  // Uniform-cell look-up tables over the two sorted tables above: lut[cell(v)] = number of table entries in EARLIER
+  // cells; the entries of v's own cell (at most kLutProbe of them, checked on the host) are compared explicitly, so
+  // rank(v) = #{entries < v} (or <= v) is exact for every v.
+  double xlut_lo, xlut_scale;
+  double ylut_lo, ylut_scale;
+  unsigned char xlut[1024];
+  unsigned char ylut[64];
 };
+constexpr int kLutProbe = 4;
 
 struct HogTablesDev
 {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
 // Candidate j of the query -> position in the sorted array, for a thread whose j only grows: r is its row cursor.
 __device__ __forceinline__ int row_advance(const RowTable& rt, int j, int& r)
 {
-  while (j >= rt.prefix[r + 1])
+  while (r + 1 < rt.nrows && j >= rt.prefix[r + 1])  // (bounded: a cursor can never leave the table)
     r++;
   return rt.begin[r] + (j - rt.prefix[r]);
 }

@@ -142,6 +142,32 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
     g->boxy[i] = g->backs[i] + p.hand_depth;             // rotating_hand.cpp:127
   }
   g->cos_antipodal = std::cos(20 * M_PI / 180.0);  // antipodal.cpp:16 with thresh 20 (rotating_hand.cpp:162)
+  // look-up tables (see HandGeom): the device evaluates exactly this cell formula
+  auto build_lut = [&](const double* tab, int n, int ncell, double* lo_out, double* scale_out, unsigned char* lut) -> bool {
+    const double lo = tab[0], hi = tab[n - 1];
+    const double scale = (hi > lo) ? (double) ncell / (hi - lo) : 0.0;
+    *lo_out = lo;
+    *scale_out = scale;
+    std::vector<int> cell(n);
+    for (int k = 0; k < n; k++)
+      cell[k] = (int) std::fmin(std::fmax((tab[k] - lo) * scale, 0.0), (double) (ncell - 1));
+    for (int c = 0; c < ncell; c++)
+    {
+      int before = 0, inside = 0;
+      for (int k = 0; k < n; k++)
+      {
+        before += cell[k] < c ? 1 : 0;
+        inside += cell[k] == c ? 1 : 0;
+      }
+      if (inside > kLutProbe)
+        return false;
+      lut[c] = (unsigned char) before;
+    }
+    return true;
+  };
+  if (!build_lut(g->thr, g->n_thr, 1024, &g->xlut_lo, &g->xlut_scale, g->xlut) ||
+      !build_lut(g->depths, g->n_depths, 64, &g->ylut_lo, &g->ylut_scale, g->ylut))
+    *err = "hand geometry packs more than 4 finger-slot thresholds (or bite depths) into one look-up cell";
 }
 
 int ensure_call_buffers(Ctx* c, int64_t S)

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   __shared__ RowTable rt;
   __shared__ HandGeom G;
   __shared__ double thr_s[64];
+  __shared__ double dep_s[24];
   __shared__ OriState ori[8];
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   build_rows(gv, sx, sy, sz, rpad, rt);  // ends with barriers: G and counters are visible afterwards
   if (tid < 64)
     thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
+  if (tid < 24)
+    dep_s[tid] = tid < G.n_depths ? G.depths[tid] : INFINITY;
   if (rt.bad)
   {
     if (tid == 0)
@@ -203,11 +206,14 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         if (inball)
         {
           const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
-          tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
-          ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
           const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
           keep = (tz > -1.0 * hh) && (tz < hh);
-          w = __float_as_uint(p.w);
+          if (keep)  // only ~1/4 of the ball survives the crop: the other two rows of frame^T are computed for those
+          {
+            tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+            ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+            w = __float_as_uint(p.w);
+          }
         }
       }
       const unsigned long long mk = __ballot(keep);
@@ -294,9 +300,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       double ymin = ymin_w[oo], ymax = ymax_w[oo];
       for (int t0 = lane; t0 < nc; t0 += 256)
       {
-        // Four independent points per lane, straight-line code: the depth class and the region index are plain
-        // counts of `>=` / `<` against the (+inf padded) depth and threshold tables, which are wave-uniform and come
-        // from constant memory (scalar registers) -- no LDS round trips, no data-dependent loops.
+        // Four independent points per lane, straight-line code (no data-dependent loops), so that the LDS look-ups of
+        // the four points overlap.
         double xr[4], yr[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -312,33 +317,33 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             ymax = fmax(ymax, yr[u]);
           }
         }
-        int yk[4] = { 0, 0, 0, 0 }, cc[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < (debug_stop == 12 ? 0 : 16); k++)
-        {
-          const double dk = geom_p->depths[k];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            yk[u] += (yr[u] >= dk) ? 1 : 0;  // depth class: y < d_k  <=>  k >= yk
-        }
-#pragma unroll
-        for (int k = 0; k < (debug_stop == 11 ? 0 : 40); k++)
-        {
-          const double tk = geom_p->thr[k];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            cc[u] += (tk < xr[u]) ? 1 : 0;  // region: number of slot thresholds left of x
-        }
+        // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
 #pragma unroll
         for (int u = 0; u < 4; u++)
-          if (yk[u] < K)
+        {
+          const int cy = (int) fmin(fmax((yr[u] - G.ylut_lo) * G.ylut_scale, 0.0), 63.0);
+          const int ly = G.ylut[cy];
+          int yk = ly;
+#pragma unroll
+          for (int j = 0; j < kLutProbe; j++)
+            yk += (dep_s[ly + j] <= yr[u]) ? 1 : 0;
+          if (yk < K && debug_stop != 11)
           {
-            const int c = cc[u];
-            const int e = (thr_s[c] == xr[u]) ? 1 : 0;  // c <= n_thr <= 40 < 64
+            const int cx = (int) fmin(fmax((xr[u] - G.xlut_lo) * G.xlut_scale, 0.0), 1023.0);
+            const int lx = G.xlut[cx];
+            int c = lx, e = 0;
+#pragma unroll
+            for (int j = 0; j < kLutProbe; j++)
+            {
+              const double tv = thr_s[lx + j];
+              c += (tv < xr[u]) ? 1 : 0;
+              e |= (tv == xr[u]) ? 1 : 0;
+            }
             const int key = 2 * c + e;
             if (debug_stop != 10)
-              atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk[u]));
+              atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
           }
+        }
       }
       ymin_w[oo] = ymin;
       ymax_w[oo] = ymax;
@@ -542,6 +547,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   }
   __syncthreads();
   AGH_STAMP(5);
+  if (debug_stop == 5)
+    return;
   // ---- results ----
   for (int oo = 0; oo < 2; oo++)
   {
@@ -584,6 +591,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     for (int k = lane; k < kImageWords; k += 64)
       images[((int64_t) s * 8 + o) * kImageWords + k] = img[o][k];
   }
+  if (debug_stop == 6)
+    return;
   if (tid == 0)
   {
     nh[s] = cnt_ball;

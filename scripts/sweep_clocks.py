@@ -22,5 +22,6 @@ for i, n in enumerate(names):
 tot = t[:, 6] - t[:, 0]
 print("total per WG median", np.median(tot), "p90", np.percentile(tot, 90), "max", tot.max())
 print("kernel span", t[:, 6].max() - t[:, 0].min(), "first start spread", np.percentile(t[:, 0] - t[:, 0].min(), [50, 90, 100]))
+print('guard trips', (d[:, 7] < 0).sum(), d[d[:, 7] < 0][:5])
 cand = (d[:, 7] & 0xffffffff); ball = d[:, 7] >> 32
 print("candidates mean", cand.mean(), "ball mean", ball.mean())
