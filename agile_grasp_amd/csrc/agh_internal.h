@@ -67,11 +67,10 @@ struct HogTablesDev
   // Gradient LUT for binary images: index = (sx+1)*3 + (sy+1), sx/sy = sign of dx/dy
   float mag0[9], mag1[9];
   int bin0[9], bin1[9];
-  // pixData of HOGCache::init in its accumulation order (count1 | count2 | count4 groups)
+  // pixData of HOGCache::init in its accumulation order (count1 | count2 | count4 groups): position of entry k inside
+  // the 16x16 block and its weight gradWeight * histWeights for each of the four cells (0 where it does not vote)
   int pix_x[256], pix_y[256];
-  int pix_ncell[256];
-  int pix_cell[256][4];
-  float pix_w[256][4];  // gradWeight * histWeights[c]
+  float pix_wcell[256][4];
 };
 
 enum SampleStatus : int

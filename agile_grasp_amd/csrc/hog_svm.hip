@@ -172,12 +172,10 @@ void hog_tables_host(HogTablesDev* t)
     {
       t->pix_x[k] = p.x;
       t->pix_y[k] = p.y;
-      t->pix_ncell[k] = p.n;
       for (int c = 0; c < 4; c++)
-      {
-        t->pix_cell[k][c] = p.cell[c];
-        t->pix_w[k][c] = p.w[c];
-      }
+        t->pix_wcell[k][c] = 0.f;
+      for (int c = 0; c < p.n; c++)
+        t->pix_wcell[k][p.cell[c]] = p.w[c];
       k++;
     }
 }
@@ -187,21 +185,25 @@ constexpr int kNBlocks = 77;  // 11 block columns (x = 0..80 step 8) x 7 block r
 constexpr int kCodeW = 96, kCodeH = 64;
 
 __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ images,
-  const int32_t* __restrict__ slot_of_hyp, const int64_t* __restrict__ n_hyp, const HogTablesDev* __restrict__ T,
+  const int32_t* __restrict__ slot_of_hyp, const int64_t* __restrict__ n_hyp, const HogTablesDev* __restrict__ Tg,
   const float* __restrict__ svm_w, double rho, agh_hypothesis* __restrict__ out, uint8_t* __restrict__ keep,
   double* __restrict__ sums, float* __restrict__ desc_out)
 {
   __shared__ uint32_t bm[kImageWords + 2];
   __shared__ uint8_t code[kCodeH * kCodeW];
-  __shared__ uint8_t nzk[kNBlocks][256];
+  __shared__ uint8_t nzk[kNBlocks][256];  // per block: pixData entries with a non-zero gradient, in order
   __shared__ int nzc[kNBlocks];
   __shared__ float hist[kNBlocks][36];
   __shared__ float grp[882];
+  __shared__ HogTablesDev Ts;  // the 11 KiB of tables are hit on every vote: keep them in LDS
 
   const int h = blockIdx.x;
   if ((int64_t) h >= *n_hyp)
     return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < (int) (sizeof(HogTablesDev) / 4); k += 256)
+    ((unsigned*) &Ts)[k] = ((const unsigned*) Tg)[k];
+  const HogTablesDev* T = &Ts;
   const uint32_t* im = images + (int64_t) slot_of_hyp[h] * kImageWords;
   for (int k = tid; k < kImageWords; k += 256)
     bm[k] = im[k];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
     code[p] = (uint8_t) ((sx + 1) * 3 + (sy + 1));
   }
   __syncthreads();
-  // per block: ordered list of the pixData entries with a non-zero gradient
+  // per block: ordered list of the pixData entries with a non-zero gradient (all other pixels vote +0.0f: nothing)
   for (int b = wave; b < kNBlocks; b += 4)
   {
     const int x0 = (b / 7) * 8, y0 = (b % 7) * 8;
@@ -238,37 +240,32 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
       nzc[b] = cnt;
   }
   __syncthreads();
-  // block histograms (HOGCache::getBlock): one (block, cell) per work item, pixData order
+  // block histograms (HOGCache::getBlock): one (block, cell) per work item, votes in pixData order.  The nine bins live
+  // in registers; every listed pixel adds mag * weight to its two bins and +0.0f (exact) to the others, and a pixel
+  // that does not vote for this cell has weight 0 -- so there is no data-dependent branch and no LDS read-modify-write.
   for (int wi = tid; wi < kNBlocks * 4; wi += 256)
   {
     const int b = wi >> 2, cell = wi & 3;
     const int x0 = (b / 7) * 8, y0 = (b % 7) * 8;
-    float* hh = &hist[b][cell * 9];
+    float hh[9];
+#pragma unroll
     for (int k = 0; k < 9; k++)
       hh[k] = 0.f;
     const int cnt = nzc[b];
     for (int q = 0; q < cnt; q++)
     {
       const int k = nzk[b][q];
-      const int nc = T->pix_ncell[k];
-      float w = 0.f;
-      bool mine = false;
-      for (int ci = 0; ci < nc; ci++)
-        if (T->pix_cell[k][ci] == cell)
-        {
-          w = T->pix_w[k][ci];
-          mine = true;
-        }
-      if (mine)
-      {
-        const int cd = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]];
-        const int h0 = T->bin0[cd], h1 = T->bin1[cd];
-        const float t0 = hh[h0] + T->mag0[cd] * w;
-        const float t1 = hh[h1] + T->mag1[cd] * w;
-        hh[h0] = t0;
-        hh[h1] = t1;
-      }
+      const float w = T->pix_wcell[k][cell];
+      const int cd = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]];
+      const int h0 = T->bin0[cd], h1 = T->bin1[cd];
+      const float v0 = T->mag0[cd] * w, v1 = T->mag1[cd] * w;
+#pragma unroll
+      for (int k2 = 0; k2 < 9; k2++)
+        hh[k2] = hh[k2] + ((k2 == h0) ? v0 : ((k2 == h1) ? v1 : 0.f));
     }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+      hist[b][cell * 9 + k] = hh[k];
   }
   __syncthreads();
   // L2-Hys (HOGCache::normalizeBlockHistogram), sequential per block
@@ -308,8 +305,16 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   if (tid == 0)
   {
     double s = 0;
-    for (int m = 0; m < 882; m++)
-      s += grp[m];
+    for (int m0 = 0; m0 < 882; m0 += 14)  // 882 = 63 x 14: loads in flight, adds in index order
+    {
+      float g_[14];
+#pragma unroll
+      for (int u = 0; u < 14; u++)
+        g_[u] = grp[m0 + u];
+#pragma unroll
+      for (int u = 0; u < 14; u++)
+        s += g_[u];
+    }
     const float res = (float) (s * 1.0 + 0.0);
     const double sum = -rho + 1.0 * res;  // CvSVM::predict: class_labels[sum > 0 ? 0 : 1] = {-1, +1}
     const uint8_t k = (sum > 0) ? 0 : 1;  // the reference keeps prediction == 1 (learning.cpp:225-227)
