@@ -262,6 +262,98 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
 // K1b: quadric.cpp:134-153 + solveGeneralizedEigenProblem (330-363) as a 9x9 symmetric-definite reduction.
 // 4 samples per 64-thread workgroup, 16 lanes per sample (9 active).  Mirrors oracle solve_taubin()/jacobi_sym<9>.
 // ---------------------------------------------------------------------------------------------------------------
+// One round of the round-robin Jacobi: the four disjoint pairs {(R+k) mod 9, (R-k) mod 9}, k = 1..4 (index R sits out).
+__device__ __forceinline__ double shfl16(double v, int src_in_group, int gbase)
+{
+  return __shfl(v, gbase + src_in_group);
+}
+
+template <int R>
+__device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], int gl, int gbase, bool row, bool active,
+  int sweep)
+{
+  // (1) every lane fetches (a_pq, a_pp, a_qq) of the four pairs from the lanes that own them, then keeps its own pair's
+  double apq = 0.0, app = 0.0, aqq = 0.0;
+  const int dd = row ? (gl - R + 9) % 9 : 0;
+  const int kk = dd <= 4 ? dd : 9 - dd;  // pair id 1..4 of this lane, 0: sits out / idle lane
+#pragma unroll
+  for (int k = 1; k <= 4; k++)
+  {
+    constexpr int unused = 0;
+    (void) unused;
+    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
+    const int p = a < b ? a : b, q = a < b ? b : a;
+    const double x_pq = shfl16(ar[q], p, gbase), x_pp = shfl16(ar[p], p, gbase), x_qq = shfl16(ar[q], q, gbase);
+    if (kk == k)
+    {
+      apq = x_pq;
+      app = x_pp;
+      aqq = x_qq;
+    }
+  }
+  // (2) rotation parameters of this lane's pair (both lanes of a pair compute the same values)
+  double c = 1.0, sn = 0.0;
+  int flag = 0;  // 1 rotate, 2 zero only
+  if (active && kk != 0 && apq != 0.0)
+  {
+    const double aabs = fabs(apq);
+    if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+      flag = 2;
+    else
+    {
+      const double theta = (aqq - app) / (2.0 * apq);
+      double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+      if (theta < 0.0)
+        t = -t;
+      c = 1.0 / sqrt(t * t + 1.0);
+      sn = t * c;
+      flag = 1;
+    }
+  }
+  // (3) column phase A <- A J, V <- V J: this lane's row, all four pairs (parameters come from the pair's first lane)
+#pragma unroll
+  for (int k = 1; k <= 4; k++)
+  {
+    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
+    const int p = a < b ? a : b, q = a < b ? b : a;
+    const double ck = shfl16(c, p, gbase), sk = shfl16(sn, p, gbase);
+    const int fk = __shfl(flag, gbase + p);
+    if (fk == 1)
+    {
+      const double akp = ar[p], akq = ar[q];
+      ar[p] = ck * akp - sk * akq;
+      ar[q] = sk * akp + ck * akq;
+      const double vkp = vr[p], vkq = vr[q];
+      vr[p] = ck * vkp - sk * vkq;
+      vr[q] = sk * vkp + ck * vkq;
+    }
+  }
+  // (4) row phase A <- J^T A: rows p and q of a pair are the two lanes of the pair; each fetches its mate's row
+  const int mate = (kk != 0) ? (2 * R - gl + 18) % 9 : gl;
+  const bool is_p = gl < mate;
+#pragma unroll
+  for (int j = 0; j < 9; j++)
+  {
+    const double other = shfl16(ar[j], mate, gbase);
+    if (flag == 1)
+      ar[j] = is_p ? (c * ar[j] - sn * other) : (sn * other + c * ar[j]);
+  }
+  // (5) the rotated entries are exactly zero (both triangles)
+#pragma unroll
+  for (int k = 1; k <= 4; k++)
+  {
+    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
+    const int p = a < b ? a : b, q = a < b ? b : a;
+    if (kk == k && flag != 0)
+    {
+      if (gl == p)
+        ar[q] = 0.0;
+      else
+        ar[p] = 0.0;
+    }
+  }
+}
+
 struct EigSmem
 {
   double M[10][10];
@@ -432,96 +524,46 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
     for (int j = 0; j < 9; j++)
       E.V[i][j] = (i == j) ? 1.0 : 0.0;
   __syncthreads();
-  // round-robin Jacobi (oracle jacobi_rr9): 9 rounds of 4 disjoint rotations per sweep; lane = matrix row for the
-  // column phase and for V, lane = matrix column for the row phase
+  // round-robin Jacobi (oracle jacobi_rr9) with the matrices in registers: lane gl of a 16-lane group holds row gl of A
+  // and of V.  The nine rounds of a sweep are unrolled so that every register index is a compile-time constant;
+  // values move between the lanes of a group with shuffles (no LDS round trips, no barriers inside a sweep).
+  double ar[9], vr[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++)
+  {
+    ar[j] = row ? E.A[i][j] : 0.0;
+    vr[j] = (row && i == j) ? 1.0 : 0.0;
+  }
+  const int gbase = lane & ~15;
   for (int sweep = 0; sweep < 30; sweep++)
   {
-    if (gl == 0)
-    {
-      double off = 0.0;
-      for (int p = 0; p < 8; p++)
-        for (int q = p + 1; q < 9; q++)
-          off += E.A[p][q] * E.A[p][q];
-      E.off = off;
-    }
-    __syncthreads();
-    const bool active = E.off != 0.0;
-    if (!__any(active))
+    // off == 0.0 in the oracle <=> every upper-triangle square is 0 (a sum of non-negative terms)
+    bool nz = false;
+#pragma unroll
+    for (int j = 1; j < 9; j++)
+      nz = nz || (row && j > gl && (ar[j] * ar[j] != 0.0));
+    const unsigned long long nzb = __ballot(nz);
+    const bool active = ((nzb >> gbase) & 0xffffull) != 0;
+    if (nzb == 0)
       break;
-    for (int r = 0; r < 9; r++)
+    jacobi_round<0>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<1>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<2>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<3>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<4>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<5>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<6>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<7>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<8>(ar, vr, gl, gbase, row, active, sweep);
+  }
+  if (row)
+  {
+#pragma unroll
+    for (int j = 0; j < 9; j++)
     {
-      // this lane's pair in round r: d = (gl - r) mod 9, partner = (r - d) mod 9, pair id k = min(d, 9 - d) in 1..4
-      const int dd = row ? (gl - r + 9) % 9 : 0;
-      const int kk = dd <= 4 ? dd : 9 - dd;  // 0: sits out
-      if (row && kk > 0 && dd <= 4)
-      {
-        const int mate = (r + 9 - dd) % 9;
-        const int p = gl < mate ? gl : mate, q = gl < mate ? mate : gl;
-        const double apq = E.A[p][q], app = E.A[p][p], aqq = E.A[q][q];
-        const double aabs = fabs(apq);
-        double c = 1.0, sn = 0.0;
-        int flag = 0;  // 1 rotate, 2 zero only
-        if (active && apq != 0.0)
-        {
-          if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
-            flag = 2;
-          else
-          {
-            const double theta = (aqq - app) / (2.0 * apq);
-            double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-            if (theta < 0.0)
-              t = -t;
-            c = 1.0 / sqrt(t * t + 1.0);
-            sn = t * c;
-            flag = 1;
-          }
-        }
-        E.cs[kk - 1][0] = c;
-        E.cs[kk - 1][1] = sn;
-        E.flag[kk - 1] = flag;
-      }
-      __syncthreads();
-      if (row)  // columns: A <- A J, V <- V J (lane = row k)
-        for (int m = 0; m < 4; m++)
-          if (E.flag[m] == 1)
-          {
-            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
-            const int p = a < b ? a : b, q = a < b ? b : a;
-            const double c = E.cs[m][0], sn = E.cs[m][1];
-            const double akp = E.A[i][p], akq = E.A[i][q];
-            E.A[i][p] = c * akp - sn * akq;
-            E.A[i][q] = sn * akp + c * akq;
-            const double vkp = E.V[i][p], vkq = E.V[i][q];
-            E.V[i][p] = c * vkp - sn * vkq;
-            E.V[i][q] = sn * vkp + c * vkq;
-          }
-      __syncthreads();
-      if (row)  // rows: A <- J^T A (lane = column k)
-        for (int m = 0; m < 4; m++)
-          if (E.flag[m] == 1)
-          {
-            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
-            const int p = a < b ? a : b, q = a < b ? b : a;
-            const double c = E.cs[m][0], sn = E.cs[m][1];
-            const double apk = E.A[p][i], aqk = E.A[q][i];
-            E.A[p][i] = c * apk - sn * aqk;
-            E.A[q][i] = sn * apk + c * aqk;
-          }
-      __syncthreads();
-      if (row)
-      {
-        for (int m = 0; m < 4; m++)
-          if (E.flag[m] != 0)
-          {
-            const int a = (r + m + 1) % 9, b = (r + 9 - (m + 1)) % 9;
-            const int p = a < b ? a : b, q = a < b ? b : a;
-            if (i == p)
-              E.A[p][q] = 0.0;
-          }
-        for (int j = i + 1; j < 9; j++)
-          E.A[j][i] = E.A[i][j];
-      }
-      __syncthreads();
+      E.V[i][j] = vr[j];
+      if (j == i)
+        E.A[i][i] = ar[j];
     }
   }
   __syncthreads();

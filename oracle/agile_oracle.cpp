@@ -275,8 +275,8 @@ void jacobi_sym(double A[NN][NN], double V[NN][NN], double d[NN])
  * Same rotations as jacobi_sym, but each sweep is organised in 9 rounds of 4 disjoint pairs
  * {(r+k) mod 9, (r-k) mod 9 : k = 1..4} (index r sits out); the four rotations of a round are computed from the
  * matrix at the start of the round and applied together: all column rotations (A <- A J), then all row rotations
- * (A <- J^T A), the rotated off-diagonal entries are set to exactly 0 and the lower triangle is refreshed from the
- * upper one.  Disjoint pairs touch disjoint columns / rows, so the order inside a phase is immaterial -- which is
+ * (A <- J^T A), and the rotated off-diagonal entries (both triangles) are set to exactly 0.  Rotation parameters and
+ * the convergence test read the upper triangle; the two triangles stay equal up to rounding.  Disjoint pairs touch disjoint columns / rows, so the order inside a phase is immaterial -- which is
  * what lets the GPU run a round with one lane per row.  Stands in for LAPACK dggev's QZ (quadric.cpp:330-363).
  * ------------------------------------------------------------------------------------------------- */
 void jacobi_rr9(double A[9][9], double V[9][9], double d[9])
@@ -346,10 +346,10 @@ void jacobi_rr9(double A[9][9], double V[9][9], double d[9])
           }
       for (int m = 0; m < 4; m++)
         if (rot[m] || zero[m])
+        {
           A[P[m]][Q[m]] = 0.0;
-      for (int i = 0; i < 9; i++)
-        for (int j = i + 1; j < 9; j++)
-          A[j][i] = A[i][j];
+          A[Q[m]][P[m]] = 0.0;
+        }
     }
   }
   for (int i = 0; i < 9; i++)
