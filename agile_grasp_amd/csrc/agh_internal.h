@@ -78,7 +78,8 @@ enum SampleStatus : int
   kStatusOk = 0,
   kStatusOverflow = 1,    // neighbourhood larger than the kernel's LDS capacity
   kStatusDegenerate = 2,  // N9 not positive definite: no frame, no hypotheses
-  kStatusRows = 3
+  kStatusRows = 3,
+  kStatusBadIndex = 4     // sample index outside the cloud (device-resident sample lists are validated on the device)
 };
 
 struct Ctx

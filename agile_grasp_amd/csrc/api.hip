@@ -582,6 +582,11 @@ static int check_flags(Ctx* c, hipStream_t st)
     c->err = "output buffer too small for the hypotheses found";
     return AGH_ERR_CAPACITY;
   }
+  if (flags[0] & 4)
+  {
+    c->err = "a sample index is outside the cloud";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
   return AGH_OK;
 }
 

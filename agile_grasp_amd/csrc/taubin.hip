@@ -32,7 +32,8 @@ constexpr int kChunk = 56;      // neighbours per summation chunk (56 x 37 doubl
 template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
-  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop)
+  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
+  int n_points)
 {
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
@@ -55,6 +56,15 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (!first_class && status[s] != kStatusOverflow)
     return;  // an earlier (smaller) capacity class already handled this sample
+  if (samples[s] < 0 || samples[s] >= n_points)
+  {
+    if (threadIdx.x == 0)
+    {
+      status[s] = kStatusBadIndex;
+      nt[s] = 0;
+    }
+    return;
+  }
   const float* qp = xyz + (int64_t) samples[s] * stride;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   if (tid == 0)
@@ -703,7 +713,8 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   if (ok ? (n <= nmin || n > CAP) : (nmin != 0))
     return;
   const bool valid = ok;
-  const float* qp = xyz + (int64_t) samples[s] * stride;
+  const bool bad_index = status[s] == kStatusBadIndex;
+  const float* qp = xyz + (int64_t) (bad_index ? 0 : samples[s]) * stride;
   if (!valid)
   {
     if (tid == 0)
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
       agh_frame f;
       for (int k = 0; k < 3; k++)
       {
-        f.sample[k] = (double) qp[k];
+        f.sample[k] = bad_index ? 0.0 : (double) qp[k];
         f.normal[k] = f.axis[k] = f.binormal[k] = 0.0;
       }
       for (int k = 0; k < 10; k++)
@@ -1087,6 +1098,8 @@ __global__ void k_flag_overflow(const int32_t* __restrict__ status, int S, int32
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < S && (status[i] == kStatusOverflow || status[i] == kStatusRows))
     atomicOr(&flags[0], 1);
+  if (i < S && status[i] == kStatusBadIndex)
+    atomicOr(&flags[0], 4);
 }
 
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
@@ -1104,13 +1117,13 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
     first = false;
   }
   hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
+    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments);
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind

@@ -66,6 +66,27 @@ def test_full_path_bit_exact(scene_name, svm_model):
     assert 0 < keep.sum() < keep.size
 
 
+@pytest.mark.parametrize("geom", [
+    dict(finger_width=0.012, hand_outer_diameter=0.11, hand_depth=0.07, hand_height=0.025, init_bite=0.015),
+    dict(finger_width=0.008, hand_outer_diameter=0.075, hand_depth=0.045, hand_height=0.015, init_bite=0.005),
+    dict(nn_radius_taubin=0.025, nn_radius_hands=0.07),
+])
+def test_other_hand_geometries_bit_exact(tiny_scene, geom):
+    """Finger-slot thresholds, bite depths, look-up tables and radii all derive from the parameters: check parity for
+    geometries other than the node defaults (learning_test.cpp uses init_bite 0.015, for instance)."""
+    from oracle import oracle_py as O
+
+    sc = tiny_scene
+    ctx = _ctx(sc, **geom)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ref = O.find_hands(O.default_params(sc.cam_origins, **geom), sc.xyz, sc.cam, sc.samples, want_images=True)
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert len(hyps) > 5
+    assert_hyps_equal(hyps, ref["hyps"])
+    assert np.array_equal(ctx.images(), ref["images"])
+
+
 def test_svm_file_loader_matches_memory_loader(tiny_scene, svm_model):
     sc = tiny_scene
     w, rho = svm_model
@@ -244,6 +265,17 @@ def test_device_resident_api_matches_host_api(tiny_scene, svm_model):
     torch.cuda.synchronize()
     n = int(n_t.item())
     from agile_grasp_amd import binding
+
+    dev.synchronize()  # also reports device-side errors of the asynchronous calls
+    bad = s_t.clone()
+    bad[5] = sc.n + 7  # device-resident sample lists are validated on the device: loud error, no out-of-bounds read
+    dev.find_hands_torch(bad, out_t, n_t, stream=st)
+    with pytest.raises(binding.AghError) as e:
+        dev.synchronize()
+    assert e.value.code == -1
+    dev.find_hands_torch(s_t, out_t, n_t, stream=st)
+    dev.classify_torch(keep_t, stream=st)
+    dev.synchronize()
 
     got = np.frombuffer(out_t.cpu().numpy().tobytes(), dtype=binding.HYP_DTYPE)[:n]
     assert n == len(ref)
