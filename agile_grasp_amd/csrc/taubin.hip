@@ -937,46 +937,99 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   }
   if (debug_stop == 3)
     return;
-  // exact sequential sums of the candidate columns, 64 per grab
+  // exact sequential sums of the candidate columns
   double best = -1.0;
   int best_j = 0x7fffffff;
-  for (;;)
+  if (ncnd <= 16)
   {
-    int c0 = 0;
-    if (lane == 0)
-      c0 = atomicAdd(&next_col, 64);
-    c0 = __shfl(c0, 0);
-    if (c0 >= ncnd)
-      break;
-    const bool have = c0 + lane < ncnd;
-    const int j = have ? (int) cand[c0 + lane] : 0;
-    const double jx = have ? nx[j] : 0.0, jy = have ? ny[j] : 0.0, jz = have ? nz[j] : 0.0;
-    double acc = 0.0;
-    int t = 0;
-    for (; t + 4 <= ks; t += 4)
+    // Few candidates (the usual case: 1-3): one candidate per wave at a time.  The 64 lanes form 64 terms
+    // (n_t . n_j)^6 at once; the reference's left-to-right sum is then a chain of adds over the lanes' values
+    // (v_readlane -> scalar operand), i.e. ~one dependent fp64 add per neighbour instead of the whole 9-flop term.
+    for (;;)
     {
-      double g6[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
+      int c = 0;
+      if (lane == 0)
+        c = atomicAdd(&next_col, 1);
+      c = __shfl(c, 0);
+      if (c >= ncnd)
+        break;
+      const int j = cand[c];
+      const double jx = nx[j], jy = ny[j], jz = nz[j];
+      double acc = 0.0;
+      for (int t0 = 0; t0 < ks; t0 += 64)
       {
-        const double gdot = (nx[t + u] * jx + ny[t + u] * jy) + nz[t + u] * jz;
-        const double g2 = gdot * gdot;
-        g6[u] = (g2 * g2) * g2;
-      }
+        const int t = t0 + lane;
+        double g6 = 0.0;
+        if (t < ks)
+        {
+          const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
+          const double g2 = gdot * gdot;
+          g6 = (g2 * g2) * g2;
+        }
+        const int lo = __double2loint(g6), hi = __double2hiint(g6);
+        const int cnt = min(64, ks - t0);
+        if (cnt == 64)
+        {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        acc += g6[u];
+          for (int l = 0; l < 64; l++)
+            acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+        }
+        else
+        {
+#pragma unroll
+          for (int l = 0; l < 64; l++)
+            if (l < cnt)
+              acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+        }
+      }
+      if (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff)
+      {
+        best = acc;
+        best_j = j;
+      }
     }
-    for (; t < ks; t++)
+  }
+  else
+  {
+    // many candidates (near-degenerate normals): 64 columns per grab, one column per lane
+    for (;;)
     {
-      const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
-      const double g2 = gdot * gdot;
-      acc += (g2 * g2) * g2;
-    }
-    if (have && (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff))
-    {
-      best = acc;
-      best_j = j;
+      int c0 = 0;
+      if (lane == 0)
+        c0 = atomicAdd(&next_col, 64);
+      c0 = __shfl(c0, 0);
+      if (c0 >= ncnd)
+        break;
+      const bool have = c0 + lane < ncnd;
+      const int j = have ? (int) cand[c0 + lane] : 0;
+      const double jx = have ? nx[j] : 0.0, jy = have ? ny[j] : 0.0, jz = have ? nz[j] : 0.0;
+      double acc = 0.0;
+      int t = 0;
+      for (; t + 4 <= ks; t += 4)
+      {
+        double g6[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+          const double gdot = (nx[t + u] * jx + ny[t + u] * jy) + nz[t + u] * jz;
+          const double g2 = gdot * gdot;
+          g6[u] = (g2 * g2) * g2;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          acc += g6[u];
+      }
+      for (; t < ks; t++)
+      {
+        const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
+        const double g2 = gdot * gdot;
+        acc += (g2 * g2) * g2;
+      }
+      if (have && (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff))
+      {
+        best = acc;
+        best_j = j;
+      }
     }
   }
   if (debug_stop == 4)
@@ -1134,14 +1187,14 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (rand_mode)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
   const double* co = &c->p.cam_origin[0][0];
-  // capacity classes (LDS = 24 B per normal): voxelised clouds fit the 1536 class (3-4 blocks per CU); the 4096 class
+  // capacity classes (LDS = 24 B per normal): voxelised clouds fit the 1280 class (4 blocks per CU); the 4096 class
   // only does work for the samples that need it
-  hipLaunchKernelGGL(k_taubin_frame<1536>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
+  hipLaunchKernelGGL(k_taubin_frame<1280>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
     co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame);
   hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1536, c->debug_stop_frame);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1280, c->debug_stop_frame);
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
