@@ -105,6 +105,7 @@ struct Ctx
   int* d_cell_count = nullptr;  // kCellCap
   int* d_block_sums = nullptr;
   int* d_cell_of = nullptr;     // n
+  int* d_rank_of = nullptr;     // n: rank of a point inside its cell
   float4* d_sorted = nullptr;   // n
   int64_t grid_cap = 0;
   bool has_cloud = false;

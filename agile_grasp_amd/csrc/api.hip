@@ -382,7 +382,7 @@ void agh_destroy(agh_ctx* ctx)
   if (c->stream)
     (void) hipStreamSynchronize(c->stream);
   void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
-    c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
+    c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep };
   for (void* p : ptrs)
@@ -416,7 +416,8 @@ int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes,
   if (n > c->grid_cap)
   {
     int rc;
-    if ((rc = dev_alloc(c, &c->d_cell_of, (size_t) n)) || (rc = dev_alloc(c, &c->d_sorted, (size_t) n)))
+    if ((rc = dev_alloc(c, &c->d_cell_of, (size_t) n)) || (rc = dev_alloc(c, &c->d_rank_of, (size_t) n)) ||
+        (rc = dev_alloc(c, &c->d_sorted, (size_t) n)))
       return rc;
     c->grid_cap = n;
   }

@@ -87,18 +87,41 @@ __global__ void k_desc_finish(GridDesc* d, double base_cell, int64_t n)
   d->ncell = dim[0] * dim[1] * dim[2];
 }
 
+// Cell histogram.  Clouds arrive in voxel order (localization.cpp:282-351), so consecutive points mostly share a cell:
+// each run of equal cells inside a wave issues ONE atomic (with return), and every point remembers its rank inside its
+// cell, which makes the scatter below atomic-free.
 __global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xyz, int64_t stride, int64_t n,
-  const GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ count)
+  const GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ rank_of, int* __restrict__ count)
 {
   const GridDesc g = *d;
-  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+  const int lane = threadIdx.x & 63;
+  const int64_t step = (int64_t) gridDim.x * blockDim.x;
+  const int64_t n_up = (n + 63) & ~(int64_t) 63;  // whole waves iterate together (the shuffles below need all lanes)
+  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n_up; i += step)
   {
-    const float* p = xyz + i * stride;
-    const int cx = cell_coord(g, (double) p[0], 0), cy = cell_coord(g, (double) p[1], 1),
-              cz = cell_coord(g, (double) p[2], 2);
-    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-    cell_of[i] = c;
-    atomicAdd(&count[c], 1);
+    int c = -1;
+    if (i < n)
+    {
+      const float* p = xyz + i * stride;
+      const int cx = cell_coord(g, (double) p[0], 0), cy = cell_coord(g, (double) p[1], 1),
+                cz = cell_coord(g, (double) p[2], 2);
+      c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    }
+    const int prev = __shfl_up(c, 1);
+    const bool head = (lane == 0) || (c != prev);
+    const unsigned long long hm = __ballot(head);
+    const int hl = 63 - __clzll((long long) (hm & ((2ull << lane) - 1ull)));  // head lane of this lane's run
+    const unsigned long long after = (hl == 63) ? 0ull : (hm >> (hl + 1));
+    const int runlen = after ? (__ffsll((long long) after)) : (64 - hl);
+    int base = 0;
+    if (head && c >= 0)
+      base = atomicAdd(&count[c], runlen);
+    base = __shfl(base, hl);
+    if (i < n)
+    {
+      cell_of[i] = c;
+      rank_of[i] = base + (lane - hl);
+    }
   }
 }
 
@@ -192,13 +215,12 @@ __global__ __launch_bounds__(256) void k_scan_final(const int* __restrict__ coun
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ xyz, int64_t stride,
-  const int32_t* __restrict__ cam, int64_t n, const int* __restrict__ cell_of, const int* __restrict__ cell_start,
-  int* __restrict__ count, float4* __restrict__ sorted)
+  const int32_t* __restrict__ cam, int64_t n, const int* __restrict__ cell_of, const int* __restrict__ rank_of,
+  const int* __restrict__ cell_start, float4* __restrict__ sorted)
 {
   for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
   {
-    const int c = cell_of[i];
-    const int pos = cell_start[c] + atomicSub(&count[c], 1) - 1;
+    const int pos = cell_start[cell_of[i]] + rank_of[i];
     const float* p = xyz + i * stride;
     const unsigned w = ((unsigned) i << 1) | (cam ? (unsigned) (cam[i] & 1) : 0u);
     sorted[pos] = make_float4(p[0], p[1], p[2], __uint_as_float(w));
@@ -218,7 +240,7 @@ int grid_build(Ctx* c, hipStream_t st)
   hipLaunchKernelGGL(k_desc_finish, dim3(1), dim3(1), 0, st, c->d_desc, base_cell, n);
   if (n > 0)
     hipLaunchKernelGGL(k_cell_count, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc,
-      c->d_cell_of, c->d_cell_count);
+      c->d_cell_of, c->d_rank_of, c->d_cell_count);
   const int sb = kCellCap / kScanBlock;
   hipLaunchKernelGGL(k_scan_sums, dim3(sb), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_block_sums);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, c->d_block_sums, c->d_desc);
@@ -226,7 +248,7 @@ int grid_build(Ctx* c, hipStream_t st)
     c->d_cell_start, (int) n);
   if (n > 0)
     hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, c->d_cam, n, c->d_cell_of,
-      c->d_cell_start, c->d_cell_count, c->d_sorted);
+      c->d_rank_of, c->d_cell_start, c->d_sorted);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
