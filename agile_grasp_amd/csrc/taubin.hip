@@ -88,31 +88,43 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   // ---- gather + FLANN distance filter + compaction into LDS ----
   const int total = rt.total;
   int row_cur = 0;
-  for (int j0 = 0; j0 < total; j0 += 256)
+  for (int j0 = 0; j0 < total; j0 += 1024)  // four candidates per thread: all four loads are in flight together
   {
-    const int j = j0 + tid;
-    bool pass = false;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    float d2 = 0.f;
-    if (j < total)
+    float4 pp[4];
+    bool have[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
     {
-      p = gv.sorted[row_advance(rt, j, row_cur)];
-      d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
-      pass = d2 < r2f;
+      const int j = j0 + u * 256 + tid;
+      have[u] = j < total;
+      if (have[u])
+        pp[u] = gv.sorted[row_advance(rt, j, row_cur)];
     }
-    const unsigned long long m = __ballot(pass);
-    int base = 0;
-    if (lane == 0 && m)
-      base = atomicAdd(&count, __popcll(m));
-    base = __shfl(base, 0);
-    if (pass)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
     {
-      const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (k < CAP)
+      const float4 p = pp[u];
+      float d2 = 0.f;
+      bool pass = false;
+      if (have[u])
       {
-        stage[k] = p;
-        key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
-        atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
+        d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
+        pass = d2 < r2f;
+      }
+      const unsigned long long m = __ballot(pass);
+      int base = 0;
+      if (lane == 0 && m)
+        base = atomicAdd(&count, __popcll(m));
+      base = __shfl(base, 0);
+      if (pass)
+      {
+        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < CAP)
+        {
+          stage[k] = p;
+          key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
+          atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
+        }
       }
     }
   }

@@ -1,0 +1,300 @@
+// localization.h -- the Localization facade (include/agile_grasp/localization.h:64-351) over the MI355X hand search.
+//
+// Kept: constructors, every setter, localizeHands(cloud, size_left, indices, calculates_antipodal, uses_clustering),
+// predictAntipodalHands(hand_list, svm_filename), filterHands.  The preprocessing that precedes the hot path
+// (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355) is restated here on the
+// host, operation for operation, because its output ORDER defines the point indices the search works on; moving it to
+// the GPU is the first "next" row of SURVEY 8f.  Not carried over: the RANSAC table-plane removal behind
+// uses_clustering (localization.cpp:51-98, pcl::SACSegmentation; training path only), findHandles (HandleSearch, out of
+// scope), the Plot members, and the PCD-filename overloads unless PCL is available.
+#ifndef AGILE_GRASP_AMD_LOCALIZATION_H
+#define AGILE_GRASP_AMD_LOCALIZATION_H
+
+#include <cmath>
+#include <iostream>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "hand_search.h"
+#include "learning.h"
+
+namespace agile_grasp_amd
+{
+
+class Localization
+{
+public:
+  Localization() : num_threads_(1), num_samples_(2000), filters_boundaries_(false), plotting_mode_(0) { init(); }
+  Localization(int num_threads, bool filters_boundaries, int plotting_mode)
+    : num_threads_(num_threads), num_samples_(2000), filters_boundaries_(filters_boundaries), plotting_mode_(plotting_mode)
+  {
+    init();
+  }
+
+  // ---- setters (localization.h:148-259) ----
+  void setCameraTransforms(const Matrix4d& cam_tf_left, const Matrix4d& cam_tf_right)
+  {
+    cam_tf_left_ = cam_tf_left;
+    cam_tf_right_ = cam_tf_right;
+    search_.reset();
+  }
+  const Matrix4d& getCameraTransform(bool is_left) { return is_left ? cam_tf_left_ : cam_tf_right_; }
+  void setWorkspace(const VectorXd& workspace) { workspace_ = workspace; }
+  void setNumSamples(int num_samples)
+  {
+    num_samples_ = num_samples;
+    search_.reset();
+  }
+  // stored but never forwarded, exactly like the reference (localization.h:189-201 vs localization.cpp:111-112)
+  void setNeighborhoodRadiusHands(double r) { nn_radius_hands_ = r; }
+  void setNeighborhoodRadiusTaubin(double r) { nn_radius_taubin_ = r; }
+  void setFingerWidth(double v)
+  {
+    finger_width_ = v;
+    search_.reset();
+  }
+  void setHandDepth(double v)
+  {
+    hand_depth_ = v;
+    search_.reset();
+  }
+  void setHandOuterDiameter(double v)
+  {
+    hand_outer_diameter_ = v;
+    search_.reset();
+  }
+  void setInitBite(double v)
+  {
+    init_bite_ = v;
+    search_.reset();
+  }
+  void setHandHeight(double v)
+  {
+    hand_height_ = v;
+    search_.reset();
+  }
+  // additions: the reference hard-wires these inside HandSearch
+  void setDeterministicNormalEstimation(bool b)
+  {
+    deterministic_ = b;
+    search_.reset();
+  }
+  void setDevice(int device)
+  {
+    device_ = device;
+    search_.reset();
+  }
+
+  /** localization.cpp:3-140 */
+  std::vector<GraspHypothesis> localizeHands(const PointCloud::Ptr& cloud_in, int size_left,
+    const std::vector<int>& indices, bool calculates_antipodal, bool uses_clustering)
+  {
+    std::vector<GraspHypothesis> hand_list;
+    if (size_left == 0 || !cloud_in || cloud_in->size() == 0)
+    {
+      std::cout << "Input cloud is empty!\n";
+      std::cout << size_left << std::endl;
+      return hand_list;
+    }
+    // camera source of every point (0 = left, 1 = right), localization.cpp:17-24
+    std::cout << "Generating camera sources for " << cloud_in->size() << " points ...\n";
+    std::vector<int> cam(cloud_in->size(), 0);
+    for (std::size_t i = (std::size_t) size_left; i < cam.size(); i++)
+      cam[i] = 1;
+    // pcl::removeNaNFromPointCloud(*cloud_in, *cloud_in, ...) (27): in place, order preserved.  NB the reference does
+    // NOT re-index pts_cam_source here; neither do we (a cloud with NaNs shifts camera ids exactly as it does there).
+    {
+      std::size_t k = 0;
+      for (std::size_t i = 0; i < cloud_in->points.size(); i++)
+      {
+        const float x = cloud_in->points[i].x, y = cloud_in->points[i].y, z = cloud_in->points[i].z;
+        if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z))
+          cloud_in->points[k++] = cloud_in->points[i];
+      }
+      cloud_in->points.resize(k);
+    }
+    std::cout << "Filtering workspace ...\n";
+    PointCloud::Ptr cloud(new PointCloud);
+    std::vector<int> cam_ws;
+    filterWorkspace(cloud_in, cam, cloud, cam_ws);
+    std::cout << " " << cloud->size() << " points left\n";
+    std::cout << "Voxelizing point cloud\n";
+    PointCloud::Ptr voxels(new PointCloud);
+    std::vector<int> cam_vox;
+    voxelizeCloud(cloud, cam_ws, voxels, cam_vox, 0.003);
+    std::cout << " Created " << voxels->points.size() << " voxels\n";
+    if (uses_clustering)
+      std::cout << " (table-plane removal needs pcl::SACSegmentation and is not part of this build; continuing)\n";
+    VectorXi pts_cam_source(cam_vox.size());
+    for (std::size_t i = 0; i < cam_vox.size(); i++)
+      pts_cam_source(i) = cam_vox[i];
+    ensureSearch();
+    hand_list = search_->findHands(voxels, pts_cam_source, indices, voxels, calculates_antipodal, uses_clustering);
+    if (filters_boundaries_)
+    {
+      std::cout << "Filtering out hands close to workspace boundaries ...\n";
+      hand_list = filterHands(hand_list);
+      std::cout << " # hands left: " << hand_list.size() << "\n";
+    }
+    last_cloud_ = voxels;
+    last_cam_ = pts_cam_source;
+    return hand_list;
+  }
+
+  /** localization.cpp:142-167 */
+  std::vector<GraspHypothesis> predictAntipodalHands(const std::vector<GraspHypothesis>& hand_list,
+    const std::string& svm_filename)
+  {
+    if (!search_)
+    {
+      std::cout << " Error: predictAntipodalHands needs a preceding localizeHands\n";
+      return std::vector<GraspHypothesis>();
+    }
+    Learning learn(*search_, num_threads_);
+    Matrix3Xd cams_mat;  // the search already holds both camera origins (localization.cpp:147-150)
+    std::vector<GraspHypothesis> antipodal_hands = learn.classify(hand_list, svm_filename, cams_mat);
+    std::cout << antipodal_hands.size() << " antipodal hand configurations found\n";
+    return antipodal_hands;
+  }
+
+  /** the voxelised cloud and camera ids the last localizeHands searched (what the reference plots) */
+  const PointCloud::Ptr& getSearchedCloud() const { return last_cloud_; }
+  const VectorXi& getSearchedCamSource() const { return last_cam_; }
+
+  // ---- preprocessing, public so that tests can call it ----
+  /** localization.cpp:216-245 */
+  void filterWorkspace(const PointCloud::Ptr& cloud_in, const std::vector<int>& cam_in, PointCloud::Ptr& cloud_out,
+    std::vector<int>& cam_out) const
+  {
+    PointCloud::Ptr cloud(new PointCloud);
+    cam_out.clear();
+    for (std::size_t i = 0; i < cloud_in->points.size(); i++)
+    {
+      const float x = cloud_in->points[i].x, y = cloud_in->points[i].y, z = cloud_in->points[i].z;
+      if (x >= workspace_(0) && x <= workspace_(1) && y >= workspace_(2) && y <= workspace_(3) && z >= workspace_(4) &&
+          z <= workspace_(5))
+      {
+        cloud->points.push_back(cloud_in->points[i]);
+        cam_out.push_back(cam_in[i]);
+      }
+    }
+    cloud_out = cloud;
+  }
+
+  /** localization.cpp:247-355: per-camera minimum, floor((p - min) / cell), unique in lexicographic order, back to
+   *  coordinates as voxel * cell + min; camera 0 block first, then camera 1. */
+  void voxelizeCloud(const PointCloud::Ptr& cloud_in, const std::vector<int>& cam_in, PointCloud::Ptr& cloud_out,
+    std::vector<int>& cam_out, double cell_size) const
+  {
+    double mn[2][3] = { { 10000, 10000, 10000 }, { 10000, 10000, 10000 } };
+    const std::size_t n = cloud_in->points.size();
+    for (std::size_t i = 0; i < n; i++)
+    {
+      const int c = cam_in[i];
+      if (c != 0 && c != 1)
+        continue;
+      const float p[3] = { cloud_in->points[i].x, cloud_in->points[i].y, cloud_in->points[i].z };
+      for (int a = 0; a < 3; a++)
+        if (p[a] < mn[c][a])
+          mn[c][a] = p[a];
+    }
+    struct Vox
+    {
+      int v[3];
+      bool operator<(const Vox& o) const
+      {
+        for (int a = 0; a < 3; a++)
+          if (v[a] != o.v[a])
+            return v[a] < o.v[a];
+        return false;
+      }
+    };
+    std::set<Vox> bins[2];
+    for (std::size_t i = 0; i < n; i++)
+    {
+      const int c = cam_in[i];
+      if (c != 0 && c != 1)
+        continue;
+      const double p[3] = { (double) cloud_in->points[i].x, (double) cloud_in->points[i].y, (double) cloud_in->points[i].z };
+      Vox vx;
+      for (int a = 0; a < 3; a++)
+        vx.v[a] = (int) std::floor((p[a] - mn[c][a]) / cell_size);
+      bins[c].insert(vx);
+    }
+    PointCloud::Ptr cloud(new PointCloud);
+    cam_out.clear();
+    for (int c = 0; c < 2; c++)
+      for (std::set<Vox>::const_iterator it = bins[c].begin(); it != bins[c].end(); ++it)
+      {
+        cloud->points.resize(cloud->points.size() + 1);
+        cloud->points.back().x = (float) ((double) it->v[0] * cell_size + 1.0 * mn[c][0]);
+        cloud->points.back().y = (float) ((double) it->v[1] * cell_size + 1.0 * mn[c][1]);
+        cloud->points.back().z = (float) ((double) it->v[2] * cell_size + 1.0 * mn[c][2]);
+        cam_out.push_back(c);
+      }
+    cloud_out = cloud;
+  }
+
+  /** localization.cpp:364-388 */
+  std::vector<GraspHypothesis> filterHands(const std::vector<GraspHypothesis>& hand_list) const
+  {
+    const double MIN_DIST = 0.02;
+    std::vector<GraspHypothesis> filtered;
+    for (std::size_t i = 0; i < hand_list.size(); i++)
+    {
+      const Vector3d& center = hand_list[i].getGraspSurface();
+      std::size_t k;
+      for (k = 0; k < workspace_.size(); k++)
+        if (std::fabs(center((int) std::floor(k / 2.0)) - workspace_(k)) < MIN_DIST)
+          break;
+      if (k == workspace_.size())
+        filtered.push_back(hand_list[i]);
+    }
+    return filtered;
+  }
+
+private:
+  void init()
+  {
+    workspace_ = VectorXd(6);
+    const double ws[6] = { -1.0, 1.0, -1.0, 1.0, -1.0, 1.0 };  // find_grasps.cpp:19
+    for (int i = 0; i < 6; i++)
+      workspace_(i) = ws[i];
+    finger_width_ = 0.01;  // find_grasps.cpp:13-17
+    hand_outer_diameter_ = 0.09;
+    hand_depth_ = 0.06;
+    init_bite_ = 0.01;
+    hand_height_ = 0.02;
+    nn_radius_taubin_ = 0.03;
+    nn_radius_hands_ = 0.08;
+    deterministic_ = false;
+    device_ = 0;
+  }
+  void ensureSearch()
+  {
+    if (search_)
+      return;
+    search_.reset(new HandSearch(finger_width_, hand_outer_diameter_, hand_depth_, hand_height_, init_bite_,
+      num_threads_, num_samples_, cam_tf_left_, false));
+    search_->setCamTfRight(cam_tf_right_);
+    search_->setDeterministicNormalEstimation(deterministic_);
+    search_->setDevice(device_);
+  }
+
+  int num_threads_, num_samples_;
+  bool filters_boundaries_;
+  int plotting_mode_;
+  Matrix4d cam_tf_left_, cam_tf_right_;
+  VectorXd workspace_;
+  double finger_width_, hand_outer_diameter_, hand_depth_, init_bite_, hand_height_, nn_radius_taubin_, nn_radius_hands_;
+  bool deterministic_;
+  int device_;
+  std::unique_ptr<HandSearch> search_;
+  PointCloud::Ptr last_cloud_;
+  VectorXi last_cam_;
+};
+
+}  // namespace agile_grasp_amd
+#endif

@@ -30,6 +30,7 @@ typedef Eigen::Vector3d Vector3d;
 typedef Eigen::Matrix4d Matrix4d;
 typedef Eigen::VectorXi VectorXi;
 typedef Eigen::Matrix3Xd Matrix3Xd;
+typedef Eigen::VectorXd VectorXd;
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
 }  // namespace agile_grasp_amd
@@ -62,6 +63,15 @@ struct VectorXi
   int& operator()(std::size_t i) { return d[i]; }
   std::size_t size() const { return d.size(); }
   const int* data() const { return d.data(); }
+};
+struct VectorXd
+{
+  std::vector<double> d;
+  VectorXd() {}
+  explicit VectorXd(std::size_t n) : d(n, 0.0) {}
+  double operator()(std::size_t i) const { return d[i]; }
+  double& operator()(std::size_t i) { return d[i]; }
+  std::size_t size() const { return d.size(); }
 };
 struct Matrix3Xd  // 3 x n, column-major like Eigen
 {

@@ -1,0 +1,80 @@
+// localization_test.cpp -- drives the Localization facade (include/agile_grasp_amd/localization.h) on a RAW cloud
+// (NaNs, points outside the workspace, no voxelisation), like src/tests/test_local_axes.cpp drives the reference's.
+//   localization_test <raw.bin> <svm file> <mode: voxels|hands>
+// raw.bin: int64 n, int64 size_left, int64 n_idx, double ws[6], double cam_left[3], double cam_right[3], n*3 float xyz,
+// n_idx int32 indices (into the voxelised cloud).
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "agile_grasp_amd/localization.h"
+
+using namespace agile_grasp_amd;
+
+int main(int argc, char** argv)
+{
+  if (argc < 4)
+    return 2;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f)
+    return 2;
+  long long n = 0, size_left = 0, n_idx = 0;
+  double ws[6], cl[3], cr[3];
+  if (std::fread(&n, 8, 1, f) != 1 || std::fread(&size_left, 8, 1, f) != 1 || std::fread(&n_idx, 8, 1, f) != 1 ||
+      std::fread(ws, 8, 6, f) != 6 || std::fread(cl, 8, 3, f) != 3 || std::fread(cr, 8, 3, f) != 3)
+    return 2;
+  std::vector<float> xyz(3 * (size_t) n);
+  std::vector<int> idx((size_t) n_idx);
+  if (std::fread(xyz.data(), 4, xyz.size(), f) != xyz.size() || std::fread(idx.data(), 4, idx.size(), f) != idx.size())
+    return 2;
+  std::fclose(f);
+  PointCloud::Ptr cloud(new PointCloud);
+  cloud->points.resize((size_t) n);
+  for (long long i = 0; i < n; i++)
+  {
+    cloud->points[(size_t) i].x = xyz[3 * i];
+    cloud->points[(size_t) i].y = xyz[3 * i + 1];
+    cloud->points[(size_t) i].z = xyz[3 * i + 2];
+  }
+  Matrix4d tl, tr;
+  for (int r = 0; r < 3; r++)
+  {
+    tl(r, 3) = cl[r];
+    tr(r, 3) = cr[r];
+  }
+  Localization loc(1, false, 0);
+  loc.setCameraTransforms(tl, tr);
+  VectorXd w(6);
+  for (int i = 0; i < 6; i++)
+    w(i) = ws[i];
+  loc.setWorkspace(w);
+  loc.setDeterministicNormalEstimation(true);
+  if (std::strcmp(argv[3], "voxels") == 0)
+  {
+    // preprocessing only (runs without a GPU): NaN removal is part of localizeHands, so mimic its order here
+    std::vector<int> cam((size_t) n, 0);
+    for (long long i = size_left; i < n; i++)
+      cam[(size_t) i] = 1;
+    size_t k = 0;
+    for (size_t i = 0; i < cloud->points.size(); i++)
+      if (std::isfinite(cloud->points[i].x) && std::isfinite(cloud->points[i].y) && std::isfinite(cloud->points[i].z))
+        cloud->points[k++] = cloud->points[i];
+    cloud->points.resize(k);
+    PointCloud::Ptr c2, c3;
+    std::vector<int> cam2, cam3;
+    loc.filterWorkspace(cloud, cam, c2, cam2);
+    loc.voxelizeCloud(c2, cam2, c3, cam3, 0.003);
+    std::printf("VOXELS %zu\n", c3->points.size());
+    for (size_t i = 0; i < c3->points.size(); i++)
+      std::printf("V %.9g %.9g %.9g %d\n", c3->points[i].x, c3->points[i].y, c3->points[i].z, cam3[i]);
+    return 0;
+  }
+  std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, false, false);
+  std::vector<GraspHypothesis> kept = loc.predictAntipodalHands(hands, argv[2]);
+  std::printf("RESULT %zu %zu %zu\n", loc.getSearchedCloud() ? loc.getSearchedCloud()->size() : (size_t) 0, hands.size(),
+    kept.size());
+  for (size_t i = 0; i < hands.size(); i++)
+    std::printf("H %.17g %.17g %.17g %.17g\n", hands[i].getGraspSurface()(0), hands[i].getGraspBottom()(1),
+      hands[i].getApproach()(2), hands[i].getGraspWidth());
+  return 0;
+}

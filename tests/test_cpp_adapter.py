@@ -79,3 +79,105 @@ def test_adapter_matches_c_abi(tmp_path, tiny_scene, svm_model, deterministic):
         assert int(row[7]) == h["cam_source"] and int(row[8]) == h["n_in_box"]
     kept_idx = [int(l.split()[1]) for l in lines if l.startswith("A ")]
     assert kept_idx == list(np.nonzero(keep)[0])
+
+
+# ---- Localization facade: host-side preprocessing restated from localization.cpp:25-45, 216-355 ----
+def _build_loc(tmp_path):
+    from agile_grasp_amd import build
+
+    build.build()
+    exe = str(tmp_path / "localization_test")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "localization_test.cpp"), "-o", exe, "-L" + libdir,
+                           "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _raw_cloud(seed=11):
+    """A raw two-view cloud as it reaches Localization::localizeHands: unvoxelised, with NaNs and outliers."""
+    from agile_grasp_amd import synthetic
+
+    rng = np.random.default_rng(seed)
+    table = (0.55, 0.95, -0.2, 0.2, -0.10)
+    raw = synthetic.to_scene_frame(synthetic._surface_points(np.random.default_rng(seed), table, 3, 0.002))
+    left = (raw[rng.random(len(raw)) < 0.7] + rng.uniform(-3e-4, 3e-4, (1, 3))).astype(np.float32)
+    right = (raw[rng.random(len(raw)) < 0.7] + rng.uniform(-3e-4, 3e-4, (1, 3))).astype(np.float32)
+    far = rng.uniform(2.0, 3.0, (50, 3)).astype(np.float32)  # outside the workspace
+    xyz = np.concatenate([left, far[:25], right, far[25:]])
+    size_left = len(left) + 25
+    xyz[rng.choice(len(xyz), 40, replace=False)] = np.nan
+    ws = np.array([-0.5, 1.9, -1.2, 1.2, -1.2, 1.2])
+    return xyz, size_left, ws, synthetic.to_scene_frame(synthetic.camera_origins())
+
+
+def _preprocess_numpy(xyz, size_left, ws):
+    """numpy restatement of the reference's preprocessing (the reference's camera-id misalignment after NaN removal
+    included: pts_cam_source is built before removeNaNFromPointCloud and never re-indexed, localization.cpp:17-33)."""
+    cam_full = np.zeros(len(xyz), np.int32)
+    cam_full[size_left:] = 1
+    ok = np.isfinite(xyz).all(1)
+    p = xyz[ok]
+    cam = cam_full[:len(p)]
+    inb = ((p[:, 0] >= ws[0]) & (p[:, 0] <= ws[1]) & (p[:, 1] >= ws[2]) & (p[:, 1] <= ws[3]) & (p[:, 2] >= ws[4])
+           & (p[:, 2] <= ws[5]))
+    p, cam = p[inb], cam[inb]
+    out, out_cam = [], []
+    for c in (0, 1):
+        q = p[cam == c]
+        mn = q.min(0).astype(np.float64)
+        vox = np.unique(np.floor((q.astype(np.float64) - mn) / 0.003).astype(np.int64), axis=0)
+        out.append((vox.astype(np.float64) * 0.003 + 1.0 * mn).astype(np.float32))
+        out_cam.append(np.full(len(vox), c, np.int32))
+    return np.concatenate(out), np.concatenate(out_cam)
+
+
+def _dump_raw(path, xyz, size_left, idx, ws, cams):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qqq", len(xyz), size_left, len(idx)))
+        f.write(np.asarray(ws, np.float64).tobytes())
+        f.write(np.asarray(cams, np.float64).tobytes())
+        f.write(xyz.astype(np.float32).tobytes())
+        f.write(np.asarray(idx, np.int32).tobytes())
+
+
+def test_localization_preprocessing_matches_restatement(tmp_path):
+    exe = _build_loc(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, [], ws, cams)
+    out = subprocess.run([exe, path, "none", "voxels"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("V ")]
+    got = np.array([[np.float32(v) for v in r[:3]] for r in rows], np.float32)
+    got_cam = np.array([int(r[3]) for r in rows], np.int32)
+    exp, exp_cam = _preprocess_numpy(xyz, size_left, ws)
+    assert len(got) == len(exp) > 5000
+    assert np.array_equal(got, exp) and np.array_equal(got_cam, exp_cam)
+
+
+@pytest.mark.gpu
+def test_localization_facade_matches_c_abi(tmp_path, svm_model):
+    from agile_grasp_amd import binding
+
+    exe = _build_loc(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    vox, vcam = _preprocess_numpy(xyz, size_left, ws)
+    idx = np.sort(np.random.default_rng(0).permutation(len(vox))[:48]).astype(np.int32)
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, idx, ws, cams)
+    out = subprocess.run([exe, path, os.path.join(GOLD, "svm_032015_linear_20_20_same"), "hands"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    res = [l for l in lines if l.startswith("RESULT")][0].split()
+    ctx = binding.Context(cams)
+    ctx.set_cloud(vox, vcam)
+    hyps = ctx.find_hands(idx)
+    ctx.load_svm(*svm_model)
+    keep = ctx.classify()
+    assert int(res[1]) == len(vox) and int(res[2]) == len(hyps) and int(res[3]) == int(keep.sum())
+    assert len(hyps) > 0
+    hl = [[float(v) for v in l.split()[1:]] for l in lines if l.startswith("H ")]
+    for row, h in zip(hl, hyps):
+        assert row == [float(h["surface"][0]), float(h["bottom"][1]), float(h["approach"][2]), float(h["width"])]
