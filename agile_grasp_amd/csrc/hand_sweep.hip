@@ -54,21 +54,24 @@ __device__ __forceinline__ int wave_sum_i32(int v)
   return v;
 }
 
-constexpr int kTile = 1536;  // cropped points staged in LDS at a time (24 KiB of double2 + 6 KiB of ids): 3 blocks/CU
-static_assert(kTile >= 1024, "a batch of 1024 candidates must fit an empty tile");
+// Cropped points staged in LDS at a time: 2048 x double2 (32 KiB) for the online path, 1536 x (double2 + point id)
+// (30 KiB) when per-point normals are needed for the antipodal test -- both leave room for 3 blocks per CU.
 
 __device__ __forceinline__ unsigned lowmask(int n)
 {
   return n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
 }
 
+template <bool NORMALS>
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg)
 {
+  constexpr int kTile = NORMALS ? 1536 : 2048;
+  static_assert(kTile >= 1024, "a batch of 1024 candidates must fit an empty tile");
   __shared__ double2 pts[kTile];
-  __shared__ unsigned pid[kTile];
+  __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
   __shared__ HandGeom G;
   __shared__ double thr_s[64];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
   __shared__ unsigned img[8][kImageWords + 2];
-  __shared__ int cnt_ball, cnt_crop, any_hand;
+  __shared__ int cnt_ball, cnt_crop, any_hand, pending;
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     cnt_ball = 0;
     cnt_crop = 0;
     any_hand = 0;
+    pending = 0;
   }
   for (int k = tid; k < 8 * 44; k += 256)
     (&regmask[0][0])[k] = 0u;
@@ -178,119 +182,105 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     return;
   AGH_STAMP(1);
 
-  // One batch of 1024 candidates (four per thread, all loads in flight together): FLANN filter, hand-frame
-  // transform, crop (rotating_hand.cpp:26,37-51), append to the LDS tile.
-  int row_cur = 0;
-  auto batch = [&](int j0, bool count_ball) {
-    float4 pp[4];
-    bool have[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
+  // Gather: every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes, two loads in
+  // flight per lane (row base and length are wave-uniform: no per-candidate row look-up, fully coalesced).  Each
+  // candidate is filtered (FLANN float32 distance), rotated into the hand frame and cropped (rotating_hand.cpp:26,37-51)
+  // and the survivors are appended to the LDS tile with one reservation per wave-instruction.  A wave pauses when fewer
+  // than 512 slots are left (4 waves x 128 candidates is the most that can still arrive), so a neighbourhood that does
+  // not fit one tile simply streams through it in several rounds; the cursor (row, offset) says where to resume.
+  int cur_r = wave, cur_i = 0, nball = 0;
+  const int nrows = rt.nrows;
+  auto gather_reset = [&]() {
+    cur_r = wave;
+    cur_i = 0;
+  };
+  auto consume1 = [&](const float4& p, bool have, bool count_ball) {
+    bool keep = false;
+    double tx = 0.0, ty = 0.0;
+    unsigned w = 0;
+    if (have)
     {
-      const int j = j0 + u * 256 + tid;
-      have[u] = j < total;
-      if (have[u])
-        pp[u] = gv.sorted[row_advance(rt, j, row_cur)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-    {
-      bool inball = false, keep = false;
-      double tx = 0.0, ty = 0.0;
-      unsigned w = 0;
-      if (have[u])
+      const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
+      if (d2 < r2f)
       {
-        const float4 p = pp[u];
-        const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
-        inball = d2 < r2f;
-        if (inball)
+        nball += count_ball ? 1 : 0;
+        const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
+        const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
+        keep = (tz > -1.0 * hh) && (tz < hh);
+        if (keep)  // only ~1/4 of the ball survives the crop: the other two rows of frame^T are computed for those
         {
-          const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
-          const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
-          keep = (tz > -1.0 * hh) && (tz < hh);
-          if (keep)  // only ~1/4 of the ball survives the crop: the other two rows of frame^T are computed for those
-          {
-            tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
-            ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
-            w = __float_as_uint(p.w);
-          }
+          tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+          ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+          w = __float_as_uint(p.w);
         }
       }
-      const unsigned long long mk = __ballot(keep);
+    }
+    const unsigned long long mk = __ballot(keep);
+    if (mk)
+    {
       int base = 0;
-      if (count_ball)
-      {
-        const unsigned long long mb = __ballot(inball);
-        if (lane == 0 && mb)
-          atomicAdd(&cnt_ball, __popcll(mb));
-      }
-      if (lane == 0 && mk)
+      if (lane == 0)
         base = atomicAdd(&cnt_crop, __popcll(mk));
       base = __shfl(base, 0);
       if (keep)
       {
-        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
-        if (k < kTile)
-        {
-          pts[k] = make_double2(tx, ty);
+        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));  // < kTile by the pause rule below
+        pts[k] = make_double2(tx, ty);
+        if (NORMALS)
           pid[k] = w;
-        }
       }
     }
   };
-  // Fill the LDS tile from candidate j0 on; returns the tile's point count (block-uniform).  Batches that are certain to
-  // fit run back to back; once fewer than 1024 slots are left one more batch is tried optimistically (only ~1/6 of
-  // the candidates survive the ball + crop tests) and rolled back if it does not fit -- it is then redone in the
-  // next tile.  Typical neighbourhoods (~1400 cropped points) therefore take exactly one tile.
-  auto fill = [&](int& j0, bool count_ball) -> int {
-    for (;;)
+  // Fills the tile from the cursors on; returns the tile's point count and whether every wave reached the end.
+  // Must be entered with cnt_crop == 0 made visible by a barrier.
+  auto gather_tile = [&](bool count_ball, bool& all_done) -> int {
+    while (cur_r < nrows)
     {
-      __syncthreads();
-      const int c = cnt_crop;
-      const int cb = cnt_ball;
-      __syncthreads();
-      if (j0 >= total)
-        return c;
-      const int m = (kTile - c) / 1024;
-      if (m > 0)
+      if (*(volatile int*) &cnt_crop > kTile - 512)
+        break;
+      const int rb = rt.begin[cur_r];
+      const int len = rt.prefix[cur_r + 1] - rt.prefix[cur_r];
+      if (cur_i < len)
       {
-        for (int b = 0; b < m && j0 < total; b++, j0 += 1024)
-          batch(j0, count_ball);
-        continue;
+        const bool h0 = cur_i + lane < len, h1 = cur_i + 64 + lane < len;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        if (h0)
+          p0 = gv.sorted[rb + cur_i + lane];
+        if (h1)
+          p1 = gv.sorted[rb + cur_i + 64 + lane];
+        consume1(p0, h0, count_ball);
+        if (cur_i + 64 < len)
+          consume1(p1, h1, count_ball);
+        cur_i += 128;
       }
-      if (c > kTile - 128)
-        return c;
-      const int row_save = row_cur;
-      batch(j0, count_ball);  // writes beyond the tile are dropped inside
-      __syncthreads();
-      const int c2 = cnt_crop;
-      __syncthreads();
-      if (c2 > kTile)
+      if (cur_i >= len)
       {
-        if (tid == 0)
-        {
-          cnt_crop = c;  // roll back; this batch is redone in the next tile
-          cnt_ball = cb;
-        }
-        row_cur = row_save;  // the row cursor only moves forward: rewind it for the redo
-        __syncthreads();
-        return c;
+        cur_r += 4;
+        cur_i = 0;
       }
-      j0 += 1024;
     }
+    if (lane == 0 && cur_r < nrows)
+      pending = 1;
+    __syncthreads();
+    const int c = cnt_crop;
+    all_done = pending == 0;
+    return c;
+  };
+  // Between two tiles of one pass: everybody has finished with the tile, then the counters are cleared.
+  auto next_tile = [&]() {
+    __syncthreads();
+    if (tid == 0)
+    {
+      cnt_crop = 0;
+      pending = 0;
+    }
+    __syncthreads();
   };
 
   const int K = G.n_depths;
-  // ---- pass A: classify every cropped point once per orientation (tiles of kTile points) ----
+  // ---- pass A: classify every cropped point once per orientation ----
   double ymin_w[2] = { INFINITY, INFINITY }, ymax_w[2] = { -INFINITY, -INFINITY };
-  int j0 = 0, ntiles = 0, nc = 0;
-  for (;;)
-  {
-    nc = fill(j0, true);
-    if (ntiles == 0)
-      AGH_STAMP(2);
-    if (debug_stop == 2)
-      return;
+  auto classify = [&](int nc) {
     for (int oo = 0; oo < 2; oo++)
     {
       const int o = wave + 4 * oo;
@@ -303,7 +293,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         // Four independent points per lane, straight-line code (no data-dependent loops), so that the LDS look-ups of
         // the four points overlap.
         double xr[4], yr[4];
-#pragma unroll
+  #pragma unroll
         for (int u = 0; u < 4; u++)
         {
           const int t = t0 + 64 * u;
@@ -318,13 +308,13 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
           }
         }
         // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
-#pragma unroll
+  #pragma unroll
         for (int u = 0; u < 4; u++)
         {
           const int cy = (int) fmin(fmax((yr[u] - G.ylut_lo) * G.ylut_scale, 0.0), 63.0);
           const int ly = G.ylut[cy];
           int yk = ly;
-#pragma unroll
+  #pragma unroll
           for (int j = 0; j < kLutProbe; j++)
             yk += (dep_s[ly + j] <= yr[u]) ? 1 : 0;
           if (yk < K && debug_stop != 11)
@@ -332,7 +322,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             const int cx = (int) fmin(fmax((xr[u] - G.xlut_lo) * G.xlut_scale, 0.0), 1023.0);
             const int lx = G.xlut[cx];
             int c = lx, e = 0;
-#pragma unroll
+  #pragma unroll
             for (int j = 0; j < kLutProbe; j++)
             {
               const double tv = thr_s[lx + j];
@@ -348,13 +338,25 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       ymin_w[oo] = ymin;
       ymax_w[oo] = ymax;
     }
+  };
+  int ntiles = 0, nc = 0;
+  for (;;)
+  {
+    bool all_done = false;
+    nc = gather_tile(true, all_done);
+    if (ntiles == 0)
+      AGH_STAMP(2);
+    if (debug_stop == 2)
+      return;
+    classify(nc);
     ntiles++;
-    if (j0 >= total)
+    if (all_done)
       break;
-    __syncthreads();
-    if (tid == 0)
-      cnt_crop = 0;
+    next_tile();
   }
+  nball = wave_sum_i32(nball);
+  if (lane == 0 && nball)
+    atomicAdd(&cnt_ball, nball);
   __syncthreads();
   AGH_STAMP(3);
   if (debug_stop == 3)
@@ -473,16 +475,14 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     const bool refill = ntiles > 1;  // a single tile is still resident in LDS
     if (refill)
     {
-      __syncthreads();
-      if (tid == 0)
-        cnt_crop = 0;
-      j0 = 0;
-      row_cur = 0;
+      next_tile();
+      gather_reset();
     }
     for (;;)
     {
+      bool all_done = true;
       if (refill)
-        nc = fill(j0, false);
+        nc = gather_tile(false, all_done);
       for (int oo = 0; oo < 2; oo++)
       {
         const int o = wave + 4 * oo;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             vc = min(79, max(0, vc));
             const int bit = (79 - vc) * 100 + hc;
             atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
-            if (normals)
+            if (NORMALS)
             {
               const double* nn = normals + 3 * (int64_t) (pid[t] >> 1);
               const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
@@ -538,11 +538,9 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         numl_w[oo] += numl;
         numr_w[oo] += numr;
       }
-      if (!refill || j0 >= total)
+      if (!refill || all_done)
         break;
-      __syncthreads();
-      if (tid == 0)
-        cnt_crop = 0;
+      next_tile();
     }
   }
   __syncthreads();
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     if (dbg)
     {
       dbg[(int64_t) s * 8 + 6] = wall_clock64();
-      dbg[(int64_t) s * 8 + 7] = ((long long) cnt_ball << 32) | (unsigned) total;
+      dbg[(int64_t) s * 8 + 7] = ((long long) cnt_ball << 32) | (unsigned) (ntiles << 24) | (unsigned) (total & 0xffffff);
     }
   }
 #undef AGH_STAMP
@@ -711,8 +709,12 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const int Si = (int) S;
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
-  hipLaunchKernelGGL(k_hand_sweep, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f, rpad, nrm,
-    img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
+  if (nrm)
+    hipLaunchKernelGGL(k_hand_sweep<true>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
+      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
+  else
+    hipLaunchKernelGGL(k_hand_sweep<false>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
+      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

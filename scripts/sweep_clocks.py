@@ -25,3 +25,13 @@ print("kernel span", t[:, 6].max() - t[:, 0].min(), "first start spread", np.per
 print('guard trips', (d[:, 7] < 0).sum(), d[d[:, 7] < 0][:5])
 cand = (d[:, 7] & 0xffffffff); ball = d[:, 7] >> 32
 print("candidates mean", cand.mean(), "ball mean", ball.mean())
+pa = ph[:, 2]
+order = np.argsort(ball)
+for q in (0.1, 0.5, 0.8, 0.9, 0.95, 0.99):
+    i = order[int(q * len(order))]
+    print("ball quantile", q, "ball", ball[i], "passA", pa[i], "gather", ph[i, 1], "passB", ph[i, 4])
+big = ball > 7000
+print("ball>7000:", big.sum(), "passA mean", pa[big].mean() if big.any() else 0, "; ball<5000 passA mean", pa[ball < 5000].mean())
+print("corr(ball, passA)", np.corrcoef(ball, pa)[0, 1])
+slow = pa > 5000
+print("slow passA count", slow.sum(), "their ball mean", ball[slow].mean(), "min", ball[slow].min())
