@@ -54,8 +54,8 @@ __device__ __forceinline__ int wave_sum_i32(int v)
   return v;
 }
 
-// Cropped points staged in LDS at a time: 2048 x double2 (32 KiB) for the online path, 1536 x (double2 + point id)
-// (30 KiB) when per-point normals are needed for the antipodal test -- both leave room for 3 blocks per CU.
+// Cropped points staged in LDS at a time: 2176 x double2 (34 KiB) for the online path, 1728 x (double2 + point id)
+// (34 KiB) when per-point normals are needed for the antipodal test -- both leave room for 3 blocks per CU.
 
 __device__ __forceinline__ unsigned lowmask(int n)
 {
@@ -68,8 +68,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg)
 {
-  constexpr int kTile = NORMALS ? 1536 : 2048;
-  static_assert(kTile >= 1024, "a batch of 1024 candidates must fit an empty tile");
+  constexpr int kTile = NORMALS ? 1728 : 2176;  // the block must stay under a third of the CU's 160 KiB (512-B granules)
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
   __shared__ unsigned img[8][kImageWords + 2];
-  __shared__ int cnt_ball, cnt_crop, any_hand, pending;
+  __shared__ int cnt_ball, cnt_crop, any_hand, pending, tile_end;
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,6 +112,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     cnt_crop = 0;
     any_hand = 0;
     pending = 0;
+    tile_end = 0x7fffffff;
   }
   for (int k = tid; k < 8 * 44; k += 256)
     (&regmask[0][0])[k] = 0u;
@@ -185,17 +185,18 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   // Gather: every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes, two loads in
   // flight per lane (row base and length are wave-uniform: no per-candidate row look-up, fully coalesced).  Each
   // candidate is filtered (FLANN float32 distance), rotated into the hand frame and cropped (rotating_hand.cpp:26,37-51)
-  // and the survivors are appended to the LDS tile with one reservation per wave-instruction.  A wave pauses when fewer
-  // than 512 slots are left (4 waves x 128 candidates is the most that can still arrive), so a neighbourhood that does
-  // not fit one tile simply streams through it in several rounds; the cursor (row, offset) says where to resume.
+  // and the survivors are appended to the LDS tile: one LDS atomic per wave-instruction reserves their slots; if the
+  // reservation does not fit, the tile is closed and the wave pauses AT that instruction, so a neighbourhood that does
+  // not fit one tile streams through it in several rounds.  The cursor (row, offset) says where to resume.
   int cur_r = wave, cur_i = 0, nball = 0;
   const int nrows = rt.nrows;
   auto gather_reset = [&]() {
     cur_r = wave;
     cur_i = 0;
   };
-  auto consume1 = [&](const float4& p, bool have, bool count_ball) {
-    bool keep = false;
+  // returns false if the tile is full (nothing was appended, the candidates must be offered again)
+  auto consume1 = [&](const float4& p, bool have, bool count_ball) -> bool {
+    bool keep = false, inball = false;
     double tx = 0.0, ty = 0.0;
     unsigned w = 0;
     if (have)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
       if (d2 < r2f)
       {
-        nball += count_ball ? 1 : 0;
+        inball = true;
         const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
         const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
         keep = (tz > -1.0 * hh) && (tz < hh);
@@ -218,26 +219,39 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     const unsigned long long mk = __ballot(keep);
     if (mk)
     {
+      const int cnt = __popcll(mk);
       int base = 0;
       if (lane == 0)
-        base = atomicAdd(&cnt_crop, __popcll(mk));
+      {
+        // Reservations are totally ordered by the atomic: every one that fits precedes the first that does not, and the
+        // counter only grows, so the valid entries are exactly [0, base of the first failed reservation).
+        base = atomicAdd(&cnt_crop, cnt);
+        if (base + cnt > kTile)
+        {
+          atomicMin(&tile_end, base);
+          base = -1;
+        }
+      }
       base = __shfl(base, 0);
+      if (base < 0)
+        return false;
       if (keep)
       {
-        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));  // < kTile by the pause rule below
+        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
         pts[k] = make_double2(tx, ty);
         if (NORMALS)
           pid[k] = w;
       }
     }
+    nball += (count_ball && inball) ? 1 : 0;
+    return true;
   };
   // Fills the tile from the cursors on; returns the tile's point count and whether every wave reached the end.
   // Must be entered with cnt_crop == 0 made visible by a barrier.
   auto gather_tile = [&](bool count_ball, bool& all_done) -> int {
-    while (cur_r < nrows)
+    bool full = false;
+    while (cur_r < nrows && !full)
     {
-      if (*(volatile int*) &cnt_crop > kTile - 512)
-        break;
       const int rb = rt.begin[cur_r];
       const int len = rt.prefix[cur_r + 1] - rt.prefix[cur_r];
       if (cur_i < len)
@@ -248,12 +262,17 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
           p0 = gv.sorted[rb + cur_i + lane];
         if (h1)
           p1 = gv.sorted[rb + cur_i + 64 + lane];
-        consume1(p0, h0, count_ball);
-        if (cur_i + 64 < len)
-          consume1(p1, h1, count_ball);
-        cur_i += 128;
+        if (!consume1(p0, h0, count_ball))
+          full = true;
+        else if (cur_i + 64 < len && !consume1(p1, h1, count_ball))
+        {
+          full = true;
+          cur_i += 64;
+        }
+        else
+          cur_i += 128;
       }
-      if (cur_i >= len)
+      if (!full && cur_i >= len)
       {
         cur_r += 4;
         cur_i = 0;
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     if (lane == 0 && cur_r < nrows)
       pending = 1;
     __syncthreads();
-    const int c = cnt_crop;
+    const int c = min(cnt_crop, tile_end);
     all_done = pending == 0;
     return c;
   };
@@ -273,6 +292,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     {
       cnt_crop = 0;
       pending = 0;
+      tile_end = 0x7fffffff;
     }
     __syncthreads();
   };
@@ -498,37 +518,51 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         const bool pos_x = posx_w[oo];
         double wmin = wmin_w[oo], wmax = wmax_w[oo];
         int nbox = 0, numl = 0, numr = 0;
-        for (int t = lane; t < nc; t += 64)
+        for (int t0 = lane; t0 < nc; t0 += 256)
         {
-          const double2 p = pts[t];
-          const double xr = cs * p.x + ms * p.y;
-          const double yr = sn * p.x + cs * p.y;
-          if (yr < bite && xr > left && xr < right)  // finger_hand.cpp:158-167
+          // four independent points per lane (straight-line code: the two exactly-rounded divisions of each point
+          // overlap with those of the others)
+          double xr[4], yr[4];
+          bool act[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
           {
-            wmin = fmin(wmin, xr);
-            wmax = fmax(wmax, xr);
+            const int t = t0 + 64 * u;
+            act[u] = t < nc;
+            const double2 p = pts[act[u] ? t : 0];
+            xr[u] = cs * p.x + ms * p.y;
+            yr[u] = sn * p.x + cs * p.y;
           }
-          if (yr < box_y)  // rotating_hand.cpp:125-130
+#pragma unroll
+          for (int u = 0; u < 4; u++)
           {
-            nbox++;
-            const double bx = xr - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
-            const double by = yr - sfy;
+            if (act[u] && yr[u] < bite && xr[u] > left && xr[u] < right)  // finger_hand.cpp:158-167
+            {
+              wmin = fmin(wmin, xr[u]);
+              wmax = fmax(wmax, xr[u]);
+            }
+            const double bx = xr[u] - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
+            const double by = yr[u] - sfy;
             const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
             const double vy = (by - 0.0) / img_cell;
-            int hc = (int) floor(hx), vc = (int) floor(vy);
-            hc = min(99, max(0, hc));
-            vc = min(79, max(0, vc));
-            const int bit = (79 - vc) * 100 + hc;
-            atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
-            if (NORMALS)
+            if (act[u] && yr[u] < box_y)  // rotating_hand.cpp:125-130
             {
-              const double* nn = normals + 3 * (int64_t) (pid[t] >> 1);
-              const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
-              const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
-              const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
-              const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
-              numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
-              numr += (nxr > G.cos_antipodal) ? 1 : 0;
+              nbox++;
+              int hc = (int) floor(hx), vc = (int) floor(vy);
+              hc = min(99, max(0, hc));
+              vc = min(79, max(0, vc));
+              const int bit = (79 - vc) * 100 + hc;
+              atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
+              if (NORMALS)
+              {
+                const double* nn = normals + 3 * (int64_t) (pid[t0 + 64 * u] >> 1);
+                const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
+                const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
+                const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
+                const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
+                numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
+                numr += (nxr > G.cos_antipodal) ? 1 : 0;
+              }
             }
           }
         }
