@@ -86,45 +86,52 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   }
   const float binscale = (float) kSortBins / r2f;  // monotone map of d2 in [0, r2f) onto the sort bins
   // ---- gather + FLANN distance filter + compaction into LDS ----
-  const int total = rt.total;
-  int row_cur = 0;
-  for (int j0 = 0; j0 < total; j0 += 1024)  // four candidates per thread: all four loads are in flight together
+  // every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes, two loads in flight
+  // per lane: row base and length are wave-uniform (no per-candidate row look-up) and the reads are fully coalesced
   {
-    float4 pp[4];
-    bool have[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-    {
-      const int j = j0 + u * 256 + tid;
-      have[u] = j < total;
-      if (have[u])
-        pp[u] = gv.sorted[row_advance(rt, j, row_cur)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-    {
-      const float4 p = pp[u];
+    auto take = [&](const float4& p, bool have) {
       float d2 = 0.f;
       bool pass = false;
-      if (have[u])
+      if (have)
       {
         d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
         pass = d2 < r2f;
       }
       const unsigned long long m = __ballot(pass);
-      int base = 0;
-      if (lane == 0 && m)
-        base = atomicAdd(&count, __popcll(m));
-      base = __shfl(base, 0);
-      if (pass)
+      if (m)
       {
-        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (k < CAP)
+        int base = 0;
+        if (lane == 0)
+          base = atomicAdd(&count, __popcll(m));
+        base = __shfl(base, 0);
+        if (pass)
         {
-          stage[k] = p;
-          key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
-          atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
+          const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (k < CAP)
+          {
+            stage[k] = p;
+            key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
+            atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
+          }
         }
+      }
+    };
+    const int nrows = rt.nrows;
+    for (int r = wave; r < nrows; r += 4)
+    {
+      const int rb = rt.begin[r];
+      const int len = rt.prefix[r + 1] - rt.prefix[r];
+      for (int i0 = 0; i0 < len; i0 += 128)
+      {
+        const bool h0 = i0 + lane < len, h1 = i0 + 64 + lane < len;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        if (h0)
+          p0 = gv.sorted[rb + i0 + lane];
+        if (h1)
+          p1 = gv.sorted[rb + i0 + 64 + lane];
+        take(p0, h0);
+        if (i0 + 64 < len)
+          take(p1, h1);
       }
     }
   }
