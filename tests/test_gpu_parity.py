@@ -202,6 +202,55 @@ def test_edge_cases(tiny_scene):
     assert len(h) == 3 * len(one)
 
 
+@pytest.mark.parametrize("kind", ["duplicates", "lattice_plane", "collinear", "random_blob", "two_sheets"])
+def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
+    """Ties in the neighbour order (duplicate points, lattice symmetry), singular fits (exact planes, lines), tiny and
+    ragged neighbourhoods: whatever the oracle does with them, the kernels must do the same, bit for bit."""
+    from oracle import oracle_py as O
+
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    cams = tiny_scene.cam_origins
+    c0 = np.array([0.75, 0.05, -0.05])
+    if kind == "duplicates":
+        base = c0 + rng.uniform(-0.05, 0.05, (1500, 3)) * np.array([1, 1, 0.15])
+        xyz = np.concatenate([base, base[:400], base[:100]])  # exact duplicates: d2 ties broken by index
+    elif kind == "lattice_plane":
+        g = np.arange(-0.06, 0.06, 0.003)
+        u, v = np.meshgrid(g, g, indexing="ij")
+        xyz = c0 + np.stack([u.ravel(), v.ravel(), np.zeros(u.size)], 1)  # exactly planar: N9 singular -> invalid frames
+    elif kind == "collinear":
+        t = np.linspace(-0.08, 0.08, 300)
+        xyz = np.concatenate([c0 + np.stack([t, 0 * t, 0 * t], 1), c0 + rng.uniform(-0.02, 0.02, (40, 3))])
+    elif kind == "random_blob":
+        xyz = c0 + rng.normal(0, 0.03, (4000, 3))
+    else:  # two parallel sheets 4 mm apart (two camera lattices that do not agree)
+        g = np.arange(-0.07, 0.07, 0.003)
+        u, v = np.meshgrid(g, g, indexing="ij")
+        a = np.stack([u.ravel(), v.ravel(), 0.02 * np.sin(20 * u.ravel())], 1)
+        xyz = c0 + np.concatenate([a, a + np.array([0.0011, 0.0007, 0.004])])
+    xyz = xyz.astype(np.float32)
+    cam = (rng.random(len(xyz)) < 0.4).astype(np.int32)
+    samples = np.sort(rng.choice(len(xyz), min(40, len(xyz)), replace=False)).astype(np.int32)
+    from agile_grasp_amd import binding
+
+    ctx = binding.Context(cams)
+    ctx.set_cloud(xyz, cam)
+    hyps = ctx.find_hands(samples)
+    ref = O.find_hands(O.default_params(cams), xyz, cam, samples, want_images=True)
+    fr, rf = ctx.frames(), ref["frames"]
+    assert np.array_equal(fr["valid"], rf["valid"]) and np.array_equal(fr["n_nb"], rf["n_nb"])
+    ok = rf["valid"] != 0
+    for f in ("majority_cam", "max_index", "params", "eigenvalue", "normal", "axis", "binormal"):
+        assert np.array_equal(fr[f][ok], rf[f][ok], equal_nan=True), (kind, f)
+    nt, nh = ctx.neighbor_counts()
+    assert np.array_equal(nh[ok], ref["nh"][ok])
+    assert len(hyps) == len(ref["hyps"])
+    for f in INT_FIELDS + FLOAT_FIELDS:
+        assert np.array_equal(hyps[f], ref["hyps"][f]), (kind, f)
+    if len(hyps):
+        assert np.array_equal(ctx.images(), ref["images"])
+
+
 def test_capacity_overflow_is_loud():
     """A non-voxelised blob with > 2048 neighbours in the Taubin ball must raise, never return partial results."""
     from agile_grasp_amd import binding
