@@ -80,7 +80,7 @@ EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device",
     "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
-    "agh_get_normals", "agh_get_timing", "agh_synchronize", "agh_selftest_math",
+    "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
 ]
 
 
@@ -133,7 +133,7 @@ class Context:
         for c in range(2):
             for r in range(3):
                 p.cam_origin[c][r] = float(cam_origins[c][r])
-        p.normals_mode, p.device, p.profile, p.rand_seed = normals_mode, device, 1 if profile else 0, rand_seed
+        p.normals_mode, p.device, p.profile, p.rand_seed = normals_mode, device, int(profile), rand_seed
         for k, v in geometry.items():
             setattr(p, k, v)
         self.params = p
@@ -229,6 +229,9 @@ class Context:
         t = AghTiming()
         self._check(self.lib.agh_get_timing(self._h, C.byref(t)))
         return {t.name[i].decode(): float(t.ms[i]) for i in range(t.n)}
+
+    def set_profile(self, level: int):
+        self._check(self.lib.agh_set_profile(self._h, C.c_int32(level)))
 
     def synchronize(self):
         self._check(self.lib.agh_synchronize(self._h))

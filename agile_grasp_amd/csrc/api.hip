@@ -235,14 +235,15 @@ __global__ void k_iota(int32_t* out, int base, int n)
 
 void timing_begin(Ctx* c, hipStream_t st)
 {
-  if (!c->p.profile)
+  if (c->p.profile != 1 && c->ev_used <= 60000)
     return;
   if (c->ev_used > 60000)  // nobody is reading the timings: start over instead of growing without bound
   {
     c->ev_used = 0;
     c->ev_name.clear();
   }
-  timing_mark(c, "start", st);
+  if (c->p.profile == 1)
+    timing_mark(c, "start", st);
 }
 
 }  // namespace
@@ -253,6 +254,13 @@ void timing_mark(Ctx* c, const char* name, hipStream_t st)
 {
   if (!c->p.profile)
     return;
+  if (c->p.profile == 2)  // two events per call: the end of the kernel before the hand sweep, and its own end
+  {
+    if (std::strcmp(name, "taubin_frame") == 0)
+      name = "start";
+    else if (std::strcmp(name, "hand_sweep") != 0)
+      return;
+  }
   if (c->ev_used >= (int) c->ev.size())
   {
     hipEvent_t e;
@@ -707,6 +715,19 @@ int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points)
   if (n > 0)
     HIPCHK(c, hipMemcpy(normals, c->d_normals, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
   return (int) n;
+}
+
+int agh_set_profile(agh_ctx* ctx, int32_t level)
+{
+  if (!ctx || level < 0 || level > 2)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  c->p.profile = level;
+  c->ev_used = 0;
+  c->ev_name.clear();
+  return AGH_OK;
 }
 
 int agh_get_timing(agh_ctx* ctx, agh_timing* out)

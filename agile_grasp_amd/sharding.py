@@ -28,6 +28,12 @@ def buffer_bytes(n_samples: int) -> int:
     return (8 * n_samples + 1) * RECORD_BYTES
 
 
+def buffer_bytes_records(n_records: int) -> int:
+    """Bytes of the buffer prefix holding the header and the first ``n_records`` record slots.  Exchanging a prefix
+    is valid because records are compacted to the front; receivers compare the header count with the slots sent."""
+    return (n_records + 1) * RECORD_BYTES
+
+
 def all_gather_records(local_t, gather_t):
     """One collective: every rank contributes its whole fixed-size buffer; gather_t is world * len(local_t)."""
     import torch.distributed as dist
@@ -50,6 +56,8 @@ def unpack_gathered(gathered: np.ndarray, world: int, dtype: np.dtype):
     for g in range(world):
         blob = gathered[g * per:(g + 1) * per]
         n = int(np.frombuffer(blob[:8].tobytes(), np.int64)[0])
+        if (n + 1) * RECORD_BYTES > per:
+            raise OverflowError(f"rank {g} produced {n} records but only {per // RECORD_BYTES - 1} slots were exchanged")
         recs = np.frombuffer(blob[RECORD_BYTES:RECORD_BYTES + n * RECORD_BYTES].tobytes(), dtype)
         out.append(recs)
     return out

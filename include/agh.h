@@ -60,7 +60,7 @@ typedef struct agh_params
   int32_t normals_mode;       /* AGH_NORMALS_* */
   uint32_t rand_seed;         /* srand() seed for AGH_NORMALS_RAND50 */
   int32_t device;             /* HIP device ordinal */
-  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing) */
+  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing); 2: only k_hand_sweep */
 } agh_params;
 
 /* One grasp hypothesis, fixed size (160 B).  The variable-size points_for_learning_ of the reference
@@ -148,6 +148,8 @@ int agh_get_images(agh_ctx* ctx, uint8_t* images, int64_t cap_hyp); /* cap_hyp x
 int agh_get_hog(agh_ctx* ctx, float* desc, double* sums, int64_t cap_hyp); /* cap_hyp x 3528 floats (+ SVM sums) */
 int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points);  /* cloud_normals_ (3 doubles per point) */
 int agh_get_timing(agh_ctx* ctx, agh_timing* out);
+/* Change agh_params::profile of a live context (0, 1 or 2); pending timings are dropped. */
+int agh_set_profile(agh_ctx* ctx, int32_t level);
 int agh_synchronize(agh_ctx* ctx);
 /* Device self-test of the IEEE assumptions the parity contract rests on (fp64 div/sqrt, fp32 div/sqrt correctly
  * rounded, no FMA contraction): returns the number of mismatches against host arithmetic on n random inputs. */

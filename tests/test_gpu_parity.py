@@ -306,7 +306,9 @@ def test_device_resident_api_matches_host_api(tiny_scene, svm_model):
     out_t = torch.zeros(8 * sc.samples.size * 160, dtype=torch.uint8, device="cuda")
     n_t = torch.zeros(1, dtype=torch.int64, device="cuda")
     keep_t = torch.zeros(8 * sc.samples.size, dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    ts = torch.cuda.Stream()  # an explicit stream, as bench.py uses (NULL would select the context's own stream)
+    st = ts.cuda_stream
     for _ in range(2):
         dev.set_cloud_torch(xyz_t, cam_t, stream=st)
         dev.find_hands_torch(s_t, out_t, n_t, stream=st)
@@ -318,6 +320,7 @@ def test_device_resident_api_matches_host_api(tiny_scene, svm_model):
     dev.synchronize()  # also reports device-side errors of the asynchronous calls
     bad = s_t.clone()
     bad[5] = sc.n + 7  # device-resident sample lists are validated on the device: loud error, no out-of-bounds read
+    torch.cuda.synchronize()  # (bad was written on torch's stream, the search runs on ts)
     dev.find_hands_torch(bad, out_t, n_t, stream=st)
     with pytest.raises(binding.AghError) as e:
         dev.synchronize()

@@ -51,6 +51,20 @@ for g in range(world):
     n2 = 3 + 4 * g
     s2 = np.sort(r2.integers(0, S, n2)); w2 = r2.random(n2)
     ok &= len(parts[g]) == n2 and np.array_equal(parts[g]["sample"], s2) and np.array_equal(parts[g]["width"], w2)
+# compact exchange: only the header + 7 slots travel; rank 1 (7 records) just fits, 6 slots must be refused
+nb = sharding.buffer_bytes_records(7)
+g2 = torch.zeros(world * nb, dtype=torch.uint8)
+sharding.all_gather_records(local[:nb], g2)
+p2 = sharding.unpack_gathered(g2.numpy(), world, binding.HYP_DTYPE)
+ok &= all(np.array_equal(a, b) for a, b in zip(p2, parts))
+nb = sharding.buffer_bytes_records(6)
+g3 = torch.zeros(world * nb, dtype=torch.uint8)
+sharding.all_gather_records(local[:nb], g3)
+try:
+    sharding.unpack_gathered(g3.numpy(), world, binding.HYP_DTYPE)
+    ok = False
+except OverflowError:
+    pass
 slices = [sharding.shard_slice(world * S, g, world) for g in range(world)]
 merged = sharding.merge_sample_sharded(parts, slices)
 ok &= len(merged) == sum(3 + 4 * g for g in range(world)) and bool((np.diff(merged["sample"]) >= 0).all())
