@@ -78,7 +78,7 @@ assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200
 
 EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device",
-    "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
 ]
@@ -171,6 +171,38 @@ class Context:
         self._check(self.lib.agh_set_cloud(self._h, _p(xyz, C.c_float), C.c_int64(stride), camp,
                                            C.c_int64(xyz.shape[0])))
         self.n = xyz.shape[0]
+
+    def preprocess(self, xyz: np.ndarray, size_left: int, workspace, cell_size: float = 0.003, dense: bool = False) -> int:
+        """NaN removal + workspace box + per-camera voxelisation on the GPU; the result becomes the context's cloud."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        ws = np.ascontiguousarray(workspace, np.float64)
+        assert ws.size == 6
+        nv = C.c_int64(0)
+        self._check(self.lib.agh_preprocess(self._h, _p(xyz, C.c_float), C.c_int64(xyz.shape[1] * 4),
+                                            C.c_int64(xyz.shape[0]), C.c_int64(size_left), C.c_int(1 if dense else 0),
+                                            _p(ws, C.c_double), C.c_double(cell_size), C.byref(nv)))
+        self.n = nv.value
+        return nv.value
+
+    def preprocess_torch(self, xyz_t, size_left: int, workspace, cell_size: float = 0.003, dense: bool = False,
+                         stream=None) -> int:
+        assert xyz_t.is_cuda and xyz_t.is_contiguous()
+        ws = np.ascontiguousarray(workspace, np.float64)
+        nv = C.c_int64(0)
+        self._keep = [xyz_t]
+        self._check(self.lib.agh_preprocess_device(
+            self._h, C.c_void_p(xyz_t.data_ptr()), C.c_int64(xyz_t.stride(0) * 4), C.c_int64(xyz_t.shape[0]),
+            C.c_int64(size_left), C.c_int(1 if dense else 0), _p(ws, C.c_double), C.c_double(cell_size), C.byref(nv),
+            C.c_void_p(stream) if stream else None))
+        self.n = nv.value
+        return nv.value
+
+    def cloud(self):
+        xyz = np.zeros((max(self.n, 1), 3), np.float32)
+        cam = np.zeros(max(self.n, 1), np.int32)
+        k = self._check(self.lib.agh_get_cloud(self._h, _p(xyz, C.c_float), _p(cam, C.c_int32), C.c_int64(self.n)))
+        return xyz[:k], cam[:k]
 
     def find_hands(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
         samples = np.ascontiguousarray(samples, np.int32)

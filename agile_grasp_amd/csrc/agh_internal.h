@@ -82,6 +82,22 @@ enum SampleStatus : int
   kStatusBadIndex = 4     // sample index outside the cloud (device-resident sample lists are validated on the device)
 };
 
+// K-1 (voxelize.hip): per-camera voxel lattice of the preprocessing step
+constexpr unsigned long long kVoxMaxWords = 1ull << 28;  // 1 GiB of bitmap (a 6 m x 6 m x 3 m lattice at 3 mm)
+struct VoxDesc
+{
+  unsigned mn_enc[2][3], mx_enc[2][3];  // order-preserving encodings of the float minima / maxima per camera
+  double mn[2][3];                      // the minima as the reference holds them (10000 if no smaller coordinate)
+  int dim[2][3];
+  unsigned long long bits[2], word_ofs[2], n_words;
+  long long n_kept[2], n_vox[2];
+  int error;
+};
+struct VoxWorkspace
+{
+  double lo[3], hi[3];
+};
+
 struct Ctx
 {
   agh_params p;
@@ -98,6 +114,20 @@ struct Ctx
   float* own_xyz = nullptr;
   int32_t* own_cam = nullptr;
   int64_t own_cap = 0;
+
+  // preprocessing (K-1)
+  VoxDesc* d_vox_desc = nullptr;
+  uint8_t* d_vox_code = nullptr;   // per raw point: 0 dropped, 1 | cam << 1 kept
+  int* d_vox_blk = nullptr;        // finite-point counts per 1024 raw points
+  int* d_vox_blk2 = nullptr;       // popcounts per 4096 bitmap words
+  long long* d_vox_total = nullptr;
+  unsigned* d_vox_bitmap = nullptr;
+  int64_t vox_bitmap_cap = 0;      // words
+  float* d_vox_xyz = nullptr;      // voxelised cloud (packed xyz) and camera ids
+  int32_t* d_vox_cam = nullptr;
+  int64_t vox_cap = 0;
+  float* d_raw_xyz = nullptr;      // device copy of a raw host cloud
+  int64_t raw_cap = 0;
 
   // grid
   GridDesc* d_desc = nullptr;
@@ -167,6 +197,9 @@ struct Ctx
 };
 
 // ---- kernel launchers (defined in the .hip files) ----
+int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell, hipStream_t st);
+int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st);
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);

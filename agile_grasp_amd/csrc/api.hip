@@ -392,7 +392,8 @@ void agh_destroy(agh_ctx* ctx)
   void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
-    c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep };
+    c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
+    c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -474,6 +475,124 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return AGH_OK;
+}
+
+// ---- f1: preprocessing (NaN removal, workspace box, per-camera voxelisation), then the grid build ----
+int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
+  int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !d_xyz) || !workspace ||
+      !(cell_size > 0.0) || size_left < 0)
+  {
+    c->err = "agh_preprocess: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4, a workspace, cell_size > 0";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  int rc;
+  if (!c->d_vox_desc)
+  {
+    if ((rc = dev_alloc(c, &c->d_vox_desc, 1)) || (rc = dev_alloc(c, &c->d_vox_total, 1)) ||
+        (rc = dev_alloc(c, &c->d_vox_blk2, (size_t) (kVoxMaxWords / 4096) + 1)))
+      return rc;
+  }
+  if (n > c->vox_cap || !c->d_vox_code)
+  {
+    if ((rc = dev_alloc(c, &c->d_vox_code, (size_t) n)) || (rc = dev_alloc(c, &c->d_vox_blk, (size_t) n / 1024 + 2)) ||
+        (rc = dev_alloc(c, &c->d_vox_xyz, (size_t) n * 3)) || (rc = dev_alloc(c, &c->d_vox_cam, (size_t) n)))
+      return rc;
+    c->vox_cap = n;
+  }
+  timing_begin(c, st);
+  if ((rc = vox_stage1(c, d_xyz, stride_bytes / 4, n, size_left, dense, workspace, cell_size, st)) != AGH_OK)
+  {
+    c->err = "preprocessing launch failed";
+    return rc;
+  }
+  VoxDesc h;
+  HIPCHK(c, hipMemcpyAsync(&h, c->d_vox_desc, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));  // the lattice size decides the bitmap allocation: one host round trip
+  if (h.error)
+  {
+    c->err = "the voxel lattice of the kept points exceeds 2^33 cells (1 GiB bitmap): set a workspace "
+             "(Localization::setWorkspace) that bounds the scene";
+    return AGH_ERR_CAPACITY;
+  }
+  if ((int64_t) h.n_words > c->vox_bitmap_cap || !c->d_vox_bitmap)
+  {
+    if ((rc = dev_alloc(c, &c->d_vox_bitmap, (size_t) h.n_words + 4096)))
+      return rc;
+    c->vox_bitmap_cap = (int64_t) h.n_words;
+  }
+  if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, (int64_t) h.n_words, st)) != AGH_OK)
+  {
+    c->err = "preprocessing launch failed";
+    return rc;
+  }
+  timing_mark(c, "preprocess", st);
+  HIPCHK(c, hipMemcpyAsync(&h, c->d_vox_desc, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));  // the voxel count sizes the search structure
+  const int64_t nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
+  if (n_voxels_out)
+    *n_voxels_out = nv;
+  return agh_set_cloud_device(ctx, c->d_vox_xyz, 12, c->d_vox_cam, nv, hip_stream);
+}
+
+int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell_size, int64_t* n_voxels_out)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz))
+  {
+    c->err = "agh_preprocess: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n > c->raw_cap || !c->d_raw_xyz)
+  {
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) n * 3)))
+      return rc;
+    c->raw_cap = n;
+  }
+  if (n > 0)
+    HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
+                c->stream));
+  int rc = agh_preprocess_device(ctx, c->d_raw_xyz, 12, n, size_left, dense, workspace, cell_size, n_voxels_out, nullptr);
+  if (rc != AGH_OK)
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AGH_OK;
+}
+
+int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap)
+{
+  if (!ctx || cap < 0)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->has_cloud)
+  {
+    c->err = "agh_get_cloud: no cloud set";
+    return AGH_ERR_NO_CLOUD;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  const int64_t k = std::min<int64_t>(cap, c->n);
+  if (k > 0 && xyz_out)
+    HIPCHK(c, hipMemcpy2D(xyz_out, 12, c->d_xyz, (size_t) c->stride_floats * 4, 12, (size_t) k, hipMemcpyDeviceToHost));
+  if (k > 0 && cam_out)
+  {
+    if (c->d_cam)
+      HIPCHK(c, hipMemcpy(cam_out, c->d_cam, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+    else
+      std::memset(cam_out, 0, sizeof(int32_t) * k);
+  }
+  return (int) std::min<int64_t>(c->n, 0x7fffffff);
 }
 
 int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,

@@ -1,0 +1,403 @@
+// voxelize.hip -- K-1: the preprocessing in front of the search.
+//
+// Stands in for the head of Localization::localizeHands (reference src/agile_grasp/localization.cpp):
+//   17-24    camera id of raw point i = (i >= size_left), assigned before the NaN removal and never re-indexed
+//   25-27    pcl::removeNaNFromPointCloud (order preserving; a cloud flagged is_dense is passed through)
+//   216-245  filterWorkspace: min <= p <= max per axis
+//   247-355  voxelizeCloud: per-camera minimum, floor((p - min) / cell), std::set in lexicographic (x, y, z) order,
+//            coordinates back as v * cell + min, camera 0 block then camera 1 block.
+//
+// The std::set is replaced by a bitmap over each camera's voxel lattice laid out x-major, z-fastest: a set bit's
+// position IS its lexicographic rank order, so "insert" is an atomicOr and "iterate in order" is a popcount scan --
+// no sort.  A 1.3 m x 1.0 m x 0.5 m scene at 3 mm is 24 Mbit = 3 MB per camera (L2 / Infinity-Cache resident).
+// The arithmetic that defines the voxel of a point and the coordinates of a voxel is the reference's, in double,
+// without contraction.
+#include "agh_internal.h"
+
+namespace agh
+{
+
+constexpr int kPreBlock = 256;
+constexpr int kPrePerBlock = 1024;   // points per block (4 rounds of 256)
+constexpr int kWordsPerBlock = 4096; // bitmap words per block in the popcount passes (16 per thread)
+
+__global__ void k_vox_init(VoxDesc* d)
+{
+  for (int c = 0; c < 2; c++)
+    for (int a = 0; a < 3; a++)
+    {
+      d->mn_enc[c][a] = enc_float(10000.0f);  // the reference's initial minimum (localization.cpp:250-252)
+      d->mx_enc[c][a] = 0u;
+    }
+  d->n_kept[0] = d->n_kept[1] = 0;
+  d->n_vox[0] = d->n_vox[1] = 0;
+  d->error = 0;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// Finite points per block of 1024 raw points (rank base of the NaN-free cloud).
+__global__ __launch_bounds__(kPreBlock) void k_vox_count(const float* __restrict__ xyz, int64_t stride, int64_t n,
+  int* __restrict__ blk_cnt)
+{
+  const int64_t base = (int64_t) blockIdx.x * kPrePerBlock;
+  int cnt = 0;
+  for (int r = 0; r < 4; r++)
+  {
+    const int64_t i = base + r * kPreBlock + threadIdx.x;
+    if (i < n)
+    {
+      const float* p = xyz + i * stride;
+      cnt += finite3(p[0], p[1], p[2]) ? 1 : 0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    cnt += __shfl_down(cnt, o);
+  __shared__ int s[4];
+  if ((threadIdx.x & 63) == 0)
+    s[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// Exclusive scan of an int array with one block (in place); total to *total if given.
+__global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t nb, long long* total)
+{
+  __shared__ long long carry;
+  __shared__ int wsum[16];
+  if (threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += 1024)
+  {
+    const int64_t i = b0 + threadIdx.x;
+    const int x = i < nb ? v[i] : 0;
+    int incl = x;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int y = __shfl_up(incl, o);
+      if ((int) (threadIdx.x & 63) >= o)
+        incl += y;
+    }
+    if ((threadIdx.x & 63) == 63)
+      wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int) (threadIdx.x >> 6); w++)
+      wbase += wsum[w];
+    if (i < nb)
+      v[i] = (int) (carry + wbase + incl - x);  // (ranks < 2^30 by the API's bound on n)
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry += wbase + incl;
+    __syncthreads();
+  }
+  if (total && threadIdx.x == 0)
+    *total = carry;
+}
+
+// Camera id (rank in the NaN-free cloud >= size_left), workspace test, per-camera minimum and maximum.
+__global__ __launch_bounds__(kPreBlock) void k_vox_classify(const float* __restrict__ xyz, int64_t stride, int64_t n,
+  const int* __restrict__ blk_prefix, int64_t size_left, VoxWorkspace ws, uint8_t* __restrict__ code, VoxDesc* d)
+{
+  __shared__ int wcnt[4];
+  __shared__ unsigned smn[2][3], smx[2][3];
+  __shared__ int skept[2];
+  if (threadIdx.x < 6)
+  {
+    smn[threadIdx.x / 3][threadIdx.x % 3] = 0xffffffffu;
+    smx[threadIdx.x / 3][threadIdx.x % 3] = 0u;
+  }
+  if (threadIdx.x < 2)
+    skept[threadIdx.x] = 0;
+  const int64_t base = (int64_t) blockIdx.x * kPrePerBlock;
+  int64_t running = blk_prefix ? (int64_t) blk_prefix[blockIdx.x] : base;  // finite points before this round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned mn[2][3], mx[2][3];
+  for (int c = 0; c < 2; c++)
+    for (int a = 0; a < 3; a++)
+    {
+      mn[c][a] = 0xffffffffu;
+      mx[c][a] = 0u;
+    }
+  int kept[2] = { 0, 0 };
+  for (int r = 0; r < 4; r++)
+  {
+    const int64_t i = base + r * kPreBlock + threadIdx.x;
+    float p[3] = { 0.f, 0.f, 0.f };
+    bool fin = false;
+    if (i < n)
+    {
+      const float* q = xyz + i * stride;
+      p[0] = q[0];
+      p[1] = q[1];
+      p[2] = q[2];
+      fin = blk_prefix ? finite3(p[0], p[1], p[2]) : true;
+    }
+    const unsigned long long m = __ballot(fin);
+    __syncthreads();  // (also orders the LDS initialisation above before its first use)
+    if (lane == 0)
+      wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++)
+      before += wcnt[w];
+    const int64_t rank = running + before;
+    running += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (i < n)
+    {
+      const int cam = rank >= size_left ? 1 : 0;
+      const bool in = fin && (double) p[0] >= ws.lo[0] && (double) p[0] <= ws.hi[0] && (double) p[1] >= ws.lo[1] &&
+                      (double) p[1] <= ws.hi[1] && (double) p[2] >= ws.lo[2] && (double) p[2] <= ws.hi[2];
+      code[i] = in ? (uint8_t) (1 | (cam << 1)) : (uint8_t) 0;
+      if (in)
+      {
+        kept[cam]++;
+        for (int a = 0; a < 3; a++)
+        {
+          const unsigned e = enc_float(p[a]);
+          mn[cam][a] = min(mn[cam][a], e);
+          mx[cam][a] = max(mx[cam][a], e);
+        }
+      }
+    }
+  }
+  for (int c = 0; c < 2; c++)
+  {
+    for (int a = 0; a < 3; a++)
+    {
+      unsigned lo = mn[c][a], hi = mx[c][a];
+      for (int o = 32; o > 0; o >>= 1)
+      {
+        lo = min(lo, (unsigned) __shfl_down(lo, o));
+        hi = max(hi, (unsigned) __shfl_down(hi, o));
+      }
+      if (lane == 0)
+      {
+        atomicMin(&smn[c][a], lo);
+        atomicMax(&smx[c][a], hi);
+      }
+    }
+    int k = kept[c];
+    for (int o = 32; o > 0; o >>= 1)
+      k += __shfl_down(k, o);
+    if (lane == 0 && k)
+      atomicAdd(&skept[c], k);
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)  // one global atomic pair per block, camera and axis
+  {
+    const int c = threadIdx.x / 3, a = threadIdx.x % 3;
+    if (skept[c] > 0)
+    {
+      atomicMin(&d->mn_enc[c][a], smn[c][a]);
+      atomicMax(&d->mx_enc[c][a], smx[c][a]);
+    }
+  }
+  if (threadIdx.x < 2 && skept[threadIdx.x] > 0)
+    atomicAdd((unsigned long long*) &d->n_kept[threadIdx.x], (unsigned long long) skept[threadIdx.x]);
+}
+
+// Voxel index along one axis exactly as localization.cpp:288: floor((double(p) - min) / cell).
+__device__ __forceinline__ long long vox_index(float p, double mn, double cell)
+{
+  return (long long) floor(((double) p - mn) / cell);
+}
+
+__global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_words)
+{
+  unsigned long long ofs = 0;
+  for (int c = 0; c < 2; c++)
+  {
+    unsigned long long bits = 0;
+    for (int a = 0; a < 3; a++)
+    {
+      d->mn[c][a] = (double) dec_float(d->mn_enc[c][a]);
+      d->dim[c][a] = 0;
+    }
+    if (d->n_kept[c] > 0)
+    {
+      bits = 1;
+      for (int a = 0; a < 3; a++)
+      {
+        const long long top = vox_index(dec_float(d->mx_enc[c][a]), d->mn[c][a], cell);
+        if (top < 0 || top >= (1ll << 31) - 1)
+        {
+          d->error = 1;
+          bits = 0;
+          break;
+        }
+        d->dim[c][a] = (int) top + 1;
+        // (the product is checked against max_words step by step so that it cannot wrap)
+        if (bits > (max_words * 32ull) / (unsigned long long) d->dim[c][a])
+        {
+          d->error = 1;
+          bits = 0;
+          break;
+        }
+        bits *= (unsigned long long) d->dim[c][a];
+      }
+    }
+    d->bits[c] = bits;
+    d->word_ofs[c] = ofs;
+    unsigned long long words = (bits + 31ull) / 32ull;
+    words = (words + kWordsPerBlock - 1ull) / kWordsPerBlock * kWordsPerBlock;  // camera 1 starts on a block boundary
+    ofs += words;
+  }
+  d->n_words = ofs;
+  if (ofs > max_words)
+    d->error = 1;
+}
+
+__global__ __launch_bounds__(256) void k_vox_mark(const float* __restrict__ xyz, int64_t stride, int64_t n,
+  const uint8_t* __restrict__ code, const VoxDesc* __restrict__ d, double cell, unsigned* __restrict__ bitmap)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const unsigned cd = code[i];
+  if (!cd)
+    return;
+  const int c = (int) (cd >> 1);
+  const float* p = xyz + i * stride;
+  const unsigned long long ix = (unsigned long long) vox_index(p[0], d->mn[c][0], cell);
+  const unsigned long long iy = (unsigned long long) vox_index(p[1], d->mn[c][1], cell);
+  const unsigned long long iz = (unsigned long long) vox_index(p[2], d->mn[c][2], cell);
+  const unsigned long long pos = (ix * (unsigned long long) d->dim[c][1] + iy) * (unsigned long long) d->dim[c][2] + iz;
+  atomicOr(&bitmap[d->word_ofs[c] + (pos >> 5)], 1u << (unsigned) (pos & 31ull));
+}
+
+__global__ __launch_bounds__(256) void k_vox_popcount(const unsigned* __restrict__ bitmap, int* __restrict__ blk_cnt)
+{
+  const uint4* w = (const uint4*) (bitmap + (size_t) blockIdx.x * kWordsPerBlock) + threadIdx.x * 4;
+  int cnt = 0;
+  for (int k = 0; k < 4; k++)
+  {
+    const uint4 v = w[k];
+    cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    cnt += __shfl_down(cnt, o);
+  __shared__ int s[4];
+  if ((threadIdx.x & 63) == 0)
+    s[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void k_vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, const long long* total)
+{
+  const long long first1 = d->word_ofs[1] / kWordsPerBlock < d->n_words / kWordsPerBlock
+                             ? (long long) blk_prefix[d->word_ofs[1] / kWordsPerBlock]
+                             : *total;
+  d->n_vox[0] = first1;
+  d->n_vox[1] = *total - first1;
+}
+
+// Emit the voxels in bitmap order = (camera, x, y, z) lexicographic order; coordinates as localization.cpp:313-324.
+__global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ bitmap, const int* __restrict__ blk_prefix,
+  const VoxDesc* __restrict__ d, double cell, float* __restrict__ out_xyz, int32_t* __restrict__ out_cam)
+{
+  const size_t w0 = (size_t) blockIdx.x * kWordsPerBlock + (size_t) threadIdx.x * 16;
+  unsigned w[16];
+  const uint4* src = (const uint4*) (bitmap + w0);
+  int cnt = 0;
+  for (int k = 0; k < 4; k++)
+  {
+    const uint4 v = src[k];
+    w[4 * k] = v.x;
+    w[4 * k + 1] = v.y;
+    w[4 * k + 2] = v.z;
+    w[4 * k + 3] = v.w;
+    cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int y = __shfl_up(incl, o);
+    if ((int) (threadIdx.x & 63) >= o)
+      incl += y;
+  }
+  __shared__ int wsum[4];
+  if ((threadIdx.x & 63) == 63)
+    wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int64_t k = (int64_t) blk_prefix[blockIdx.x] + incl - cnt;
+  for (int q = 0; q < (int) (threadIdx.x >> 6); q++)
+    k += wsum[q];
+  if (!cnt)
+    return;
+  const int c = w0 >= d->word_ofs[1] ? 1 : 0;
+  const unsigned long long ny = (unsigned long long) d->dim[c][1], nz = (unsigned long long) d->dim[c][2];
+  const double m0 = d->mn[c][0], m1 = d->mn[c][1], m2 = d->mn[c][2];
+  for (int j = 0; j < 16; j++)
+  {
+    unsigned bits = w[j];
+    while (bits)
+    {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const unsigned long long pos = ((unsigned long long) (w0 + j) - d->word_ofs[c]) * 32ull + (unsigned) b;
+      const unsigned long long t = pos / nz;
+      const long long iz = (long long) (pos - t * nz), iy = (long long) (t % ny), ix = (long long) (t / ny);
+      out_xyz[3 * k] = (float) ((double) ix * cell + 1.0 * m0);
+      out_xyz[3 * k + 1] = (float) ((double) iy * cell + 1.0 * m1);
+      out_xyz[3 * k + 2] = (float) ((double) iz * cell + 1.0 * m2);
+      out_cam[k] = c;
+      k++;
+    }
+  }
+}
+
+int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell, hipStream_t st)
+{
+  VoxWorkspace ws;
+  for (int a = 0; a < 3; a++)
+  {
+    ws.lo[a] = workspace[2 * a];
+    ws.hi[a] = workspace[2 * a + 1];
+  }
+  const int64_t nb = (n + kPrePerBlock - 1) / kPrePerBlock;
+  hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(1), 0, st, c->d_vox_desc);
+  if (n > 0)
+  {
+    if (!dense)
+    {
+      hipLaunchKernelGGL(k_vox_count, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n, c->d_vox_blk);
+      hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk, nb, (long long*) nullptr);
+    }
+    hipLaunchKernelGGL(k_vox_classify, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n,
+      dense ? (const int*) nullptr : (const int*) c->d_vox_blk, size_left, ws, c->d_vox_code, c->d_vox_desc);
+  }
+  hipLaunchKernelGGL(k_vox_lattice, dim3(1), dim3(1), 0, st, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st)
+{
+  const int64_t nb2 = n_words / kWordsPerBlock;
+  if (hipMemsetAsync(c->d_vox_bitmap, 0, (size_t) n_words * 4, st) != hipSuccess)
+    return AGH_ERR_HIP;
+  if (n > 0 && n_words > 0)
+  {
+    hipLaunchKernelGGL(k_vox_mark, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_xyz, stride_floats, n,
+      (const uint8_t*) c->d_vox_code, (const VoxDesc*) c->d_vox_desc, cell, c->d_vox_bitmap);
+    hipLaunchKernelGGL(k_vox_popcount, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
+      c->d_vox_blk2);
+  }
+  hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk2, nb2, c->d_vox_total);
+  hipLaunchKernelGGL(k_vox_totals, dim3(1), dim3(1), 0, st, c->d_vox_desc, (const int*) c->d_vox_blk2,
+    (const long long*) c->d_vox_total);
+  if (n > 0 && n_words > 0)
+    hipLaunchKernelGGL(k_vox_emit, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
+      (const int*) c->d_vox_blk2, (const VoxDesc*) c->d_vox_desc, cell, c->d_vox_xyz, c->d_vox_cam);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+}  // namespace agh

@@ -191,3 +191,41 @@ def config(name: str) -> Scene:
     if name == "small":
         return make_scene(40_000, 200, seed=5, two_view=True, n_objects=6, name="small")
     raise KeyError(name)
+
+
+@dataclasses.dataclass
+class RawCloud:
+    """A two-camera cloud as it enters Localization::localizeHands (before NaN removal / workspace / voxels)."""
+    xyz: np.ndarray  # (N, 3) float32, camera 0 block then camera 1 block, may hold NaN rows
+    size_left: int
+    workspace: np.ndarray  # (6,) float64 {xmin, xmax, ymin, ymax, zmin, zmax}
+    cam_origins: np.ndarray
+
+
+def make_raw_cloud(n_points: int, seed: int, nan_frac: float = 0.01, n_objects: int = 14, trim: float = 0.03) -> RawCloud:
+    """Raw (un-voxelised) two-view capture of the tabletop scene: 1.5 mm surface samples kept with probability 0.8
+    per camera and jittered, ``nan_frac`` of the rows replaced by NaN (sensor drop-outs), and a workspace box that
+    cuts ``trim`` metres off every side of the scene's bounding box so that the filter has work to do."""
+    rng = np.random.default_rng(seed)
+    want_area = 0.5 * n_points * (0.0015 ** 2) / 0.8
+    table_area = max(want_area - 0.023 * n_objects, 0.25 * want_area)
+    lx, ly = np.sqrt(table_area * 1.3), np.sqrt(table_area / 1.3)
+    raw = to_scene_frame(_surface_points(np.random.default_rng(seed), (0.5, 0.5 + lx, -ly / 2, ly / 2, -0.10),
+                                         n_objects, 0.0015))
+    views = []
+    for _cam in range(2):
+        keep = rng.random(raw.shape[0]) < 0.8
+        views.append(raw[keep] + rng.uniform(-0.0003, 0.0003, size=(int(keep.sum()), 3)))
+    # trim both views by the same factor to reach n_points in total (order preserved)
+    total = views[0].shape[0] + views[1].shape[0]
+    if total > n_points:
+        f = n_points / total
+        views = [v[np.sort(rng.permutation(v.shape[0])[:int(v.shape[0] * f)])] for v in views]
+    xyz = np.concatenate(views).astype(np.float32)
+    size_left = views[0].shape[0]
+    if nan_frac > 0:
+        bad = rng.random(xyz.shape[0]) < nan_frac
+        xyz[bad] = np.nan
+    lo, hi = np.nanmin(xyz, 0).astype(np.float64) + trim, np.nanmax(xyz, 0).astype(np.float64) - trim
+    ws = np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]])
+    return RawCloud(np.ascontiguousarray(xyz), int(size_left), ws, to_scene_frame(camera_origins()))

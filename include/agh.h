@@ -124,6 +124,21 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
 int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
   int64_t n, void* hip_stream);
 
+/* The head of Localization::localizeHands (localization.cpp:17-45) on the GPU, followed by the grid build: camera id of
+ * raw point i = (i >= size_left); removal of points with a non-finite coordinate (skipped when dense != 0, like
+ * pcl::removeNaNFromPointCloud on an is_dense cloud) WITHOUT re-indexing the camera ids (the reference's behaviour);
+ * workspace box {xmin,xmax,ymin,ymax,zmin,zmax} (filterWorkspace, :216-245); per-camera voxelisation with cell_size
+ * (voxelizeCloud, :247-355; the reference passes 0.003) in lexicographic voxel order, camera 0 block first.  The
+ * voxelised cloud becomes the context's cloud (as after agh_set_cloud) and can be read back with agh_get_cloud.
+ * The device variant synchronises hip_stream twice (lattice size, voxel count).  AGH_ERR_CAPACITY if the kept points
+ * span more than 2^33 lattice cells. */
+int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell_size, int64_t* n_voxels_out);
+int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
+  int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream);
+/* The context's current cloud: packed xyz (3 floats per point) and camera ids; returns the number of points. */
+int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
+
 /* HandSearch::findHands for explicit sample indices.  out receives <= 8*n_samples records, sample-major and
  * orientation-ascending (the reference's concatenation order, hand_search.cpp:194-200). */
 int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,

@@ -23,6 +23,8 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <set>
+#include <array>
 #include <vector>
 
 namespace
@@ -1580,6 +1582,67 @@ int orc_solve_taubin(const double* M, const double* N, double* v_out, double* la
       Nm[i][j] = N[i * 10 + j];
     }
   return solve_taubin(Mm, Nm, v_out, lambda_out) ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// f1: the preprocessing in front of HandSearch::findHands (/root/reference/src/agile_grasp/localization.cpp)
+//   17-24   camera id of point i = (i >= size_left), assigned BEFORE the NaN removal and never re-indexed
+//   25-27   pcl::removeNaNFromPointCloud: order-preserving removal of points with a non-finite coordinate; a cloud
+//           flagged is_dense is copied as it is (PCL filter.hpp) -- `dense` selects that branch
+//   216-245 filterWorkspace: keep min <= p <= max per axis (float promoted to double), camera id taken at the
+//           point's position in the NaN-free cloud
+//   247-355 voxelizeCloud: per-camera minimum, floor((p - min) / cell) in double, std::set in lexicographic
+//           (x, y, z) order (localization.h:273-293), coordinates back as v * cell + 1 * min, stored as float;
+//           camera 0 block, then camera 1 block.
+int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell_size, float* xyz_out, int32_t* cam_out, int64_t cap)
+{
+  std::vector<std::array<float, 3>> pts;
+  pts.reserve((size_t) n);
+  for (int64_t i = 0; i < n; i++)
+  {
+    const float* p = xyz + i * stride_floats;
+    if (dense || (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])))
+      pts.push_back({ p[0], p[1], p[2] });
+  }
+  std::vector<std::array<float, 3>> ws;
+  std::vector<int> cam;
+  for (size_t i = 0; i < pts.size(); i++)
+  {
+    const std::array<float, 3>& p = pts[i];
+    if (p[0] >= workspace[0] && p[0] <= workspace[1] && p[1] >= workspace[2] && p[1] <= workspace[3] &&
+        p[2] >= workspace[4] && p[2] <= workspace[5])
+    {
+      ws.push_back(p);
+      cam.push_back((int64_t) i >= size_left ? 1 : 0);
+    }
+  }
+  double mn[2][3] = { { 10000, 10000, 10000 }, { 10000, 10000, 10000 } };
+  for (size_t i = 0; i < ws.size(); i++)
+    for (int a = 0; a < 3; a++)
+      if (ws[i][a] < mn[cam[i]][a])
+        mn[cam[i]][a] = ws[i][a];
+  std::set<std::array<int, 3>> bins[2];  // std::array compares lexicographically, like UniqueVectorComparator
+  for (size_t i = 0; i < ws.size(); i++)
+  {
+    std::array<int, 3> v;
+    for (int a = 0; a < 3; a++)
+      v[a] = (int) std::floor(((double) ws[i][a] - mn[cam[i]][a]) / cell_size);
+    bins[cam[i]].insert(v);
+  }
+  int64_t k = 0;
+  for (int c = 0; c < 2; c++)
+    for (const std::array<int, 3>& v : bins[c])
+    {
+      if (k < cap)
+      {
+        for (int a = 0; a < 3; a++)
+          xyz_out[3 * k + a] = (float) ((double) v[a] * cell_size + 1.0 * mn[c][a]);
+        cam_out[k] = c;
+      }
+      k++;
+    }
+  return k;
 }
 
 } // extern "C"

@@ -118,6 +118,11 @@ void orc_glibc_rand(uint32_t seed, int32_t* out, int64_t count);
 /* generalized eigen reduction exposed for the LAPACK goldens: M,N 10x10 row-major; v_out 10. */
 int orc_solve_taubin(const double* M, const double* N, double* v_out, double* lambda_out);
 
+/* f1: NaN removal + workspace box + per-camera voxelisation (localization.cpp:17-45,216-355).  xyz_out 3*cap floats,
+ * cam_out cap ints; returns the number of voxels (may exceed cap: then only cap are written). */
+int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell_size, float* xyz_out, int32_t* cam_out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

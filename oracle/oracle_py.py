@@ -227,3 +227,18 @@ def solve_taubin(M: np.ndarray, N: np.ndarray):
     lam = C.c_double(0)
     rc = lib().orc_solve_taubin(_fp(M, C.c_double), _fp(N, C.c_double), _fp(v, C.c_double), C.byref(lam))
     return rc, v, lam.value
+
+
+def preprocess(xyz: np.ndarray, size_left: int, workspace, cell_size: float = 0.003, dense: bool = False):
+    """NaN removal + workspace filter + per-camera voxelisation (localization.cpp:17-45,216-355)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[0]
+    ws = np.ascontiguousarray(workspace, np.float64)
+    out = np.zeros((max(n, 1), 3), np.float32)
+    cam = np.zeros(max(n, 1), np.int32)
+    f = lib().orc_preprocess
+    f.restype = C.c_int64
+    k = f(_fp(xyz, C.c_float), C.c_int64(xyz.shape[1] if n else 3), C.c_int64(n), C.c_int64(size_left),
+          C.c_int(1 if dense else 0), _fp(ws, C.c_double), C.c_double(cell_size), _fp(out, C.c_float),
+          _fp(cam, C.c_int32), C.c_int64(out.shape[0]))
+    return out[:k].copy(), cam[:k].copy()

@@ -160,3 +160,28 @@ def convert_to_image(pts, binormal, source_to_center):
     vc = np.minimum(79, np.maximum(0, vc))
     img[79 - vc, hc] = 255
     return img
+
+
+def preprocess(xyz, size_left, ws, cell=0.003, dense=False):
+    """Second transcription of the head of Localization::localizeHands (localization.cpp:17-45, 216-355): camera id by
+    position in the NaN-free cloud, workspace box, per-camera lattice floor((p - min) / cell), unique voxels in
+    lexicographic order, coordinates v * cell + min as float32, camera 0 block then camera 1 block."""
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    fin = np.isfinite(xyz).all(1) if not dense else np.ones(len(xyz), bool)
+    p = xyz[fin]
+    cam = (np.arange(len(p)) >= size_left).astype(np.int32)
+    pd = p.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        inb = ((pd[:, 0] >= ws[0]) & (pd[:, 0] <= ws[1]) & (pd[:, 1] >= ws[2]) & (pd[:, 1] <= ws[3]) &
+               (pd[:, 2] >= ws[4]) & (pd[:, 2] <= ws[5]))
+    pd, cam = pd[inb], cam[inb]
+    outs, cams = [np.zeros((0, 3), np.float32)], [np.zeros(0, np.int32)]
+    for c in range(2):
+        q = pd[cam == c]
+        if len(q) == 0:
+            continue
+        mn = np.minimum(q.min(0), 10000.0)
+        vx = np.unique(np.floor((q - mn) / cell).astype(np.int64), axis=0)
+        outs.append((vx.astype(np.float64) * cell + mn).astype(np.float32))
+        cams.append(np.full(len(vx), c, np.int32))
+    return np.concatenate(outs), np.concatenate(cams)

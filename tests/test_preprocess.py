@@ -1,0 +1,121 @@
+"""NaN removal + workspace box + per-camera voxelisation (localization.cpp:17-45,216-355).
+
+CPU part: the C++ oracle against an independent numpy transcription.  GPU part: the HIP bitmap voxeliser (through the
+C ABI) against the oracle -- same points, same order, same float32 bits, same camera ids -- and the chain
+preprocess -> find_hands against set_cloud(oracle voxels) -> find_hands.
+"""
+import numpy as np
+import pytest
+
+from tests import ref_numpy
+
+BIG = [-1e3, 1e3, -1e3, 1e3, -1e3, 1e3]
+
+
+def _cases():
+    from agile_grasp_amd import synthetic
+
+    rng = np.random.default_rng(11)
+    out = {}
+    rc = synthetic.make_raw_cloud(60_000, 7)
+    out["scene_nan_ws"] = (rc.xyz, rc.size_left, rc.workspace, False)
+    out["scene_dense_flag"] = (rc.xyz, rc.size_left, rc.workspace, True)  # is_dense clouds skip the NaN compaction
+    out["scene_no_ws"] = (rc.xyz, rc.size_left, BIG, False)
+    out["left_only"] = (rc.xyz[:rc.size_left], rc.size_left, rc.workspace, False)
+    out["right_only"] = (rc.xyz, 0, rc.workspace, False)
+    out["size_left_beyond"] = (rc.xyz[:5000], 10_000, BIG, False)
+    out["empty"] = (np.zeros((0, 3), np.float32), 0, BIG, False)
+    out["all_nan"] = (np.full((300, 3), np.nan, np.float32), 100, BIG, False)
+    out["all_outside"] = (rng.uniform(2, 3, (500, 3)).astype(np.float32), 250, [0, 1, 0, 1, 0, 1], False)
+    out["single_point"] = (np.array([[0.1, -0.2, 0.3]], np.float32), 1, BIG, False)
+    # coordinates exactly on lattice planes, on the workspace faces, negative, +-0 and +-inf
+    g = (np.arange(-40, 40)[:, None] * 0.003).astype(np.float32)
+    lat = np.concatenate([np.concatenate([g, g * 0, g * 0 + 0.5], 1), np.concatenate([g * 0 - 0.0, g, -g], 1)])
+    lat = np.concatenate([lat, [[np.inf, 0, 0], [0, -np.inf, 0], [-0.12, 0.0, 0.5], [0.117, -0.0, 0.5]]]).astype(np.float32)
+    out["lattice_planes"] = (lat, 80, [-0.12, 0.117, -0.12, 0.117, -0.2, 0.5], False)
+    dup = np.repeat(rng.uniform(-0.05, 0.05, (40, 3)).astype(np.float32), 50, 0)
+    out["duplicates"] = (dup[rng.permutation(len(dup))], 1000, BIG, False)
+    far = rng.uniform(10_000.2, 10_001.0, (400, 3)).astype(np.float32)  # beyond the initial minimum 10000: it stays
+    out["beyond_10000"] = (far, 200, [0, 2e4, 0, 2e4, 0, 2e4], False)
+    sparse = rng.uniform(-2, 2, (20_000, 3)).astype(np.float32)     # 1334^3 lattice per camera, almost empty bitmap
+    out["sparse_wide"] = (sparse, 9000, BIG, False)
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_numpy_transcription(name):
+    from oracle import oracle_py as orc
+
+    xyz, size_left, ws, dense = CASES[name]
+    v, cam = orc.preprocess(xyz, size_left, ws, 0.003, dense)
+    v2, cam2 = ref_numpy.preprocess(xyz, size_left, ws, 0.003, dense)
+    assert np.array_equal(v.view(np.uint32), v2.view(np.uint32))
+    assert np.array_equal(cam, cam2)
+    if len(v):  # lexicographic order inside each camera block, camera 0 first, no duplicates
+        assert (np.diff(cam) >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_voxeliser_bit_exact(name):
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as orc
+
+    xyz, size_left, ws, dense = CASES[name]
+    ctx = binding.Context(synthetic.camera_origins())
+    for stride_pad in (0, 5):  # packed xyz and pcl::PointXYZRGBA-like 32-byte points
+        x = xyz if stride_pad == 0 else np.concatenate([xyz, np.full((len(xyz), stride_pad), 7.0, np.float32)], 1)
+        nv = ctx.preprocess(x, size_left, ws, 0.003, dense)
+        v, cam = orc.preprocess(xyz, size_left, ws, 0.003, dense)
+        assert nv == len(v)
+        gv, gcam = ctx.cloud()
+        assert np.array_equal(gv.view(np.uint32), v.view(np.uint32))
+        assert np.array_equal(gcam, cam)
+
+
+@pytest.mark.gpu
+def test_gpu_voxeliser_other_cell_sizes_and_reuse():
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as orc
+
+    rc = synthetic.make_raw_cloud(40_000, 9)
+    ctx = binding.Context(rc.cam_origins)
+    for cell in (0.003, 0.01, 0.0007, 0.05):   # the context's buffers grow and are reused across calls
+        nv = ctx.preprocess(rc.xyz, rc.size_left, rc.workspace, cell)
+        v, cam = orc.preprocess(rc.xyz, rc.size_left, rc.workspace, cell)
+        gv, gcam = ctx.cloud()
+        assert nv == len(v) and np.array_equal(gv.view(np.uint32), v.view(np.uint32)) and np.array_equal(gcam, cam)
+
+
+@pytest.mark.gpu
+def test_lattice_too_large_is_loud():
+    from agile_grasp_amd import binding, synthetic
+
+    ctx = binding.Context(synthetic.camera_origins())
+    pts = np.array([[0, 0, 0], [900, 900, 900]], np.float32)  # 300000^3 cells
+    with pytest.raises(binding.AghError) as e:
+        ctx.preprocess(pts, 2, BIG, 0.003)
+    assert e.value.code == -4 and "lattice" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_preprocess_then_search_equals_oracle_chain():
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as orc
+
+    rc = synthetic.make_raw_cloud(60_000, 7)
+    v, cam = orc.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    samples = np.sort(np.random.default_rng(3).permutation(len(v))[:96]).astype(np.int32)
+    p = orc.default_params(rc.cam_origins)
+    ref = orc.find_hands(p, v, cam, samples)
+    ctx = binding.Context(rc.cam_origins)
+    ctx.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    got = ctx.find_hands(samples)
+    rh = ref["hyps"]
+    assert len(got) == len(rh) and len(got) > 0
+    for f in ("sample", "orientation", "cam_source", "n_in_box", "axis", "approach", "binormal", "bottom", "surface",
+              "width"):
+        assert np.array_equal(got[f], rh[f]), f
