@@ -91,6 +91,63 @@ public:
     int rc = agh_set_cloud(ctx_, &cloud->points[0].x, (std::int64_t) sizeof(cloud->points[0]), cam.data(), n);
     if (rc != AGH_OK)
       return fail("agh_set_cloud");
+    return findHandsInSearchedCloud(indices, calculates_antipodal);
+  }
+
+  /** The head of Localization::localizeHands on the GPU (localization.cpp:17-45: camera ids, NaN removal, workspace
+   *  box, per-camera voxelisation) followed by the search-structure build.  The voxelised cloud stays on the device as
+   *  the cloud findHandsInSearchedCloud works on; a host copy is returned for the caller (plots, sample indices).
+   *  @return false (after printing) on error */
+  bool preprocess(const PointCloud::Ptr& cloud_in, int size_left, const VectorXd& workspace, double cell_size,
+    PointCloud::Ptr& voxels_out, VectorXi& pts_cam_source_out)
+  {
+    if (!ensureContext())
+      return false;
+    double ws[6];
+    for (int i = 0; i < 6; i++)
+      ws[i] = workspace(i);
+    std::int64_t nv = 0;
+    const std::int64_t n = (std::int64_t) cloud_in->size();
+    int rc = agh_preprocess(ctx_, n > 0 ? &cloud_in->points[0].x : nullptr, (std::int64_t) sizeof(cloud_in->points[0]), n,
+      (std::int64_t) size_left, cloud_is_dense(*cloud_in) ? 1 : 0, ws, cell_size, &nv);
+    if (rc != AGH_OK)
+    {
+      fail("agh_preprocess");
+      return false;
+    }
+    std::vector<float> xyz(3 * (std::size_t) nv + 3);
+    std::vector<std::int32_t> cam((std::size_t) nv + 1);
+    if (agh_get_cloud(ctx_, xyz.data(), cam.data(), nv) < 0)
+    {
+      fail("agh_get_cloud");
+      return false;
+    }
+    voxels_out.reset(new PointCloud);
+    voxels_out->points.resize((std::size_t) nv);
+    pts_cam_source_out = VectorXi((std::size_t) nv);
+    for (std::int64_t i = 0; i < nv; i++)
+    {
+      voxels_out->points[(std::size_t) i].x = xyz[3 * (std::size_t) i];
+      voxels_out->points[(std::size_t) i].y = xyz[3 * (std::size_t) i + 1];
+      voxels_out->points[(std::size_t) i].z = xyz[3 * (std::size_t) i + 2];
+      pts_cam_source_out((std::size_t) i) = cam[(std::size_t) i];
+    }
+    searched_n_ = nv;
+    return true;
+  }
+
+  /** hand_search.cpp:31-62 on the cloud the context already holds (after findHands' upload or preprocess). */
+  std::vector<GraspHypothesis> findHandsInSearchedCloud(const std::vector<int>& indices, bool calculates_antipodal)
+  {
+    std::vector<GraspHypothesis> hand_list;
+    if (!ctx_)
+      return hand_list;
+    const std::int64_t n = (std::int64_t) agh_get_cloud(ctx_, nullptr, nullptr, 0);
+    if (n <= 0)
+    {
+      std::cout << "Input cloud is empty!\n";
+      return hand_list;
+    }
     std::vector<std::int32_t> idx;
     if (indices.empty())
     {
@@ -104,7 +161,7 @@ public:
     std::cout << "Estimating local axes ...\nFinding hand poses ...\n";  // hand_search.cpp:52,58
     std::vector<agh_hypothesis> out(8 * idx.size() + 1);
     std::int64_t n_out = 0;
-    rc = agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
+    const int rc = agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
       (std::int64_t) out.size(), &n_out);
     if (rc != AGH_OK)
       return fail("agh_find_hands");
@@ -171,6 +228,7 @@ private:
   }
 
   agh_ctx* ctx_;
+  std::int64_t searched_n_ = 0;
   agh_params params_;
   Matrix4d cam_tf_left_, cam_tf_right_;
   int num_threads_, num_samples_;

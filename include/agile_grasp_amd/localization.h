@@ -2,9 +2,8 @@
 //
 // Kept: constructors, every setter, localizeHands(cloud, size_left, indices, calculates_antipodal, uses_clustering),
 // predictAntipodalHands(hand_list, svm_filename), filterHands.  The preprocessing that precedes the hot path
-// (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355) is restated here on the
-// host, operation for operation, because its output ORDER defines the point indices the search works on; moving it to
-// the GPU is the first "next" row of SURVEY 8f.  Not carried over: the RANSAC table-plane removal behind
+// (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355; its output ORDER defines
+// the point indices the search works on) runs on the GPU as well (agh_preprocess).  Not carried over: the RANSAC table-plane removal behind
 // uses_clustering (localization.cpp:51-98, pcl::SACSegmentation; training path only), findHandles (HandleSearch, out of
 // scope), the Plot members, and the PCD-filename overloads unless PCL is available.
 #ifndef AGILE_GRASP_AMD_LOCALIZATION_H
@@ -13,7 +12,6 @@
 #include <cmath>
 #include <iostream>
 #include <memory>
-#include <set>
 #include <string>
 #include <vector>
 
@@ -98,40 +96,21 @@ public:
       std::cout << size_left << std::endl;
       return hand_list;
     }
-    // camera source of every point (0 = left, 1 = right), localization.cpp:17-24
+    // localization.cpp:17-45 on the GPU (agh_preprocess): camera id = (position >= size_left), removal of non-finite
+    // points WITHOUT re-indexing the camera ids (the reference's behaviour), workspace box, per-camera 3 mm voxels in
+    // lexicographic order.  Unlike pcl::removeNaNFromPointCloud(*cloud_in, *cloud_in, ...) the caller's cloud is left
+    // untouched.
     std::cout << "Generating camera sources for " << cloud_in->size() << " points ...\n";
-    std::vector<int> cam(cloud_in->size(), 0);
-    for (std::size_t i = (std::size_t) size_left; i < cam.size(); i++)
-      cam[i] = 1;
-    // pcl::removeNaNFromPointCloud(*cloud_in, *cloud_in, ...) (27): in place, order preserved.  NB the reference does
-    // NOT re-index pts_cam_source here; neither do we (a cloud with NaNs shifts camera ids exactly as it does there).
-    {
-      std::size_t k = 0;
-      for (std::size_t i = 0; i < cloud_in->points.size(); i++)
-      {
-        const float x = cloud_in->points[i].x, y = cloud_in->points[i].y, z = cloud_in->points[i].z;
-        if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z))
-          cloud_in->points[k++] = cloud_in->points[i];
-      }
-      cloud_in->points.resize(k);
-    }
-    std::cout << "Filtering workspace ...\n";
-    PointCloud::Ptr cloud(new PointCloud);
-    std::vector<int> cam_ws;
-    filterWorkspace(cloud_in, cam, cloud, cam_ws);
-    std::cout << " " << cloud->size() << " points left\n";
-    std::cout << "Voxelizing point cloud\n";
-    PointCloud::Ptr voxels(new PointCloud);
-    std::vector<int> cam_vox;
-    voxelizeCloud(cloud, cam_ws, voxels, cam_vox, 0.003);
+    std::cout << "Filtering workspace ...\nVoxelizing point cloud\n";
+    ensureSearch();
+    PointCloud::Ptr voxels;
+    VectorXi pts_cam_source;
+    if (!search_->preprocess(cloud_in, size_left, workspace_, 0.003, voxels, pts_cam_source))
+      return hand_list;
     std::cout << " Created " << voxels->points.size() << " voxels\n";
     if (uses_clustering)
       std::cout << " (table-plane removal needs pcl::SACSegmentation and is not part of this build; continuing)\n";
-    VectorXi pts_cam_source(cam_vox.size());
-    for (std::size_t i = 0; i < cam_vox.size(); i++)
-      pts_cam_source(i) = cam_vox[i];
-    ensureSearch();
-    hand_list = search_->findHands(voxels, pts_cam_source, indices, voxels, calculates_antipodal, uses_clustering);
+    hand_list = search_->findHandsInSearchedCloud(indices, calculates_antipodal);
     if (filters_boundaries_)
     {
       std::cout << "Filtering out hands close to workspace boundaries ...\n";
@@ -162,80 +141,6 @@ public:
   /** the voxelised cloud and camera ids the last localizeHands searched (what the reference plots) */
   const PointCloud::Ptr& getSearchedCloud() const { return last_cloud_; }
   const VectorXi& getSearchedCamSource() const { return last_cam_; }
-
-  // ---- preprocessing, public so that tests can call it ----
-  /** localization.cpp:216-245 */
-  void filterWorkspace(const PointCloud::Ptr& cloud_in, const std::vector<int>& cam_in, PointCloud::Ptr& cloud_out,
-    std::vector<int>& cam_out) const
-  {
-    PointCloud::Ptr cloud(new PointCloud);
-    cam_out.clear();
-    for (std::size_t i = 0; i < cloud_in->points.size(); i++)
-    {
-      const float x = cloud_in->points[i].x, y = cloud_in->points[i].y, z = cloud_in->points[i].z;
-      if (x >= workspace_(0) && x <= workspace_(1) && y >= workspace_(2) && y <= workspace_(3) && z >= workspace_(4) &&
-          z <= workspace_(5))
-      {
-        cloud->points.push_back(cloud_in->points[i]);
-        cam_out.push_back(cam_in[i]);
-      }
-    }
-    cloud_out = cloud;
-  }
-
-  /** localization.cpp:247-355: per-camera minimum, floor((p - min) / cell), unique in lexicographic order, back to
-   *  coordinates as voxel * cell + min; camera 0 block first, then camera 1. */
-  void voxelizeCloud(const PointCloud::Ptr& cloud_in, const std::vector<int>& cam_in, PointCloud::Ptr& cloud_out,
-    std::vector<int>& cam_out, double cell_size) const
-  {
-    double mn[2][3] = { { 10000, 10000, 10000 }, { 10000, 10000, 10000 } };
-    const std::size_t n = cloud_in->points.size();
-    for (std::size_t i = 0; i < n; i++)
-    {
-      const int c = cam_in[i];
-      if (c != 0 && c != 1)
-        continue;
-      const float p[3] = { cloud_in->points[i].x, cloud_in->points[i].y, cloud_in->points[i].z };
-      for (int a = 0; a < 3; a++)
-        if (p[a] < mn[c][a])
-          mn[c][a] = p[a];
-    }
-    struct Vox
-    {
-      int v[3];
-      bool operator<(const Vox& o) const
-      {
-        for (int a = 0; a < 3; a++)
-          if (v[a] != o.v[a])
-            return v[a] < o.v[a];
-        return false;
-      }
-    };
-    std::set<Vox> bins[2];
-    for (std::size_t i = 0; i < n; i++)
-    {
-      const int c = cam_in[i];
-      if (c != 0 && c != 1)
-        continue;
-      const double p[3] = { (double) cloud_in->points[i].x, (double) cloud_in->points[i].y, (double) cloud_in->points[i].z };
-      Vox vx;
-      for (int a = 0; a < 3; a++)
-        vx.v[a] = (int) std::floor((p[a] - mn[c][a]) / cell_size);
-      bins[c].insert(vx);
-    }
-    PointCloud::Ptr cloud(new PointCloud);
-    cam_out.clear();
-    for (int c = 0; c < 2; c++)
-      for (std::set<Vox>::const_iterator it = bins[c].begin(); it != bins[c].end(); ++it)
-      {
-        cloud->points.resize(cloud->points.size() + 1);
-        cloud->points.back().x = (float) ((double) it->v[0] * cell_size + 1.0 * mn[c][0]);
-        cloud->points.back().y = (float) ((double) it->v[1] * cell_size + 1.0 * mn[c][1]);
-        cloud->points.back().z = (float) ((double) it->v[2] * cell_size + 1.0 * mn[c][2]);
-        cam_out.push_back(c);
-      }
-    cloud_out = cloud;
-  }
 
   /** localization.cpp:364-388 */
   std::vector<GraspHypothesis> filterHands(const std::vector<GraspHypothesis>& hand_list) const

@@ -33,6 +33,7 @@ typedef Eigen::Matrix3Xd Matrix3Xd;
 typedef Eigen::VectorXd VectorXd;
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
+inline bool cloud_is_dense(const PointCloud& c) { return c.is_dense; }
 }  // namespace agile_grasp_amd
 
 #else  // stand-ins
@@ -89,10 +90,12 @@ struct PointCloud
 {
   typedef std::shared_ptr<PointCloud> Ptr;
   std::vector<PointXYZRGBA> points;
+  bool is_dense = false;  // pcl::PointCloud::is_dense: "no point has a non-finite coordinate"
   std::size_t size() const { return points.size(); }
 };
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
+inline bool cloud_is_dense(const PointCloud& c) { return c.is_dense; }
 }  // namespace agile_grasp_amd
 #endif
 

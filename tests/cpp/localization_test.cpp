@@ -51,22 +51,18 @@ int main(int argc, char** argv)
   loc.setDeterministicNormalEstimation(true);
   if (std::strcmp(argv[3], "voxels") == 0)
   {
-    // preprocessing only (runs without a GPU): NaN removal is part of localizeHands, so mimic its order here
-    std::vector<int> cam((size_t) n, 0);
-    for (long long i = size_left; i < n; i++)
-      cam[(size_t) i] = 1;
-    size_t k = 0;
-    for (size_t i = 0; i < cloud->points.size(); i++)
-      if (std::isfinite(cloud->points[i].x) && std::isfinite(cloud->points[i].y) && std::isfinite(cloud->points[i].z))
-        cloud->points[k++] = cloud->points[i];
-    cloud->points.resize(k);
-    PointCloud::Ptr c2, c3;
-    std::vector<int> cam2, cam3;
-    loc.filterWorkspace(cloud, cam, c2, cam2);
-    loc.voxelizeCloud(c2, cam2, c3, cam3, 0.003);
-    std::printf("VOXELS %zu\n", c3->points.size());
-    for (size_t i = 0; i < c3->points.size(); i++)
-      std::printf("V %.9g %.9g %.9g %d\n", c3->points[i].x, c3->points[i].y, c3->points[i].z, cam3[i]);
+    // preprocessing as localizeHands runs it (on the GPU): print the cloud the search worked on
+    std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, false, false);
+    const PointCloud::Ptr& vox = loc.getSearchedCloud();
+    if (!vox)
+    {
+      std::printf("NO_CLOUD\n");
+      return 0;
+    }
+    std::printf("VOXELS %zu\n", vox->points.size());
+    for (size_t i = 0; i < vox->points.size(); i++)
+      std::printf("V %.9g %.9g %.9g %d\n", vox->points[i].x, vox->points[i].y, vox->points[i].z,
+        (int) loc.getSearchedCamSource()((int) i));
     return 0;
   }
   std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, false, false);

@@ -141,11 +141,28 @@ def _dump_raw(path, xyz, size_left, idx, ws, cams):
         f.write(np.asarray(idx, np.int32).tobytes())
 
 
-def test_localization_preprocessing_matches_restatement(tmp_path):
+def test_localization_fails_loudly_without_gpu(tmp_path):
+    import torch
+
+    exe = _build_loc(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    xyz, size_left, ws, cams = _raw_cloud()
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, [3], ws, cams)
+    out = subprocess.run([exe, path, "none", "voxels"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "NO_CLOUD" in out.stdout and "Error" in out.stdout  # no CPU preprocessing, no CPU search
+
+
+@pytest.mark.gpu
+def test_localization_preprocessing_matches_oracle(tmp_path):
+    from oracle import oracle_py as orc
+
     exe = _build_loc(tmp_path)
     xyz, size_left, ws, cams = _raw_cloud()
     path = str(tmp_path / "raw.bin")
-    _dump_raw(path, xyz, size_left, [], ws, cams)
+    _dump_raw(path, xyz, size_left, [3], ws, cams)
     out = subprocess.run([exe, path, "none", "voxels"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     rows = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("V ")]
@@ -154,6 +171,8 @@ def test_localization_preprocessing_matches_restatement(tmp_path):
     exp, exp_cam = _preprocess_numpy(xyz, size_left, ws)
     assert len(got) == len(exp) > 5000
     assert np.array_equal(got, exp) and np.array_equal(got_cam, exp_cam)
+    ov, ocam = orc.preprocess(xyz, size_left, ws)
+    assert np.array_equal(got, ov) and np.array_equal(got_cam, ocam)
 
 
 @pytest.mark.gpu
