@@ -1,0 +1,35 @@
+#!/bin/bash
+# Regenerates everything under profiles/ on the GPU box (one gpurun call):
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/refresh_profiles.sh'
+# then copy gpurun_out/profiles/* into profiles/.  Every step runs under `timeout`; rocprofv3 runs use --no-events
+# (HIP events inside a profiled process have hung before) and PMC counters are collected in their own passes.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+TAG=${TAG:-r01}
+for cfg in C2 C3; do
+  rm -rf /tmp/kt_$cfg
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$cfg -o kt -- python $R/bench.py --config $cfg --steps 50 --warmup 5 \
+    --no-events --no-cpu-baseline > /tmp/kt_$cfg.log 2>&1
+  db=$(find /tmp/kt_$cfg -name "*.db" | head -1)
+  [ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_$(echo $cfg | tr A-Z a-z)_kernel_trace_stats.csv > /dev/null
+done
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$ctr
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --config C2 --steps 10 --warmup 2 \
+    --no-events --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1
+done
+f=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
+[ -n "$f" ] && [ -n "$w" ] && python $R/scripts/pmc_traffic.py $f $w C2:det $OUT/pmc_traffic.json > /dev/null
+cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json 2>/dev/null   # bench.py reads roofline.traffic from here
+cd $R
+timeout 300 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> /dev/null
+timeout 300 python bench.py --config C3 > $OUT/${TAG}_bench_c3.json 2> /dev/null
+timeout 300 python bench.py --config C2 --normals rand50 --no-cpu-baseline > $OUT/${TAG}_bench_c2_rand50.json 2> /dev/null
+timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TAG}_bench_c4.json 2> /dev/null
+timeout 300 python scripts/preprocess_bench.py 2> /dev/null | grep raw_points > $OUT/${TAG}_preprocess.jsonl
+ls -la $OUT
+head -c 600 $OUT/${TAG}_bench_c2.json; echo
+head -8 $OUT/${TAG}_c2_kernel_trace_stats.csv
