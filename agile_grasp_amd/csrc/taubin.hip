@@ -297,90 +297,125 @@ __device__ __forceinline__ double shfl16(double v, int src_in_group, int gbase)
   return __shfl(v, gbase + src_in_group);
 }
 
+// Lane N of every 16-lane row to all lanes of that row: one DPP move per 32-bit half (row_newbcast, gfx90a+), no LDS
+// crossbar and no wait.  The 16-lane groups of k_taubin_eigen are exactly the DPP rows.
+template <int N>
+__device__ __forceinline__ double bcast16(double v)
+{
+  const long long x = __builtin_bit_cast(long long, v);
+  int lo = (int) x, hi = (int) (x >> 32);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + N, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + N, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long) hi << 32) | (long long) (unsigned) lo);
+}
+template <int N>
+__device__ __forceinline__ int bcast16(int v)
+{
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xf, 0xf, true);
+}
+
+// One round of the round-robin Jacobi sweep (oracle jacobi_rr9).  The wave runs it with all lanes enabled and without
+// a single divergent branch: the kernel is bound by the instructions one wave issues (one wave per SIMD, four samples
+// per wave), so conditional updates are selects and the broadcasts inside a group are DPP moves.
+template <int R, int K>
+struct RrPair  // pair K (1..4) of round R: rows (R + K) mod 9 and (R - K) mod 9, p < q
+{
+  static constexpr int a = (R + K) % 9, b = (R + 9 - K) % 9;
+  static constexpr int p = a < b ? a : b, q = a < b ? b : a;
+};
+
+template <int R, int K>
+__device__ __forceinline__ void rr_gather(const double (&ar)[9], int kk, double& apq, double& app, double& aqq)
+{
+  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
+  const double x_pq = bcast16<p>(ar[q]), x_pp = bcast16<p>(ar[p]), x_qq = bcast16<q>(ar[q]);
+  const bool mine = kk == K;
+  apq = mine ? x_pq : apq;
+  app = mine ? x_pp : app;
+  aqq = mine ? x_qq : aqq;
+}
+
+template <int R, int K>
+__device__ __forceinline__ void rr_columns(double (&ar)[9], double (&vr)[9], double c, double sn, int flag)
+{
+  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
+  const double ck = bcast16<p>(c), sk = bcast16<p>(sn);
+  const bool fk = bcast16<p>(flag) == 1;
+  const double akp = ar[p], akq = ar[q];
+  const double np_ = ck * akp - sk * akq, nq_ = sk * akp + ck * akq;
+  ar[p] = fk ? np_ : akp;
+  ar[q] = fk ? nq_ : akq;
+  const double vkp = vr[p], vkq = vr[q];
+  const double vp_ = ck * vkp - sk * vkq, vq_ = sk * vkp + ck * vkq;
+  vr[p] = fk ? vp_ : vkp;
+  vr[q] = fk ? vq_ : vkq;
+}
+
+template <int R, int K>
+__device__ __forceinline__ void rr_zero(double (&ar)[9], int kk, int gl, bool zero_it)
+{
+  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
+  const bool mine = zero_it && kk == K;
+  ar[q] = (mine && gl == p) ? 0.0 : ar[q];
+  ar[p] = (mine && gl == q) ? 0.0 : ar[p];
+}
+
 template <int R>
 __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], int gl, int gbase, bool row, bool active,
   int sweep)
 {
-  // (1) every lane fetches (a_pq, a_pp, a_qq) of the four pairs from the lanes that own them, then keeps its own pair's
-  double apq = 0.0, app = 0.0, aqq = 0.0;
+  // lane roles in round R: pair id kk (1..4, 0: sits out / idle lane), the pair's other row, and which of the two
   const int dd = row ? (gl - R + 9) % 9 : 0;
-  const int kk = dd <= 4 ? dd : 9 - dd;  // pair id 1..4 of this lane, 0: sits out / idle lane
-#pragma unroll
-  for (int k = 1; k <= 4; k++)
-  {
-    constexpr int unused = 0;
-    (void) unused;
-    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
-    const int p = a < b ? a : b, q = a < b ? b : a;
-    const double x_pq = shfl16(ar[q], p, gbase), x_pp = shfl16(ar[p], p, gbase), x_qq = shfl16(ar[q], q, gbase);
-    if (kk == k)
-    {
-      apq = x_pq;
-      app = x_pp;
-      aqq = x_qq;
-    }
-  }
-  // (2) rotation parameters of this lane's pair (both lanes of a pair compute the same values)
-  double c = 1.0, sn = 0.0;
-  int flag = 0;  // 1 rotate, 2 zero only
-  if (active && kk != 0 && apq != 0.0)
-  {
-    const double aabs = fabs(apq);
-    if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
-      flag = 2;
-    else
-    {
-      const double theta = (aqq - app) / (2.0 * apq);
-      double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-      if (theta < 0.0)
-        t = -t;
-      c = 1.0 / sqrt(t * t + 1.0);
-      sn = t * c;
-      flag = 1;
-    }
-  }
-  // (3) column phase A <- A J, V <- V J: this lane's row, all four pairs (parameters come from the pair's first lane)
-#pragma unroll
-  for (int k = 1; k <= 4; k++)
-  {
-    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
-    const int p = a < b ? a : b, q = a < b ? b : a;
-    const double ck = shfl16(c, p, gbase), sk = shfl16(sn, p, gbase);
-    const int fk = __shfl(flag, gbase + p);
-    if (fk == 1)
-    {
-      const double akp = ar[p], akq = ar[q];
-      ar[p] = ck * akp - sk * akq;
-      ar[q] = sk * akp + ck * akq;
-      const double vkp = vr[p], vkq = vr[q];
-      vr[p] = ck * vkp - sk * vkq;
-      vr[q] = sk * vkp + ck * vkq;
-    }
-  }
-  // (4) row phase A <- J^T A: rows p and q of a pair are the two lanes of the pair; each fetches its mate's row
+  const int kk = dd <= 4 ? dd : 9 - dd;
   const int mate = (kk != 0) ? (2 * R - gl + 18) % 9 : gl;
   const bool is_p = gl < mate;
+  // (1) (a_pq, a_pp, a_qq) of this lane's pair, read from the lane that owns row p (upper triangle) / row q
+  double apq = 0.0, app = 0.0, aqq = 0.0;
+  rr_gather<R, 1>(ar, kk, apq, app, aqq);
+  rr_gather<R, 2>(ar, kk, apq, app, aqq);
+  rr_gather<R, 3>(ar, kk, apq, app, aqq);
+  rr_gather<R, 4>(ar, kk, apq, app, aqq);
+  // (2) rotation parameters (both lanes of a pair compute the same values); lanes without a rotation get the
+  //     identity and never use it
+  const double aabs = fabs(apq);
+  const bool cand = active && kk != 0 && apq != 0.0;
+  const bool negligible = sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq));
+  // oracle jacobi_rr9: h = sqrt(alpha^2 + beta^2), d = |alpha| + h, r = sqrt(d^2 + beta^2), c = d / r,
+  // s = sgn |beta| / r
+  const double alpha = aqq - app, beta = 2.0 * apq;
+  const double h = sqrt(alpha * alpha + beta * beta);
+  const double dsum = fabs(alpha) + h;
+  const double rr = sqrt(dsum * dsum + beta * beta);
+  const bool rot = cand && !negligible && rr > 0.0;
+  const bool neg = (alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0);
+  const double rsafe = rot ? rr : 1.0;
+  const double sb = fabs(beta) / rsafe;
+  const double c = rot ? dsum / rsafe : 1.0;
+  const double sn = rot ? (neg ? -sb : sb) : 0.0;
+  const int flag = rot ? 1 : (cand ? 2 : 0);  // 1 rotate, 2 zero only
+  // (3) column phase A <- A J, V <- V J: this lane's row, all four pairs (parameters from the pair's first lane)
+  rr_columns<R, 1>(ar, vr, c, sn, flag);
+  rr_columns<R, 2>(ar, vr, c, sn, flag);
+  rr_columns<R, 3>(ar, vr, c, sn, flag);
+  rr_columns<R, 4>(ar, vr, c, sn, flag);
+  // (4) row phase A <- J^T A: rows p and q of a pair are the two lanes of the pair; each fetches its mate's row.
+  //     Row p: c a_p - s a_q; row q: s a_p + c a_q = c a_q - (-s) a_p (IEEE addition commutes).
+  const double se = is_p ? sn : -sn;
+  const bool rot_row = flag == 1;
 #pragma unroll
   for (int j = 0; j < 9; j++)
   {
-    const double other = shfl16(ar[j], mate, gbase);
-    if (flag == 1)
-      ar[j] = is_p ? (c * ar[j] - sn * other) : (sn * other + c * ar[j]);
+    const double own = ar[j];
+    const double other = shfl16(own, mate, gbase);
+    const double nv = c * own - se * other;
+    ar[j] = rot_row ? nv : own;
   }
   // (5) the rotated entries are exactly zero (both triangles)
-#pragma unroll
-  for (int k = 1; k <= 4; k++)
-  {
-    const int a = (R + k) % 9, b = (R + 9 - k) % 9;
-    const int p = a < b ? a : b, q = a < b ? b : a;
-    if (kk == k && flag != 0)
-    {
-      if (gl == p)
-        ar[q] = 0.0;
-      else
-        ar[p] = 0.0;
-    }
-  }
+  const bool zero_it = flag != 0;
+  rr_zero<R, 1>(ar, kk, gl, zero_it);
+  rr_zero<R, 2>(ar, kk, gl, zero_it);
+  rr_zero<R, 3>(ar, kk, gl, zero_it);
+  rr_zero<R, 4>(ar, kk, gl, zero_it);
 }
 
 struct EigSmem

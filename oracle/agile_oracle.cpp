@@ -318,13 +318,25 @@ void jacobi_rr9(double A[9][9], double V[9][9], double d[9])
           zero[k - 1] = true;
           continue;
         }
-        const double theta = (aqq - app) / (2.0 * apq);
-        double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        if (theta < 0.0)
-          t = -t;
-        const double c = 1.0 / std::sqrt(t * t + 1.0);
-        C[k - 1] = c;
-        S[k - 1] = t * c;
+        /* The classical parameters theta = alpha / beta, t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)),
+         * c = 1 / sqrt(t^2 + 1), s = t c, written without the three chained divisions (same values in exact
+         * arithmetic, no cancellation: every sum is a sum of non-negative terms):
+         *   h = sqrt(alpha^2 + beta^2), d = |alpha| + h, r = sqrt(d^2 + beta^2), c = d / r, s = sgn |beta| / r.
+         * The dependent chain is sqrt, sqrt, div instead of div, sqrt, div, sqrt, div -- it is the critical path of
+         * the GPU kernel (one 16-lane group per sample). */
+        const double alpha = aqq - app, beta = 2.0 * apq;
+        const double h = std::sqrt(alpha * alpha + beta * beta);
+        const double dd = std::fabs(alpha) + h;
+        const double rr = std::sqrt(dd * dd + beta * beta);
+        if (!(rr > 0.0))  /* alpha^2 and beta^2 both underflowed: treat the entry as negligible */
+        {
+          zero[k - 1] = true;
+          continue;
+        }
+        const bool neg = (alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0);  /* theta < 0 */
+        const double sb = std::fabs(beta) / rr;
+        C[k - 1] = dd / rr;
+        S[k - 1] = neg ? -sb : sb;
         rot[k - 1] = true;
       }
       for (int m = 0; m < 4; m++)  /* columns: A <- A J, V <- V J */
