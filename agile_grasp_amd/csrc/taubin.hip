@@ -940,30 +940,26 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   // ---- wave 0 (the other waves go straight to the exact column sums below): M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
   if (wave == 0)
   {
-    if (lane < 6)
-    {
-      const int r = (lane < 3) ? 0 : (lane < 5 ? 1 : 2);
-      const int q = (lane < 3) ? lane : (lane < 5 ? lane - 2 : 2);
-      const double* pr = (r == 0) ? nx : (r == 1 ? ny : nz);
-      const double* pq = (q == 0) ? nx : (q == 1 ? ny : nz);
-      double acc = 0.0;
-      int t = (debug_stop == 5 || debug_stop == 7) ? ks : 0;
-      for (; t + 8 <= ks; t += 8)  // loads of 8 neighbours in flight; the adds stay in index order
+    // M3 in the oracle's LaneSum64 order: lane l owns partial l (terms l, l + 64, ...), butterfly tree at the end
+    double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    if (!(debug_stop == 5 || debug_stop == 7))
+      for (int t = lane; t < ks; t += 64)
       {
-        double a_[8], b_[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-        {
-          a_[u] = pr[t + u];
-          b_[u] = pq[t + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          acc += a_[u] * b_[u];
+        const double x = nx[t], y = ny[t], z = nz[t];
+        m[0] += x * x;
+        m[1] += x * y;
+        m[2] += x * z;
+        m[3] += y * y;
+        m[4] += y * z;
+        m[5] += z * z;
       }
-      for (; t < ks; t++)
-        acc += pr[t] * pq[t];
-      sM3[lane] = acc;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+    {
+      for (int o = 32; o > 0; o >>= 1)
+        m[k] = m[k] + __shfl_xor(m[k], o);
+      if (lane == 0)
+        sM3[k] = m[k];
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -991,99 +987,33 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   }
   if (debug_stop == 3)
     return;
-  // exact sequential sums of the candidate columns
+  // exact sums of the candidate columns in the oracle's LaneSum64 order, one candidate per wave at a time: lane l adds
+  // the terms l, l + 64, ... and a butterfly combines the 64 partials (every lane ends with the same total)
   double best = -1.0;
   int best_j = 0x7fffffff;
-  if (ncnd <= 16)
+  for (;;)
   {
-    // Few candidates (the usual case: 1-3): one candidate per wave at a time.  The 64 lanes form 64 terms
-    // (n_t . n_j)^6 at once; the reference's left-to-right sum is then a chain of adds over the lanes' values
-    // (v_readlane -> scalar operand), i.e. ~one dependent fp64 add per neighbour instead of the whole 9-flop term.
-    for (;;)
+    int c = 0;
+    if (lane == 0)
+      c = atomicAdd(&next_col, 1);
+    c = __shfl(c, 0);
+    if (c >= ncnd)
+      break;
+    const int j = cand[c];
+    const double jx = nx[j], jy = ny[j], jz = nz[j];
+    double acc = 0.0;
+    for (int t = lane; t < ks; t += 64)
     {
-      int c = 0;
-      if (lane == 0)
-        c = atomicAdd(&next_col, 1);
-      c = __shfl(c, 0);
-      if (c >= ncnd)
-        break;
-      const int j = cand[c];
-      const double jx = nx[j], jy = ny[j], jz = nz[j];
-      double acc = 0.0;
-      for (int t0 = 0; t0 < ks; t0 += 64)
-      {
-        const int t = t0 + lane;
-        double g6 = 0.0;
-        if (t < ks)
-        {
-          const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
-          const double g2 = gdot * gdot;
-          g6 = (g2 * g2) * g2;
-        }
-        const int lo = __double2loint(g6), hi = __double2hiint(g6);
-        const int cnt = min(64, ks - t0);
-        if (cnt == 64)
-        {
-#pragma unroll
-          for (int l = 0; l < 64; l++)
-            acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
-        }
-        else
-        {
-#pragma unroll
-          for (int l = 0; l < 64; l++)
-            if (l < cnt)
-              acc += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
-        }
-      }
-      if (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff)
-      {
-        best = acc;
-        best_j = j;
-      }
+      const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
+      const double g2 = gdot * gdot;
+      acc += (g2 * g2) * g2;
     }
-  }
-  else
-  {
-    // many candidates (near-degenerate normals): 64 columns per grab, one column per lane
-    for (;;)
+    for (int o = 32; o > 0; o >>= 1)
+      acc = acc + __shfl_xor(acc, o);
+    if (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff)
     {
-      int c0 = 0;
-      if (lane == 0)
-        c0 = atomicAdd(&next_col, 64);
-      c0 = __shfl(c0, 0);
-      if (c0 >= ncnd)
-        break;
-      const bool have = c0 + lane < ncnd;
-      const int j = have ? (int) cand[c0 + lane] : 0;
-      const double jx = have ? nx[j] : 0.0, jy = have ? ny[j] : 0.0, jz = have ? nz[j] : 0.0;
-      double acc = 0.0;
-      int t = 0;
-      for (; t + 4 <= ks; t += 4)
-      {
-        double g6[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-        {
-          const double gdot = (nx[t + u] * jx + ny[t + u] * jy) + nz[t + u] * jz;
-          const double g2 = gdot * gdot;
-          g6[u] = (g2 * g2) * g2;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          acc += g6[u];
-      }
-      for (; t < ks; t++)
-      {
-        const double gdot = (nx[t] * jx + ny[t] * jy) + nz[t] * jz;
-        const double g2 = gdot * gdot;
-        acc += (g2 * g2) * g2;
-      }
-      if (have && (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff))
-      {
-        best = acc;
-        best_j = j;
-      }
+      best = acc;
+      best_j = j;
     }
   }
   if (debug_stop == 4)

@@ -206,6 +206,30 @@ struct GlibcRand
 };
 
 /* ---------------------------------------------------------------------------------------------------
+ * The summation order of the two sums whose order the reference leaves to Eigen (see fit_frame): 64 interleaved
+ * partial sums, term i into partial i mod 64 in index order, then a balanced binary tree
+ * (P[l] += P[l + o] for l < o, o = 32, 16, 8, 4, 2, 1).  On the GPU this is one wavefront: lane l owns partial l and
+ * the tree is a butterfly of cross-lane adds.
+ * ------------------------------------------------------------------------------------------------- */
+struct LaneSum64
+{
+  double p[64];
+  LaneSum64()
+  {
+    for (int l = 0; l < 64; l++)
+      p[l] = 0.0;
+  }
+  void add(int i, double v) { p[i & 63] += v; }
+  double total()
+  {
+    for (int o = 32; o > 0; o >>= 1)
+      for (int l = 0; l < o; l++)
+        p[l] = p[l] + p[l + o];
+    return p[0];
+  }
+};
+
+/* ---------------------------------------------------------------------------------------------------
  * Cyclic Jacobi for a small symmetric matrix (row-major n x n).  Stands in for LAPACK dggev's QZ
  * (quadric.cpp:330-363, after the reduction below) and for Eigen::EigenSolver on the symmetric 3x3
  * (quadric.cpp:268-270).  d[j] = eigenvalue, column j of V = eigenvector.
@@ -650,11 +674,21 @@ void fit_frame(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>
   }
 
   /* findAverageNormalAxis (quadric.cpp:263-305) */
-  double M3[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
-  for (int t = 0; t < k_s; t++)
-    for (int r = 0; r < 3; r++)
-      for (int q = 0; q < 3; q++)
-        M3[r][q] += nrm[3 * t + r] * nrm[3 * t + q];
+  /* M = normals * normals^T (quadric.cpp:266) is an Eigen matrix product and the column sums below are an Eigen
+   * colwise().sum(): the ORDER in which their n terms are added is Eigen's (GEMM blocking, packet width and FMA use
+   * depend on the Eigen version and the build flags), not something the reference's source pins.  Both are DEFINED
+   * here as LaneSum64: term i is added to partial i mod 64 (each partial accumulates in index order), and the 64
+   * partials are combined by a balanced binary tree. */
+  double M3[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int q = r; q < 3; q++)
+    {
+      LaneSum64 acc;
+      for (int t = 0; t < k_s; t++)
+        acc.add(t, nrm[3 * t + r] * nrm[3 * t + q]);
+      M3[r][q] = acc.total();
+      M3[q][r] = M3[r][q];
+    }
   double V3[3][3], d3[3];
   jacobi_sym<3>(M3, V3, d3);
   int mi = 0;
@@ -668,9 +702,10 @@ void fit_frame(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>
   double best = 0.0;
   for (int j = 0; j < k_s; j++)
   {
-    double s = 0.0;
+    LaneSum64 acc;
     for (int i = 0; i < k_s; i++)
-      s += pow6(dot3(&nrm[3 * i], &nrm[3 * j]), P.pow6_libm);
+      acc.add(i, pow6(dot3(&nrm[3 * i], &nrm[3 * j]), P.pow6_libm));
+    const double s = acc.total();
     if (j == 0 || s > best)
     {
       best = s;
