@@ -194,32 +194,28 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     cur_r = wave;
     cur_i = 0;
   };
-  // returns false if the tile is full (nothing was appended, the candidates must be offered again)
-  auto consume1 = [&](const float4& p, bool have, bool count_ball) -> bool {
-    bool keep = false, inball = false;
-    double tx = 0.0, ty = 0.0;
-    unsigned w = 0;
-    if (have)
+  // Filters two candidates per lane (a 128-candidate row segment per wave) and appends the survivors with ONE
+  // reservation; returns false if the tile is full (nothing was appended, the segment must be offered again).
+  // Straight-line code: the kernel is bound by the instructions a wave issues, and exec-mask juggling around the
+  // ~1/8 of the lanes that survive costs more than computing the hand-frame coordinates for all of them.
+  auto classify1 = [&](const float4& p, bool have, bool& inball, bool& keep, double& tx, double& ty) {
+    const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
+    inball = have && d2 < r2f;
+    const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
+    const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
+    keep = inball && (tz > -1.0 * hh) && (tz < hh);
+    tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
+    ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
+  };
+  auto consume2 = [&](const float4& p0, bool h0, const float4& p1, bool h1, bool count_ball) -> bool {
+    bool in0, in1, k0, k1;
+    double tx0, ty0, tx1, ty1;
+    classify1(p0, h0, in0, k0, tx0, ty0);
+    classify1(p1, h1, in1, k1, tx1, ty1);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    if (m0 | m1)
     {
-      const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
-      if (d2 < r2f)
-      {
-        inball = true;
-        const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
-        const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
-        keep = (tz > -1.0 * hh) && (tz < hh);
-        if (keep)  // only ~1/4 of the ball survives the crop: the other two rows of frame^T are computed for those
-        {
-          tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
-          ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
-          w = __float_as_uint(p.w);
-        }
-      }
-    }
-    const unsigned long long mk = __ballot(keep);
-    if (mk)
-    {
-      const int cnt = __popcll(mk);
+      const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);
       int base = 0;
       if (lane == 0)
       {
@@ -232,50 +228,82 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
           base = -1;
         }
       }
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);
       if (base < 0)
         return false;
-      if (keep)
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (k0)
       {
-        const int k = base + __popcll(mk & ((1ull << lane) - 1ull));
-        pts[k] = make_double2(tx, ty);
+        const int k = base + __popcll(m0 & below);
+        pts[k] = make_double2(tx0, ty0);
         if (NORMALS)
-          pid[k] = w;
+          pid[k] = __float_as_uint(p0.w);
+      }
+      if (k1)
+      {
+        const int k = base + c0 + __popcll(m1 & below);
+        pts[k] = make_double2(tx1, ty1);
+        if (NORMALS)
+          pid[k] = __float_as_uint(p1.w);
       }
     }
-    nball += (count_ball && inball) ? 1 : 0;
+    nball += count_ball ? ((in0 ? 1 : 0) + (in1 ? 1 : 0)) : 0;
     return true;
   };
   // Fills the tile from the cursors on; returns the tile's point count and whether every wave reached the end.
   // Must be entered with cnt_crop == 0 made visible by a barrier.
+  // The walk is software-pipelined: the loads of the NEXT 128 candidates are issued before the current 128 are
+  // filtered, so a wave always has two row segments in flight (the gather is bound by L2 latency, not by bandwidth).
+  auto seg_normalize = [&](int& r, int& i, int& rb, int& len) {  // skip exhausted / empty rows
+    for (;;)
+    {
+      if (r >= nrows)
+      {
+        len = 0;
+        rb = 0;
+        return;
+      }
+      rb = rt.begin[r];
+      len = rt.prefix[r + 1] - rt.prefix[r];
+      if (i < len)
+        return;
+      r += 4;
+      i = 0;
+    }
+  };
+  auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
+    h0 = r < nrows && i + lane < len;
+    h1 = r < nrows && i + 64 + lane < len;
+    // unconditional loads (a lane without a candidate reads element 0 and ignores it): a load under a branch would
+    // be waited for at the join, which is exactly the latency the pipeline is there to hide
+    p0 = gv.sorted[h0 ? rb + i + lane : 0];
+    p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
+  };
   auto gather_tile = [&](bool count_ball, bool& all_done) -> int {
     bool full = false;
+    int rb = 0, len = 0;
+    seg_normalize(cur_r, cur_i, rb, len);
+    float4 p0, p1;
+    bool h0, h1;
+    seg_load(cur_r, cur_i, rb, len, p0, p1, h0, h1);
     while (cur_r < nrows && !full)
     {
-      const int rb = rt.begin[cur_r];
-      const int len = rt.prefix[cur_r + 1] - rt.prefix[cur_r];
-      if (cur_i < len)
+      int nr = cur_r, ni = cur_i + 128, nrb = 0, nlen = 0;
+      seg_normalize(nr, ni, nrb, nlen);
+      float4 q0, q1;
+      bool g0, g1;
+      seg_load(nr, ni, nrb, nlen, q0, q1, g0, g1);  // in flight while the current segment is consumed
+      if (!consume2(p0, h0, p1, h1, count_ball))
+        full = true;
+      else
       {
-        const bool h0 = cur_i + lane < len, h1 = cur_i + 64 + lane < len;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-        if (h0)
-          p0 = gv.sorted[rb + cur_i + lane];
-        if (h1)
-          p1 = gv.sorted[rb + cur_i + 64 + lane];
-        if (!consume1(p0, h0, count_ball))
-          full = true;
-        else if (cur_i + 64 < len && !consume1(p1, h1, count_ball))
-        {
-          full = true;
-          cur_i += 64;
-        }
-        else
-          cur_i += 128;
-      }
-      if (!full && cur_i >= len)
-      {
-        cur_r += 4;
-        cur_i = 0;
+        cur_r = nr;
+        cur_i = ni;
+        len = nlen;
+        p0 = q0;
+        p1 = q1;
+        h0 = g0;
+        h1 = g1;
       }
     }
     if (lane == 0 && cur_r < nrows)

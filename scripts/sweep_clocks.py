@@ -35,3 +35,15 @@ print("ball>7000:", big.sum(), "passA mean", pa[big].mean() if big.any() else 0,
 print("corr(ball, passA)", np.corrcoef(ball, pa)[0, 1])
 slow = pa > 5000
 print("slow passA count", slow.sum(), "their ball mean", ball[slow].mean(), "min", ball[slow].min())
+# schedule view: when do work-groups start and end relative to the kernel (ticks of 10 ns)
+t0 = t[:, 0].min()
+start, end = t[:, 0] - t0, t[:, 6] - t0
+span = end.max()
+print("kernel span us", span / 100.0)
+for q in (0.5, 0.75, 0.9, 0.95, 0.99, 1.0):
+    print("  fraction of WGs finished by q", q, "->", np.quantile(end, q) / 100.0, "us")
+last = np.argsort(end)[-8:]
+for i in last:
+    print("  late WG", i, "start", start[i] / 100.0, "end", end[i] / 100.0, "dur", (end[i] - start[i]) / 100.0, "ball", ball[i])
+busy = (end - start).sum() / 100.0
+print("sum of WG durations us", busy, "-> /768 slots =", busy / 768.0, "us (perfect packing)")
