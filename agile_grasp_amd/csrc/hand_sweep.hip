@@ -66,7 +66,8 @@ template <bool NORMALS>
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
-  int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg)
+  int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
+  const int* __restrict__ order)
 {
   constexpr int kTile = NORMALS ? 1728 : 2176;  // the block must stay under a third of the CU's 160 KiB (512-B granules)
   __shared__ double2 pts[kTile];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   __shared__ unsigned img[8][kImageWords + 2];
   __shared__ int cnt_ball, cnt_crop, any_hand, pending, tile_end;
 
-  const int s = blockIdx.x;
+  const int s = order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
   AGH_STAMP(0);
@@ -771,12 +772,15 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const int Si = (int) S;
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
+  // blockIdx -> sample goes through c->d_order (longest first; computed by k_taubin_eigen's sorter work-group)
   if (nrm)
     hipLaunchKernelGGL(k_hand_sweep<true>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
+      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
+      (const int*) c->d_order);
   else
     hipLaunchKernelGGL(k_hand_sweep<false>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg);
+      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
+      (const int*) c->d_order);
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

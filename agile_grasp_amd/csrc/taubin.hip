@@ -33,7 +33,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points)
+  int n_points, double rpad_w, int* __restrict__ weight)
 {
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
@@ -62,11 +62,34 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     {
       status[s] = kStatusBadIndex;
       nt[s] = 0;
+      if (first_class)
+        weight[s] = 0;
     }
     return;
   }
   const float* qp = xyz + (int64_t) samples[s] * stride;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
+  // Scheduling weight of the sample for the kernels that follow (see k_taubin_eigen's sorter block): the candidate
+  // count of its hand-search ball, i.e. the row total k_hand_sweep's gather will walk.  One wave, <= 128 rows.
+  if (first_class && wave == 3)
+  {
+    const GridDesc& g = *gv.desc;
+    const int lx = cell_coord(g, (double) qx - rpad_w, 0), hx = cell_coord(g, (double) qx + rpad_w, 0);
+    const int ly = cell_coord(g, (double) qy - rpad_w, 1), hy = cell_coord(g, (double) qy + rpad_w, 1);
+    const int lz = cell_coord(g, (double) qz - rpad_w, 2), hz = cell_coord(g, (double) qz + rpad_w, 2);
+    const int ny = hy - ly + 1, nrw = ny * (hz - lz + 1);
+    int w = 0;
+    for (int t = lane; t < nrw && t < kMaxRows; t += 64)
+    {
+      const int cy = ly + t % ny, cz = lz + t / ny;
+      const int base = (cz * g.dim[1] + cy) * g.dim[0];
+      w += gv.cell_start[base + hx + 1] - gv.cell_start[base + lx];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+      w += __shfl_xor(w, o);
+    if (lane == 0)
+      weight[s] = w;
+  }
   if (tid == 0)
     count = 0;
   for (int k = tid; k < kSortBins; k += 256)
@@ -432,12 +455,68 @@ struct EigSmem
   int fail;
 };
 
+// Longest-first scheduling of k_taubin_frame and k_hand_sweep: a sample's cost grows with its neighbourhood and the
+// samples arrive sorted by index, i.e. spatially coherent, so dense regions form runs of slow work-groups and a run
+// that starts late is a long tail.  Work-groups are dispatched in blockIdx order; `order` maps blockIdx -> sample by
+// descending weight (counting sort, 2048 bins of 16 candidates).  It is computed by ONE EXTRA work-group of this
+// kernel: k_taubin_eigen leaves half the SIMDs idle, so the sort costs no time and no launch.  Results go to per-sample
+// slots, so the processing order (and the arbitrary order inside a bin) is invisible in the output.
+constexpr int kOrderBins = 2048;
+__device__ __forceinline__ int order_bin(int w) { return kOrderBins - 1 - min(w >> 4, kOrderBins - 1); }  // 0 = heaviest
+
+__device__ void sample_order_block(const int* __restrict__ weight, int S, int* __restrict__ order, int* hist)
+{
+  const int lane = threadIdx.x;  // 64 threads
+  for (int b = lane; b < kOrderBins; b += 64)
+    hist[b] = 0;
+  __syncthreads();
+  for (int s = lane; s < S; s += 64)
+    atomicAdd(&hist[order_bin(weight[s])], 1);
+  __syncthreads();
+  constexpr int per = kOrderBins / 64;  // consecutive bins per lane
+  int loc = 0;
+  for (int k = 0; k < per; k++)
+    loc += hist[lane * per + k];
+  int incl = loc;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int y = __shfl_up(incl, o);
+    if (lane >= o)
+      incl += y;
+  }
+  int run = incl - loc;
+  for (int k = 0; k < per; k++)
+  {
+    const int c = hist[lane * per + k];
+    hist[lane * per + k] = run;
+    run += c;
+  }
+  __syncthreads();
+  for (int s = lane; s < S; s += 64)
+    order[atomicAdd(&hist[order_bin(weight[s])], 1)] = s;
+}
+
 __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
-  const int32_t* __restrict__ status, int S, double* __restrict__ eig)
+  const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
+  const int* __restrict__ weight, int* __restrict__ order)
 {
   __shared__ EigSmem sm[4];
+  __shared__ int order_hist[kOrderBins];
+  if (blockIdx.x == gridDim.x - 1)  // the extra work-group: scheduling order of the following kernels
+  {
+    sample_order_block(weight, S, order, order_hist);
+    return;
+  }
   const int lane = threadIdx.x, gl = lane & 15, grp = lane >> 4;
   const int s = blockIdx.x * 4 + grp;
+  if (gl == 0 && s < S)  // loud capacity / index errors (read back by agh_synchronize and the host entry points)
+  {
+    const int st_ = status[s];
+    if (st_ == kStatusOverflow || st_ == kStatusRows)
+      atomicOr(&flags[0], 1);
+    if (st_ == kStatusBadIndex)
+      atomicOr(&flags[0], 4);
+  }
   const bool live = s < S && status[s] == kStatusOk;
   EigSmem& E = sm[grp];
   const double n = live ? (double) nt[s] : 1.0;
@@ -743,7 +822,8 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
-  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop)
+  double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop,
+  const int* __restrict__ order)
 {
   __shared__ double nx[CAP], ny[CAP], nz[CAP];
   __shared__ int camcnt[2];
@@ -757,7 +837,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   __shared__ unsigned short cand[CAP];
   __shared__ int ncand;
 
-  const int s = blockIdx.x;
+  const int s = order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nt[s];
   const double* ev = eig + (int64_t) s * 12;
@@ -1130,15 +1210,6 @@ __global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* _
     *total_io = carry;
 }
 
-__global__ void k_flag_overflow(const int32_t* __restrict__ status, int S, int32_t* __restrict__ flags)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < S && (status[i] == kStatusOverflow || status[i] == kStatusRows))
-    atomicOr(&flags[0], 1);
-  if (i < S && status[i] == kStatusBadIndex)
-    atomicOr(&flags[0], 4);
-}
-
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st)
 {
@@ -1147,6 +1218,7 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
   const float r2f = static_cast<float>(radius * radius);  // pcl::KdTreeFLANN::radiusSearch squares in double, casts
   const double rpad = radius * 1.0001 + 1e-6;
+  const double rpad_w = c->p.nn_radius_hands * 1.0001 + 1e-6;  // scheduling weight = candidates of the hand-search ball
   const int Si = (int) S;
   // capacity classes: smallest first; later classes only touch samples flagged kStatusOverflow
   const bool small_first = radius <= 0.015;
@@ -1154,18 +1226,18 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
     first = false;
   }
   hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
+    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n);
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
-  hipLaunchKernelGGL(k_flag_overflow, dim3((Si + 255) / 256), dim3(256), 0, st, c->d_status, Si, c->d_flags);
-  hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig);
+  hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4 + 1), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+    c->d_flags, (const int*) c->d_weight, c->d_order);
   timing_mark(c, "taubin_eigen", st);
   const int rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50 ? 1 : 0;
   if (rand_mode)
@@ -1175,10 +1247,10 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   // only does work for the samples that need it
   hipLaunchKernelGGL(k_taubin_frame<1280>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame, (const int*) c->d_order);
   hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
     c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1280, c->debug_stop_frame);
+    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1280, c->debug_stop_frame, (const int*) c->d_order);
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
