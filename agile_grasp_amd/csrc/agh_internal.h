@@ -148,6 +148,7 @@ struct Ctx
   int32_t* d_nh = nullptr;         // n_hands
   int32_t* d_status = nullptr;
   int* d_weight = nullptr;         // candidate count of each sample's hand-search ball (scheduling weight)
+  uint8_t* d_vmask = nullptr;      // per sample: orientations with a hypothesis (k_hand_sweep -> concatenation)
   int* d_order = nullptr;          // samples by descending weight: blockIdx -> sample of k_hand_sweep
   float4* d_nbr = nullptr;         // s_cap * nbr_stride sorted neighbour lists
   int64_t nbr_stride = 0;

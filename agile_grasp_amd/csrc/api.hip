@@ -184,7 +184,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_nh, cap)))
     return rc;
-  if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)))
+  if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)) || (rc = dev_alloc(c, &c->d_vmask, cap)))
     return rc;
   c->nbr_stride = 4096;
   if ((rc = dev_alloc(c, &c->d_nbr, cap * c->nbr_stride)))
@@ -199,7 +199,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_slot_index, cap * 8)))
     return rc;
-  if ((rc = dev_alloc(c, &c->d_scan_tmp, (cap * 8 + 1023) / 1024 + 1)))
+  if ((rc = dev_alloc(c, &c->d_scan_tmp, cap + 1024)  /* block sums of the 3-kernel scan or one offset per sample */))
     return rc;
   if ((rc = dev_alloc(c, &c->d_out_own, cap * 8)))
     return rc;
@@ -393,7 +393,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
-    c->d_weight, c->d_order, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_weight, c->d_order, c->d_vmask, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
-  const int* __restrict__ order)
+  const int* __restrict__ order, uint8_t* __restrict__ vmask)
 {
   constexpr int kTile = NORMALS ? 1728 : 2176;  // the block must stay under a third of the CU's 160 KiB (512-B granules)
   __shared__ double2 pts[kTile];
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     {
       nh[s] = 0;
       status[s] = kStatusDegenerate;
+      vmask[s] = 0;
     }
     return;
   }
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     {
       status[s] = kStatusRows;
       nh[s] = 0;
+      vmask[s] = 0;
     }
     return;
   }
@@ -658,6 +660,10 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   {
     nh[s] = cnt_ball;
     status[s] = kStatusOk;
+    unsigned m = 0;  // orientations that produced a hypothesis: what the concatenation kernel scans
+    for (int o = 0; o < 8; o++)
+      m |= (!ori[o].rejected && ori[o].has_hand) ? (1u << o) : 0u;
+    vmask[s] = (uint8_t) m;
     if (dbg)
     {
       dbg[(int64_t) s * 8 + 6] = wall_clock64();
@@ -760,6 +766,68 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
     }
 }
 
+// K4 in two launches for S <= 65536: the sweep leaves an 8-bit mask of the orientations with a hypothesis per sample;
+// one work-group scans the S popcounts (output offset of every sample, total count), then 10 threads copy each record
+// (16 bytes per thread, coalesced).
+__global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restrict__ vmask, int S, int* __restrict__ offs,
+  int64_t* __restrict__ n_out)
+{
+  __shared__ int ws[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per = (S + 1023) / 1024;
+  const int s0 = min(tid * per, S), s1 = min(s0 + per, S);
+  int cnt = 0;
+  for (int s = s0; s < s1; s++)
+    cnt += __popc((unsigned) vmask[s]);
+  int inc = cnt;
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o)
+      inc += t;
+  }
+  if (lane == 63)
+    ws[w] = inc;
+  __syncthreads();
+  int pos = inc - cnt, total = 0;
+  for (int k = 0; k < 16; k++)
+  {
+    pos += k < w ? ws[k] : 0;
+    total += ws[k];
+  }
+  if (tid == 0)
+    *n_out = total;
+  for (int s = s0; s < s1; s++)
+  {
+    offs[s] = pos;
+    pos += __popc((unsigned) vmask[s]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __restrict__ slots,
+  const uint8_t* __restrict__ vmask, const int* __restrict__ offs, int n_slots, agh_hypothesis* __restrict__ out,
+  int64_t cap, int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags)
+{
+  static_assert(sizeof(agh_hypothesis) == 160, "10 x 16 bytes per record");
+  const int slot = blockIdx.x * 25 + threadIdx.x / 10, part = threadIdx.x % 10;
+  if (threadIdx.x >= 250 || slot >= n_slots)
+    return;
+  const int s = slot >> 3, o = slot & 7;
+  const unsigned m = vmask[s];
+  if (!((m >> o) & 1u))
+    return;
+  const int64_t pos = offs[s] + __popc(m & ((1u << o) - 1u));
+  if (pos >= cap)
+  {
+    if (part == 0)
+      atomicOr(&flags[0], 2);
+    return;
+  }
+  reinterpret_cast<uint4*>(out + pos)[part] = reinterpret_cast<const uint4*>(slots + slot)[part];
+  if (part == 0)
+    slot_of_hyp[pos] = slot;
+}
+
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st)
 {
   if (S == 0)
@@ -776,11 +844,11 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   if (nrm)
     hipLaunchKernelGGL(k_hand_sweep<true>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
       rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
-      (const int*) c->d_order);
+      (const int*) c->d_order, c->d_vmask);
   else
     hipLaunchKernelGGL(k_hand_sweep<false>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
       rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
-      (const int*) c->d_order);
+      (const int*) c->d_order, c->d_vmask);
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
@@ -794,10 +862,20 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
     hipMemsetAsync(d_nout, 0, sizeof(int64_t), st);
     return AGH_OK;
   }
-  hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
-  hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout);
-  hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
-    c->d_slot_index, c->d_flags);
+  if (S <= 65536)
+  {
+    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
+      d_nout);
+    hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
+      (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
+    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
+      c->d_slot_index, c->d_flags);
+  }
   timing_mark(c, "compact", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
