@@ -27,7 +27,10 @@ struct GridDesc
   double inv_cell;
   int dim[3];
   int ncell;
-  unsigned bbox[6];  // order-preserving uint encoding of float min[3], max[3] (scratch for the reduction)
+  unsigned bbox[6];  // order-preserving uint encoding of float min[3], max[3] (scratch for the reduction; the
+                     // work-group that consumes it resets it to {~0, ~0, ~0, 0, 0, 0} for the next build)
+  unsigned done;     // work-groups of k_bbox that have contributed (reset by the last one)
+  unsigned ticket;   // tile tickets of k_cell_scan (reset by the holder of the last one)
 };
 
 // Everything a search kernel needs to walk the grid.
@@ -134,6 +137,9 @@ struct Ctx
   int* d_cell_start = nullptr;  // kCellCap + 1
   int* d_cell_count = nullptr;  // kCellCap
   int* d_block_sums = nullptr;
+  unsigned long long* d_tile_state = nullptr;  // k_cell_scan look-back descriptors, tagged with the build number
+  unsigned build_gen = 0;
+  bool grid_clean = false;      // cell counts, bbox and counters are in their reset state (self-cleaning kernels)
   int* d_cell_of = nullptr;     // n
   int* d_rank_of = nullptr;     // n: rank of a point inside its cell
   float4* d_sorted = nullptr;   // n

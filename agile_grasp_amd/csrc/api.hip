@@ -362,6 +362,7 @@ int agh_create(const agh_params* p, agh_ctx** out)
   int rc;
   if ((rc = dev_alloc(c, &c->d_desc, 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) kCellCap + 1)) ||
       (rc = dev_alloc(c, &c->d_cell_count, (size_t) kCellCap)) || (rc = dev_alloc(c, &c->d_block_sums, 4096)) ||
+      (rc = dev_alloc(c, &c->d_tile_state, (size_t) kCellCap / 1024)) ||
       (rc = dev_alloc(c, &c->d_flags, 8)) || (rc = dev_alloc(c, &c->d_nout, 1)) ||
       (rc = dev_alloc(c, &c->d_geom, 1)) || (rc = dev_alloc(c, &c->d_hog, 1)) ||
       (rc = dev_alloc(c, &c->d_svm_w, 3528)))
@@ -393,7 +394,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
-    c->d_weight, c->d_order, c->d_vmask, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_weight, c->d_order, c->d_vmask, c->d_tile_state, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);

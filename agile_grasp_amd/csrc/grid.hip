@@ -10,58 +10,25 @@
 namespace agh
 {
 
-__global__ void k_desc_init(GridDesc* d)
+// Reset state of the self-cleaning fields (also written once by agh_create / after a failed build).
+__global__ void k_desc_reset(GridDesc* d)
 {
   for (int a = 0; a < 3; a++)
   {
     d->bbox[a] = 0xffffffffu;  // min
     d->bbox[3 + a] = 0u;       // max
   }
+  d->done = 0u;
+  d->ticket = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int64_t stride, int64_t n, GridDesc* d)
-{
-  float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
-  {
-    const float* p = xyz + i * stride;
-    for (int a = 0; a < 3; a++)
-    {
-      mn[a] = fminf(mn[a], p[a]);
-      mx[a] = fmaxf(mx[a], p[a]);
-    }
-  }
-  __shared__ float smn[4][3], smx[4][3];
-  for (int a = 0; a < 3; a++)
-    for (int o = 32; o > 0; o >>= 1)
-    {
-      mn[a] = fminf(mn[a], __shfl_down(mn[a], o));
-      mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o));
-    }
-  if ((threadIdx.x & 63) == 0)
-    for (int a = 0; a < 3; a++)
-    {
-      smn[threadIdx.x >> 6][a] = mn[a];
-      smx[threadIdx.x >> 6][a] = mx[a];
-    }
-  __syncthreads();
-  if (threadIdx.x < 3)  // one atomic pair per block and axis: same-address atomics cost ~12 ns each
-  {
-    const int a = threadIdx.x;
-    const float lo = fminf(fminf(smn[0][a], smn[1][a]), fminf(smn[2][a], smn[3][a]));
-    const float hi = fmaxf(fmaxf(smx[0][a], smx[1][a]), fmaxf(smx[2][a], smx[3][a]));
-    atomicMin(&d->bbox[a], enc_float(lo));
-    atomicMax(&d->bbox[3 + a], enc_float(hi));
-  }
-}
-
-__global__ void k_desc_finish(GridDesc* d, double base_cell, int64_t n)
+__device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const unsigned bb[6])
 {
   double mn[3], mx[3];
   for (int a = 0; a < 3; a++)
   {
-    mn[a] = n > 0 ? (double) dec_float(d->bbox[a]) : 0.0;
-    mx[a] = n > 0 ? (double) dec_float(d->bbox[3 + a]) : 0.0;
+    mn[a] = n > 0 ? (double) dec_float(bb[a]) : 0.0;
+    mx[a] = n > 0 ? (double) dec_float(bb[3 + a]) : 0.0;
   }
   double cell = base_cell;
   int dim[3];
@@ -85,6 +52,62 @@ __global__ void k_desc_finish(GridDesc* d, double base_cell, int64_t n)
   d->cell = cell;
   d->inv_cell = 1.0 / cell;
   d->ncell = dim[0] * dim[1] * dim[2];
+}
+
+// Bounding box of the cloud and, in the work-group that finishes last, the grid descriptor (one launch instead of
+// init + reduce + finish: a launch costs ~4.7 us of its own on this part, more than any of these does work).
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int64_t stride, int64_t n, GridDesc* d,
+  double base_cell)
+{
+  float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+  {
+    const float* p = xyz + i * stride;
+    for (int a = 0; a < 3; a++)
+    {
+      mn[a] = fminf(mn[a], p[a]);
+      mx[a] = fmaxf(mx[a], p[a]);
+    }
+  }
+  __shared__ float smn[4][3], smx[4][3];
+  __shared__ unsigned last;
+  for (int a = 0; a < 3; a++)
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      mn[a] = fminf(mn[a], __shfl_down(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; a++)
+    {
+      smn[threadIdx.x >> 6][a] = mn[a];
+      smx[threadIdx.x >> 6][a] = mx[a];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3 && n > 0)  // one atomic pair per block and axis: same-address atomics cost ~12 ns each
+  {
+    const int a = threadIdx.x;
+    const float lo = fminf(fminf(smn[0][a], smn[1][a]), fminf(smn[2][a], smn[3][a]));
+    const float hi = fmaxf(fmaxf(smx[0][a], smx[1][a]), fmaxf(smx[2][a], smx[3][a]));
+    atomicMin(&d->bbox[a], enc_float(lo));
+    atomicMax(&d->bbox[3 + a], enc_float(hi));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __threadfence();  // this group's atomics are performed before its arrival is counted
+    last = atomicAdd(&d->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0)
+  {
+    __threadfence();
+    unsigned bb[6];
+    for (int a = 0; a < 6; a++)
+      bb[a] = atomicExch(&d->bbox[a], a < 3 ? 0xffffffffu : 0u);  // read the result and leave the reset state behind
+    d->done = 0u;
+    desc_finish(d, base_cell, n, bb);
+  }
 }
 
 // Cell histogram.  Clouds arrive in voxel order (localization.cpp:282-351), so consecutive points mostly share a cell:
@@ -125,7 +148,11 @@ __global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xy
   }
 }
 
-// 3-phase exclusive scan over the first ncell (+1) entries; 1024 entries per block.
+// Exclusive scan of the cell histogram in ONE launch (decoupled look-back): tiles of 1024 cells are walked round-robin
+// by 256 resident work-groups, so a tile's predecessors are always running or done and the look-back cannot deadlock.  A tile
+// publishes (build number, flag, value) in one 64-bit word: flag 1 = the tile's own total, 2 = its inclusive prefix;
+// the build number makes stale words from earlier builds invisible, so the descriptors never need clearing.  The kernel
+// also zeroes the histogram it has read: the next build starts from a clean one without a memset.
 constexpr int kScanBlock = 1024;
 
 __device__ __forceinline__ int block_scan_excl(int v, int* total)
@@ -151,67 +178,83 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total)
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_scan_sums(const int* __restrict__ count, const GridDesc* __restrict__ d,
-  int* __restrict__ block_sums)
+__global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, GridDesc* __restrict__ d,
+  unsigned long long* __restrict__ tile_state, unsigned gen, int* __restrict__ cell_start, int n)
 {
+  __shared__ int s_prefix;
   const int ncell = d->ncell;
-  const int b0 = blockIdx.x * kScanBlock;
-  if (b0 >= ncell)
-    return;
-  int s = 0;
-  for (int k = 0; k < 4; k++)
+  // 256 resident work-groups walk the tiles round-robin: tile t only ever waits for tiles < t, which belong to the
+  // first pass of lower-numbered groups or to an earlier pass, so the look-back cannot deadlock (and no same-address
+  // ticket atomics, ~12 ns each, are needed to order the tiles)
+  for (int tile = blockIdx.x; tile * kScanBlock < ncell; tile += gridDim.x)
   {
-    const int i = b0 + threadIdx.x * 4 + k;
-    if (i < ncell)
-      s += count[i];
-  }
-  int total;
-  block_scan_excl(s, &total);
-  if (threadIdx.x == 0)
-    block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void k_scan_top(int* __restrict__ block_sums, const GridDesc* __restrict__ d)
-{
-  const int nb = (d->ncell + kScanBlock - 1) / kScanBlock;  // <= kCellCap / 1024 = 2048
-  int carry = 0;
-  for (int b0 = 0; b0 < nb; b0 += 256)
-  {
-    const int i = b0 + threadIdx.x;
-    const int v = i < nb ? block_sums[i] : 0;
-    int total;
-    const int ex = block_scan_excl(v, &total);
-    if (i < nb)
-      block_sums[i] = carry + ex;
-    carry += total;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_scan_final(const int* __restrict__ count, const GridDesc* __restrict__ d,
-  const int* __restrict__ block_sums, int* __restrict__ cell_start, int n)
-{
-  const int ncell = d->ncell;
-  const int b0 = blockIdx.x * kScanBlock;
-  if (b0 >= ncell)
-    return;
-  int v[4], s = 0;
+  const int b0 = tile * kScanBlock;
+  int v[4], sum = 0;
   for (int k = 0; k < 4; k++)
   {
     const int i = b0 + threadIdx.x * 4 + k;
     v[k] = i < ncell ? count[i] : 0;
-    s += v[k];
+    sum += v[k];
   }
   int total;
-  int ex = block_scan_excl(s, &total) + block_sums[blockIdx.x];
+  int ex = block_scan_excl(sum, &total);
+  const unsigned long long tag = (unsigned long long) gen << 34;
+  if (threadIdx.x < 64)  // wave 0 publishes and looks back, 64 predecessors per round (one serial load per
+  {                      // predecessor would make the last tile wait ~0.6 us x its index)
+    const int lane = threadIdx.x;
+    int prefix = 0;
+    if (lane == 0)
+      __hip_atomic_store(&tile_state[tile], tag | ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned) total, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_AGENT);
+    for (int j0 = tile - 1; j0 >= 0; j0 -= 64)
+    {
+      const int j = j0 - lane;
+      unsigned long long w = 0;
+      for (;;)
+      {
+        bool ready = true;
+        if (j >= 0)
+        {
+          w = __hip_atomic_load(&tile_state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          ready = (w >> 34) == gen && ((w >> 32) & 3ull) != 0ull;
+        }
+        if (__ballot(!ready) == 0ull)
+          break;
+        __builtin_amdgcn_s_sleep(1);  // a predecessor has not published yet
+      }
+      const unsigned long long incl = __ballot(j >= 0 && ((w >> 32) & 3ull) == 2ull);
+      const int stop = incl ? __ffsll((long long) incl) - 1 : 63;  // nearest predecessor with an inclusive prefix
+      int val = (j >= 0 && lane <= stop) ? (int) (unsigned) w : 0;
+      for (int o = 32; o > 0; o >>= 1)
+        val += __shfl_xor(val, o);
+      prefix += val;
+      if (incl)
+        break;
+    }
+    if (lane == 0)
+    {
+      if (tile != 0)
+        __hip_atomic_store(&tile_state[tile], tag | (2ull << 32) | (unsigned) (prefix + total), __ATOMIC_RELEASE,
+          __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+    }
+  }
+  __syncthreads();
+  ex += s_prefix;
   for (int k = 0; k < 4; k++)
   {
     const int i = b0 + threadIdx.x * 4 + k;
     if (i < ncell)
+    {
       cell_start[i] = ex;
+      count[i] = 0;
+    }
     ex += v[k];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+  if (tile == 0 && threadIdx.x == 0)
     cell_start[ncell] = n;
+  __syncthreads();  // s_prefix is reused by the next tile of this group
+  }
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ xyz, int64_t stride,
@@ -231,25 +274,35 @@ int grid_build(Ctx* c, hipStream_t st)
 {
   const int64_t n = c->n;
   const int nblk = (int) std::min<int64_t>((n + 255) / 256, 2048);
-  hipMemsetAsync(c->d_cell_count, 0, sizeof(int) * kCellCap, st);
-  hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(1), 0, st, c->d_desc);
-  if (n > 0)
-    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblk, 128)), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc);
+  if (!c->grid_clean)  // first build of the context, or the previous one failed half-way
+  {
+    hipMemsetAsync(c->d_cell_count, 0, sizeof(int) * kCellCap, st);
+    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (kCellCap / kScanBlock), st);
+    hipLaunchKernelGGL(k_desc_reset, dim3(1), dim3(1), 0, st, c->d_desc);
+    c->build_gen = 0;
+  }
+  c->grid_clean = false;
+  if (++c->build_gen >= (1u << 30))  // the tag has 30 bits: start over long before it wraps
+  {
+    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (kCellCap / kScanBlock), st);
+    c->build_gen = 1;
+  }
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
-  hipLaunchKernelGGL(k_desc_finish, dim3(1), dim3(1), 0, st, c->d_desc, base_cell, n);
+  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, 128))), dim3(256), 0, st, c->d_xyz, c->stride_floats, n,
+    c->d_desc, base_cell);
   if (n > 0)
     hipLaunchKernelGGL(k_cell_count, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc,
       c->d_cell_of, c->d_rank_of, c->d_cell_count);
-  const int sb = kCellCap / kScanBlock;
-  hipLaunchKernelGGL(k_scan_sums, dim3(sb), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_block_sums);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, c->d_block_sums, c->d_desc);
-  hipLaunchKernelGGL(k_scan_final, dim3(sb), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_block_sums,
-    c->d_cell_start, (int) n);
+  hipLaunchKernelGGL(k_cell_scan, dim3(256), dim3(256), 0, st, c->d_cell_count, c->d_desc,
+    c->d_tile_state, c->build_gen, c->d_cell_start, (int) n);
   if (n > 0)
     hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, c->d_cam, n, c->d_cell_of,
       c->d_rank_of, c->d_cell_start, c->d_sorted);
-  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+  if (hipGetLastError() != hipSuccess)
+    return AGH_ERR_HIP;
+  c->grid_clean = true;
+  return AGH_OK;
 }
 
 }  // namespace agh
