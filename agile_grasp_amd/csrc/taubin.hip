@@ -109,53 +109,81 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   }
   const float binscale = (float) kSortBins / r2f;  // monotone map of d2 in [0, r2f) onto the sort bins
   // ---- gather + FLANN distance filter + compaction into LDS ----
-  // every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes, two loads in flight
-  // per lane: row base and length are wave-uniform (no per-candidate row look-up) and the reads are fully coalesced
+  // every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes: row base and length
+  // are wave-uniform (no per-candidate row look-up) and the reads are fully coalesced.
+  // The walk is software-pipelined like k_hand_sweep's: the (unconditional) loads of the next 128 candidates are issued
+  // before the current 128 are filtered, and the two candidates of a lane share one reservation.
   {
-    auto take = [&](const float4& p, bool have) {
-      float d2 = 0.f;
-      bool pass = false;
-      if (have)
+    const int nrows = rt.nrows;
+    auto seg_normalize = [&](int& r, int& i, int& rb, int& len) {  // skip exhausted / empty rows
+      for (;;)
       {
-        d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
-        pass = d2 < r2f;
+        if (r >= nrows)
+        {
+          len = 0;
+          rb = 0;
+          return;
+        }
+        rb = rt.begin[r];
+        len = rt.prefix[r + 1] - rt.prefix[r];
+        if (i < len)
+          return;
+        r += 4;
+        i = 0;
       }
-      const unsigned long long m = __ballot(pass);
-      if (m)
+    };
+    auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
+      h0 = r < nrows && i + lane < len;
+      h1 = r < nrows && i + 64 + lane < len;
+      p0 = gv.sorted[h0 ? rb + i + lane : 0];  // a lane without a candidate reads element 0 and ignores it
+      p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
+    };
+    auto take2 = [&](const float4& p0, bool h0, const float4& p1, bool h1) {
+      const float d0 = flann_d2(qx, qy, qz, p0.x, p0.y, p0.z), d1 = flann_d2(qx, qy, qz, p1.x, p1.y, p1.z);
+      const bool s0 = h0 && d0 < r2f, s1 = h1 && d1 < r2f;
+      const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+      if (m0 | m1)
       {
+        const int c0 = __popcll(m0);
         int base = 0;
         if (lane == 0)
-          base = atomicAdd(&count, __popcll(m));
-        base = __shfl(base, 0);
-        if (pass)
+          base = atomicAdd(&count, c0 + __popcll(m1));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int k0 = base + __popcll(m0 & below), k1 = base + c0 + __popcll(m1 & below);
+        if (s0 && k0 < CAP)
         {
-          const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (k < CAP)
-          {
-            stage[k] = p;
-            key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
-            atomicAdd(&hist[min(kSortBins - 1, (int) (d2 * binscale))], 1);
-          }
+          stage[k0] = p0;
+          key[k0] = ((unsigned long long) __float_as_uint(d0) << 32) | (unsigned long long) __float_as_uint(p0.w);
+          atomicAdd(&hist[min(kSortBins - 1, (int) (d0 * binscale))], 1);
+        }
+        if (s1 && k1 < CAP)
+        {
+          stage[k1] = p1;
+          key[k1] = ((unsigned long long) __float_as_uint(d1) << 32) | (unsigned long long) __float_as_uint(p1.w);
+          atomicAdd(&hist[min(kSortBins - 1, (int) (d1 * binscale))], 1);
         }
       }
     };
-    const int nrows = rt.nrows;
-    for (int r = wave; r < nrows; r += 4)
+    int cur_r = wave, cur_i = 0, rb = 0, len = 0;
+    seg_normalize(cur_r, cur_i, rb, len);
+    float4 p0, p1;
+    bool h0, h1;
+    seg_load(cur_r, cur_i, rb, len, p0, p1, h0, h1);
+    while (cur_r < nrows)
     {
-      const int rb = rt.begin[r];
-      const int len = rt.prefix[r + 1] - rt.prefix[r];
-      for (int i0 = 0; i0 < len; i0 += 128)
-      {
-        const bool h0 = i0 + lane < len, h1 = i0 + 64 + lane < len;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-        if (h0)
-          p0 = gv.sorted[rb + i0 + lane];
-        if (h1)
-          p1 = gv.sorted[rb + i0 + 64 + lane];
-        take(p0, h0);
-        if (i0 + 64 < len)
-          take(p1, h1);
-      }
+      int nr = cur_r, ni = cur_i + 128, nrb = 0, nlen = 0;
+      seg_normalize(nr, ni, nrb, nlen);
+      float4 q0, q1;
+      bool g0, g1;
+      seg_load(nr, ni, nrb, nlen, q0, q1, g0, g1);  // in flight while the current segment is filtered
+      take2(p0, h0, p1, h1);
+      cur_r = nr;
+      cur_i = ni;
+      p0 = q0;
+      p1 = q1;
+      h0 = g0;
+      h1 = g1;
     }
   }
   __syncthreads();
