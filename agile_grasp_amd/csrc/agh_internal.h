@@ -62,6 +62,7 @@ struct HandGeom
   double ylut_lo, ylut_scale;
   unsigned char xlut[1024];
   unsigned char ylut[64];
+  int x_probes, y_probes;      // most entries any one cell holds: the probes a kernel instantiation must make
 };
 constexpr int kLutProbe = 4;
 

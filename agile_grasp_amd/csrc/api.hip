@@ -143,7 +143,9 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
   }
   g->cos_antipodal = std::cos(20 * M_PI / 180.0);  // antipodal.cpp:16 with thresh 20 (rotating_hand.cpp:162)
   // look-up tables (see HandGeom): the device evaluates exactly this cell formula
-  auto build_lut = [&](const double* tab, int n, int ncell, double* lo_out, double* scale_out, unsigned char* lut) -> bool {
+  auto build_lut = [&](const double* tab, int n, int ncell, double* lo_out, double* scale_out, unsigned char* lut,
+                       int* probes) -> bool {
+    *probes = 0;
     const double lo = tab[0], hi = tab[n - 1];
     const double scale = (hi > lo) ? (double) ncell / (hi - lo) : 0.0;
     *lo_out = lo;
@@ -161,12 +163,13 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
       }
       if (inside > kLutProbe)
         return false;
+      *probes = std::max(*probes, inside);
       lut[c] = (unsigned char) before;
     }
     return true;
   };
-  if (!build_lut(g->thr, g->n_thr, 1024, &g->xlut_lo, &g->xlut_scale, g->xlut) ||
-      !build_lut(g->depths, g->n_depths, 64, &g->ylut_lo, &g->ylut_scale, g->ylut))
+  if (!build_lut(g->thr, g->n_thr, 1024, &g->xlut_lo, &g->xlut_scale, g->xlut, &g->x_probes) ||
+      !build_lut(g->depths, g->n_depths, 64, &g->ylut_lo, &g->ylut_scale, g->ylut, &g->y_probes))
     *err = "hand geometry packs more than 4 finger-slot thresholds (or bite depths) into one look-up cell";
 }
 

@@ -62,7 +62,9 @@ __device__ __forceinline__ unsigned lowmask(int n)
   return n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
 }
 
-template <bool NORMALS>
+// PX / PY: look-up probes per finger-slot threshold cell / bite-depth cell (HandGeom::x_probes, y_probes): the default
+// hand needs 2 and 1, any admissible geometry at most kLutProbe.
+template <bool NORMALS, int PX, int PY>
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
           const int ly = G.ylut[cy];
           int yk = ly;
   #pragma unroll
-          for (int j = 0; j < kLutProbe; j++)
+          for (int j = 0; j < PY; j++)
             yk += (dep_s[ly + j] <= yr[u]) ? 1 : 0;
           if (yk < K && debug_stop != 11)
           {
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             const int lx = G.xlut[cx];
             int c = lx, e = 0;
   #pragma unroll
-            for (int j = 0; j < kLutProbe; j++)
+            for (int j = 0; j < PX; j++)
             {
               const double tv = thr_s[lx + j];
               c += (tv < xr[u]) ? 1 : 0;
@@ -841,14 +843,20 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
   // blockIdx -> sample goes through c->d_order (longest first; computed by k_taubin_eigen's sorter work-group)
-  if (nrm)
-    hipLaunchKernelGGL(k_hand_sweep<true>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
-      (const int*) c->d_order, c->d_vmask);
+  const bool few = c->geom.x_probes <= 2 && c->geom.y_probes <= 1;
+#define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
+  hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
+    r2f, rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
+    (const int*) c->d_order, c->d_vmask)
+  if (nrm && few)
+    AGH_LAUNCH_SWEEP(true, 2, 1);
+  else if (nrm)
+    AGH_LAUNCH_SWEEP(true, kLutProbe, kLutProbe);
+  else if (few)
+    AGH_LAUNCH_SWEEP(false, 2, 1);
   else
-    hipLaunchKernelGGL(k_hand_sweep<false>, dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, r2f,
-      rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,
-      (const int*) c->d_order, c->d_vmask);
+    AGH_LAUNCH_SWEEP(false, kLutProbe, kLutProbe);
+#undef AGH_LAUNCH_SWEEP
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -47,3 +47,5 @@ for i in last:
     print("  late WG", i, "start", start[i] / 100.0, "end", end[i] / 100.0, "dur", (end[i] - start[i]) / 100.0, "ball", ball[i])
 busy = (end - start).sum() / 100.0
 print("sum of WG durations us", busy, "-> /768 slots =", busy / 768.0, "us (perfect packing)")
+for i in np.argsort(end)[-3:]:
+    print("  phases of late WG", i, dict(zip(names, (ph[i] / 100.0).round(1))), "tiles", (int(d[i, 7]) >> 24) & 0xff, "cand", int(d[i, 7]) & 0xffffff, "ball", int(d[i, 7] >> 32))
