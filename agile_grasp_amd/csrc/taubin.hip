@@ -861,6 +861,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   __shared__ double wbest[4];
   __shared__ int wbest_j[4];
   __shared__ double sT[4][28];
+  __shared__ double sW[28];
   __shared__ double wmax_s[4];
   __shared__ unsigned short cand[CAP];
   __shared__ int ncand;
@@ -962,36 +963,55 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
         for (int b = 6 - a; b >= 0; b--)
           T[k++] += (px[a] * py[b]) * pz[6 - a - b];
     }
+    // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
+    // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
+    // full butterflies (168 exchanges) would; lane l ends with the total of moment l >> 1.
+    double R[32];
 #pragma unroll
-    for (int k = 0; k < 28; k++)
+    for (int k = 0; k < 32; k++)
+      R[k] = k < 28 ? T[k] : 0.0;
+#pragma unroll
+    for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1)
     {
-      double v = T[k];
-      for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
-      T[k] = v;
-    }
-    if (lane == 0)
+      const bool upper = (lane & o) != 0;
 #pragma unroll
-      for (int k = 0; k < 28; k++)
-        sT[wave][k] = T[k];
+      for (int k = 0; k < half; k++)
+      {
+        const double send = upper ? R[k] : R[k + half];
+        const double keep = upper ? R[k + half] : R[k];
+        R[k] = keep + __shfl_xor(send, o);
+      }
+    }
+    R[0] = R[0] + __shfl_xor(R[0], 1);
+    if ((lane & 1) == 0 && (lane >> 1) < 28)
+      sT[wave][lane >> 1] = R[0];
+  }
+  __syncthreads();
+  if (tid < 28)  // multinomial-weighted moments, once per block
+  {
+    const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
+    int k = 0, ea = 0, eb = 0;
+    for (int a = 6; a >= 0; a--)
+      for (int b = 6 - a; b >= 0; b--)
+      {
+        if (k == tid)
+        {
+          ea = a;
+          eb = b;
+        }
+        k++;
+      }
+    const double tsum = ((sT[0][tid] + sT[1][tid]) + sT[2][tid]) + sT[3][tid];
+    sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
   }
   __syncthreads();
   double est[CAP / 256];
   double est_max = -1.0;
   {
-    // multinomial-weighted moments, identical in every thread
     double W[28];
-    {
-      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
-      int k = 0;
-      for (int a = 6; a >= 0; a--)
-        for (int b = 6 - a; b >= 0; b--)
-        {
-          const double tsum = ((sT[0][k] + sT[1][k]) + sT[2][k]) + sT[3][k];
-          W[k] = tsum * (fact[6] / ((fact[a] * fact[b]) * fact[6 - a - b]));
-          k++;
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < 28; k++)
+      W[k] = sW[k];
 #pragma unroll
     for (int m = 0; m < CAP / 256; m++)
     {
