@@ -411,6 +411,16 @@ __device__ __forceinline__ void rr_zero(double (&ar)[9], int kk, int gl, bool ze
   ar[p] = (mine && gl == q) ? 0.0 : ar[p];
 }
 
+// Would the sweep ROTATE the pair (gl, J) of this lane's row (upper triangle)?  Mirrors the per-pair tests of jacobi_rr9.
+template <int J>
+__device__ __forceinline__ bool rr_needs_rotation(const double (&ar)[9], int gl, bool row, int sweep, double dg)
+{
+  const double ajj = bcast16<J>(ar[J]);  // a_JJ lives in lane J
+  const double v = ar[J], av = fabs(v);
+  const bool negl = sweep > 3 && (fabs(dg) + av == fabs(dg)) && (fabs(ajj) + av == fabs(ajj));
+  return row && J > gl && v != 0.0 && !negl;
+}
+
 template <int R>
 __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], int gl, int gbase, bool row, bool active,
   int sweep)
@@ -713,9 +723,25 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
 #pragma unroll
     for (int j = 1; j < 9; j++)
       nz = nz || (row && j > gl && (ar[j] * ar[j] != 0.0));
-    const unsigned long long nzb = __ballot(nz);
-    const bool active = ((nzb >> gbase) & 0xffffull) != 0;
-    if (nzb == 0)
+    // A sweep in which every non-zero pair is negligible (possible from sweep 4 on) only sets those entries to zero:
+    // the diagonal and V are final, and the oracle's next sweep sees off == 0.  Recognise it up front (one pass over
+    // the row: own diagonal, the column's diagonal by a row broadcast) instead of running its nine rounds.
+    double dg = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+      dg = gl == j ? ar[j] : dg;
+    bool need = false;
+    need = rr_needs_rotation<1>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<2>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<3>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<4>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<5>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<6>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<7>(ar, gl, row, sweep, dg) || need;
+    need = rr_needs_rotation<8>(ar, gl, row, sweep, dg) || need;
+    const unsigned long long nzb = __ballot(nz), needb = __ballot(need);
+    const bool active = ((nzb >> gbase) & 0xffffull) != 0 && ((needb >> gbase) & 0xffffull) != 0;
+    if (__ballot(active) == 0ull)
       break;
     jacobi_round<0>(ar, vr, gl, gbase, row, active, sweep);
     jacobi_round<1>(ar, vr, gl, gbase, row, active, sweep);
