@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
-  const int* __restrict__ order, uint8_t* __restrict__ vmask)
+  const int* __restrict__ order, uint8_t* __restrict__ vmask, double2* __restrict__ spill_all, int spill_cap)
 {
   constexpr int kTile = NORMALS ? 1728 : 2176;  // the block must stay under a third of the CU's 160 KiB (512-B granules)
   __shared__ double2 pts[kTile];
@@ -392,7 +392,13 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       ymax_w[oo] = ymax;
     }
   };
-  int ntiles = 0, nc = 0;
+  // A neighbourhood that needs more than one tile would have to be gathered again for pass B (filter, rotation and
+  // crop of every candidate a second time).  Instead its cropped points are parked in the sample's neighbour-list
+  // scratch (dead since K1c; 16 bytes per point, spill_cap points) while pass A streams through them, and pass B reads
+  // them back with plain coalesced loads.  Only if they do not fit does pass B gather again.
+  double2* spill = spill_all + (int64_t) s * spill_cap;
+  int ntiles = 0, nc = 0, nspill = 0;
+  bool spill_ok = !NORMALS;  // (the normals variant also needs the point ids: it keeps the second gather)
   for (;;)
   {
     bool all_done = false;
@@ -401,6 +407,17 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
       AGH_STAMP(2);
     if (debug_stop == 2)
       return;
+    if (spill_ok && (ntiles > 0 || !all_done))
+    {
+      if (nspill + nc <= spill_cap)
+      {
+        for (int t = tid; t < nc; t += 256)
+          spill[nspill + t] = pts[t];
+        nspill += nc;
+      }
+      else
+        spill_ok = false;
+    }
     classify(nc);
     ntiles++;
     if (all_done)
@@ -526,15 +543,28 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   if (any_hand)
   {
     const bool refill = ntiles > 1;  // a single tile is still resident in LDS
+    const bool from_spill = refill && spill_ok;
+    int spill_pos = 0;
     if (refill)
     {
       next_tile();
       gather_reset();
+      if (from_spill)
+        __threadfence();  // the parked points were written by this work-group: make them visible to all its waves
     }
     for (;;)
     {
       bool all_done = true;
-      if (refill)
+      if (from_spill)
+      {
+        nc = min(kTile, nspill - spill_pos);
+        for (int t = tid; t < nc; t += 256)
+          pts[t] = spill[spill_pos + t];
+        spill_pos += nc;
+        all_done = spill_pos >= nspill;
+        __syncthreads();
+      }
+      else if (refill)
         nc = gather_tile(false, all_done);
       for (int oo = 0; oo < 2; oo++)
       {
@@ -847,7 +877,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
   hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
     r2f, rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
-    (const int*) c->d_order, c->d_vmask)
+    (const int*) c->d_order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride)
   if (nrm && few)
     AGH_LAUNCH_SWEEP(true, 2, 1);
   else if (nrm)
