@@ -311,7 +311,25 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
       }
     }
     __syncthreads();
-    if (wave == 0 && lane < kNumSums)
+    if (wave == 0 && lane < kNumSums && rows == kChunk)
+    {
+      // full chunk: all 56 loads are issued up front (two register halves), so the dependent add chain -- the critical
+      // path of the block -- pays one LDS round trip per chunk instead of one per eight rows
+      double va[kChunk / 2], vb[kChunk / 2];
+#pragma unroll
+      for (int u = 0; u < kChunk / 2; u++)
+        va[u] = termbuf[u * kNumSums + lane];
+#pragma unroll
+      for (int u = 0; u < kChunk / 2; u++)
+        vb[u] = termbuf[(kChunk / 2 + u) * kNumSums + lane];
+#pragma unroll
+      for (int u = 0; u < kChunk / 2; u++)
+        acc += va[u];
+#pragma unroll
+      for (int u = 0; u < kChunk / 2; u++)
+        acc += vb[u];
+    }
+    else if (wave == 0 && lane < kNumSums)
     {
       int k = 0;
       for (; k + 8 <= rows; k += 8)  // 8 LDS loads in flight; the adds stay in neighbour order
