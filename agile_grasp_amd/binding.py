@@ -74,11 +74,13 @@ FRAME_DTYPE = np.dtype(
         ("valid", "<i4"),
     ]
 )
-assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200
+HANDLE_DTYPE = np.dtype([("axis", "<f8", 3), ("center", "<f8", 3), ("approach", "<f8", 3), ("binormal", "<f8", 3),
+                         ("hands_center", "<f8", 3), ("width", "<f8"), ("n_inliers", "<i4"), ("first_inlier", "<i4")])
+assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200 and HANDLE_DTYPE.itemsize == 136
 
 EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device",
-    "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
 ]
@@ -197,6 +199,19 @@ class Context:
             C.c_void_p(stream) if stream else None))
         self.n = nv.value
         return nv.value
+
+    def find_handles(self, hands: np.ndarray, min_inliers: int = 3, min_length: float = 0.005):
+        """HandleSearch::findHandles on hypothesis records; returns (handles, concatenated inlier indices)."""
+        hands = np.ascontiguousarray(hands, HYP_DTYPE)
+        H = hands.shape[0]
+        out = np.zeros(max(H, 1), HANDLE_DTYPE)
+        idx = np.zeros(max(H, 1), np.int32)
+        n = C.c_int64(0)
+        self._check(self.lib.agh_find_handles(self._h, hands.ctypes.data_as(C.c_void_p), C.c_int64(H), C.c_int32(min_inliers),
+                                              C.c_double(min_length), out.ctypes.data_as(C.c_void_p), C.c_int64(out.shape[0]),
+                                              _p(idx, C.c_int32), C.c_int64(idx.shape[0]), C.byref(n)))
+        out = out[:n.value].copy()
+        return out, idx[:int(out["n_inliers"].sum())].copy()
 
     def cloud(self):
         xyz = np.zeros((max(self.n, 1), 3), np.float32)

@@ -133,6 +133,17 @@ struct Ctx
   float* d_raw_xyz = nullptr;      // device copy of a raw host cloud
   int64_t raw_cap = 0;
 
+  // handle search (K5)
+  agh_hypothesis* d_h_hands = nullptr;
+  unsigned long long* d_h_bits = nullptr;
+  int* d_h_rowcnt = nullptr;
+  int* d_h_first = nullptr;
+  int* d_h_n = nullptr;
+  int* d_h_idx = nullptr;
+  int* d_h_counts = nullptr;  // HandleCounts
+  agh_handle* d_h_handles = nullptr;
+  int64_t h_cap = 0;
+
   // grid
   GridDesc* d_desc = nullptr;
   int* d_cell_start = nullptr;  // kCellCap + 1
@@ -210,6 +221,7 @@ struct Ctx
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
   const double workspace[6], double cell, hipStream_t st);
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st);
+int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st);
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);
@@ -348,6 +360,68 @@ __device__ __forceinline__ int row_lookup(const RowTable& rt, int j)
       hi = mid;
   }
   return rt.begin[lo] + (j - rt.prefix[lo]);
+}
+
+// Cyclic Jacobi of a symmetric 3x3 (oracle jacobi_sym<3>): one lane, the oracle's operation order.
+__device__ inline void jacobi3_serial(double A[3][3], double V[3][3], double d[3])
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; sweep++)
+  {
+    double off = 0.0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++)
+        off += A[p][q] * A[p][q];
+    if (off == 0.0)
+      break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++)
+      {
+        const double apq = A[p][q];
+        if (apq == 0.0)
+          continue;
+        const double app = A[p][p], aqq = A[q][q];
+        const double aabs = fabs(apq);
+        if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
+        {
+          A[p][q] = 0.0;
+          A[q][p] = 0.0;
+          continue;
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+        if (theta < 0.0)
+          t = -t;
+        const double c = 1.0 / sqrt(t * t + 1.0);
+        const double s = t * c;
+        A[p][p] = app - t * apq;
+        A[q][q] = aqq + t * apq;
+        A[p][q] = 0.0;
+        A[q][p] = 0.0;
+        for (int k = 0; k < 3; k++)
+        {
+          if (k == p || k == q)
+            continue;
+          const double akp = A[k][p], akq = A[k][q];
+          const double np_ = c * akp - s * akq;
+          const double nq_ = s * akp + c * akq;
+          A[k][p] = np_;
+          A[p][k] = np_;
+          A[k][q] = nq_;
+          A[q][k] = nq_;
+        }
+        for (int k = 0; k < 3; k++)
+        {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++)
+    d[i] = A[i][i];
 }
 
 #endif  // __HIPCC__

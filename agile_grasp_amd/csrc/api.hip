@@ -397,7 +397,8 @@ void agh_destroy(agh_ctx* ctx)
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
-    c->d_weight, c->d_order, c->d_vmask, c->d_tile_state, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_weight, c->d_order, c->d_vmask, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -571,6 +572,117 @@ int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t
   if (rc != AGH_OK)
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AGH_OK;
+}
+
+// ---- f2: handle search ----
+// acos(x) < 0.34 <=> x >= x1 and M_PI - acos(x) < 0.34 <=> x <= x2 for the host's libm (the one the reference's
+// safeAcos would call): found by bisection on the doubles, monotonicity checked around the result.
+static bool handle_thresholds(double* x1, double* x2)
+{
+  double lo = 0.9, hi = 1.0;  // acos(lo) >= 0.34 > acos(hi)
+  if (!(std::acos(lo) >= 0.34) || !(std::acos(hi) < 0.34))
+    return false;
+  while (std::nextafter(lo, hi) != hi)
+  {
+    const double mid = lo + (hi - lo) / 2.0;
+    if (std::acos(mid) < 0.34)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  *x1 = hi;
+  double a = -1.0, b = -0.9;  // M_PI - acos(a) < 0.34 <= M_PI - acos(b)
+  if (!(M_PI - std::acos(a) < 0.34) || (M_PI - std::acos(b) < 0.34))
+    return false;
+  while (std::nextafter(a, b) != b)
+  {
+    const double mid = a + (b - a) / 2.0;
+    if (M_PI - std::acos(mid) < 0.34)
+      a = mid;
+    else
+      b = mid;
+  }
+  *x2 = a;
+  double t = *x1, u = *x2;
+  for (int k = 0; k < 64; k++)  // a few ulps either side behave monotonically
+  {
+    t = std::nextafter(t, 2.0);
+    u = std::nextafter(u, -2.0);
+    if (!(std::acos(t) < 0.34) || !(M_PI - std::acos(u) < 0.34))
+      return false;
+  }
+  t = *x1;
+  u = *x2;
+  for (int k = 0; k < 64; k++)
+  {
+    t = std::nextafter(t, -2.0);
+    u = std::nextafter(u, 2.0);
+    if (std::acos(t) < 0.34 || M_PI - std::acos(u) < 0.34)
+      return false;
+  }
+  return true;
+}
+
+int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, int64_t* n_handles_out)
+{
+  if (!ctx || !n_handles_out || n_hands < 0 || (n_hands > 0 && !hands) || handle_cap < 0 || idx_cap < 0 || min_inliers < 1)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  *n_handles_out = 0;
+  if (n_hands > 8192)
+  {
+    c->err = "agh_find_handles: more than 8192 hands (the search runs on the hands Learning::classify kept)";
+    return AGH_ERR_CAPACITY;
+  }
+  double x1 = 0, x2 = 0;
+  if (!handle_thresholds(&x1, &x2))
+  {
+    c->err = "agh_find_handles: this libm's acos is not monotone around the 0.34 rad thresholds";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n_hands > c->h_cap || !c->d_h_counts)
+  {
+    const size_t cap = (size_t) std::max<int64_t>(n_hands, 256);
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_h_hands, cap)) || (rc = dev_alloc(c, &c->d_h_bits, cap * ((cap + 63) / 64))) ||
+        (rc = dev_alloc(c, &c->d_h_rowcnt, cap)) || (rc = dev_alloc(c, &c->d_h_first, cap)) ||
+        (rc = dev_alloc(c, &c->d_h_n, cap)) || (rc = dev_alloc(c, &c->d_h_idx, cap)) ||
+        (rc = dev_alloc(c, &c->d_h_counts, 4)) || (rc = dev_alloc(c, &c->d_h_handles, cap)))
+      return rc;
+    c->h_cap = (int64_t) cap;
+  }
+  if (n_hands > 0)
+    HIPCHK(c, hipMemcpyAsync(c->d_h_hands, hands, sizeof(agh_hypothesis) * n_hands, hipMemcpyHostToDevice, c->stream));
+  timing_begin(c, c->stream);
+  int rc = handle_search(c, n_hands, x1, x2, min_inliers, min_length, c->stream);
+  timing_mark(c, "handle_search", c->stream);
+  if (rc != AGH_OK)
+  {
+    c->err = "handle search launch failed";
+    return rc;
+  }
+  int counts[4] = { 0, 0, 0, 0 };
+  HIPCHK(c, hipMemcpyAsync(counts, c->d_h_counts, sizeof(int) * 3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (counts[2])
+  {
+    c->err = "agh_find_handles: a seed hand has more than 2048 inliers";
+    return AGH_ERR_CAPACITY;
+  }
+  *n_handles_out = counts[0];
+  if (counts[0] > handle_cap || counts[1] > idx_cap)
+  {
+    c->err = "agh_find_handles: output buffers too small";
+    return AGH_ERR_CAPACITY;
+  }
+  if (counts[0] > 0)
+  {
+    HIPCHK(c, hipMemcpy(handles_out, c->d_h_handles, sizeof(agh_handle) * counts[0], hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(inlier_idx_out, c->d_h_idx, sizeof(int32_t) * counts[1], hipMemcpyDeviceToHost));
+  }
   return AGH_OK;
 }
 

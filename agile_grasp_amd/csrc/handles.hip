@@ -1,0 +1,324 @@
+// handles.hip -- K5: handle search on the hypotheses.
+//
+// Stands in for HandleSearch::findHandles (reference src/agile_grasp/handle_search.cpp:4-128) and the Handle
+// constructor (src/agile_grasp/handle.cpp:3-74):
+//   K5a k_handle_pairs   the H x H geometric test of :21-45 as a bit matrix (one row of 64-bit words per hand); the two
+//                        acos thresholds become comparisons of the dot products with host-computed constants x1, x2
+//                        (acos is monotone: acos(x) < 0.34 <=> x >= x1, pi - acos(x) < 0.34 <=> x <= x2; the constants
+//                        are found by bisection with the same libm the oracle uses)
+//   K5b k_handle_greedy  the sequential part (:11-19, 47-80): for every still-available seed hand in index order collect
+//                        its available inliers, sort by distance along the seed's axis, cut at the first 2 cm gap
+//                        (shortenHandle, :88-118, with the meaning the oracle states for its out-of-range read), accept
+//                        if long enough, retire the members.  One work-group: the loop is inherently serial, the work
+//                        inside an iteration (mask, compaction, rank sort, gap search) is spread over its 1024 threads.
+//   K5c k_handle_build   Handle::Handle per accepted handle, one wave each.
+#include "agh_internal.h"
+
+namespace agh
+{
+
+constexpr int kHandleListCap = 2048;  // inliers of one seed (LDS)
+
+__device__ __forceinline__ double dot3d(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+__global__ __launch_bounds__(256) void k_handle_pairs(const agh_hypothesis* __restrict__ hands, int H, double x1, double x2,
+  unsigned long long* __restrict__ bits, int W, int* __restrict__ rowcnt)
+{
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const agh_hypothesis& hi = hands[i];
+  const double ia[3] = { hi.axis[0], hi.axis[1], hi.axis[2] };
+  const double ip[3] = { hi.bottom[0], hi.bottom[1], hi.bottom[2] };
+  const double in_[3] = { hi.approach[0], hi.approach[1], hi.approach[2] };
+  int cnt = 0;
+  for (int j0 = 0; j0 < W * 64; j0 += 256)
+  {
+    const int j = j0 + tid;
+    bool inl = false;
+    if (j < H)
+    {
+      const agh_hypothesis& hj = hands[j];
+      const double d[3] = { hj.bottom[0] - ip[0], hj.bottom[1] - ip[1], hj.bottom[2] - ip[2] };
+      double v[3];
+      for (int r = 0; r < 3; r++)  // (I - a a^T) d, row by row, left to right (handle_search.cpp:33)
+      {
+        const double p0 = ((r == 0) ? 1.0 : 0.0) - ia[r] * ia[0];
+        const double p1 = ((r == 1) ? 1.0 : 0.0) - ia[r] * ia[1];
+        const double p2 = ((r == 2) ? 1.0 : 0.0) - ia[r] * ia[2];
+        v[r] = (p0 * d[0] + p1 * d[1]) + p2 * d[2];
+      }
+      const double dist_from_line = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+      const double aa = dot3d(ia, hj.axis), nn = dot3d(in_, hj.approach);
+      inl = dist_from_line < 0.01 && (aa >= x1 || aa <= x2) && nn >= x1;  // :39
+    }
+    const unsigned long long m = __ballot(inl);
+    if (lane == 0 && (j0 + tid) / 64 < W)
+      bits[(int64_t) i * W + (j0 + tid) / 64] = m;
+    cnt += (lane == 0) ? __popcll(m) : 0;
+  }
+  __shared__ int sc[4];
+  if (lane == 0)
+    sc[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0)
+    rowcnt[i] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+struct HandleCounts
+{
+  int n_handles, n_idx, error;
+};
+
+__global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
+  const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
+  int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts)
+{
+  __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
+  __shared__ int wcnt[128];
+  __shared__ double ld[kHandleListCap], sd[kHandleListCap];
+  __shared__ int lj[kHandleListCap], sj[kHandleListCap];
+  __shared__ int s_n, s_gap, s_nh, s_nidx;
+  const int tid = threadIdx.x;
+  if (tid < W)
+  {
+    unsigned long long m = 0;
+    for (int b = 0; b < 64; b++)
+    {
+      const int j = tid * 64 + b;
+      if (j < H && hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
+        m |= 1ull << b;
+    }
+    alive[tid] = m;
+  }
+  if (tid == 0)
+  {
+    s_nh = 0;
+    s_nidx = 0;
+  }
+  __syncthreads();
+  for (int i = 0; i < H; i++)
+  {
+    if (!((alive[i >> 6] >> (i & 63)) & 1ull))
+      continue;
+    if (rowcnt[i] < min_inliers)
+      continue;  // (the available inliers are a subset of the row)
+    // available inliers of seed i: mask, count, compact in ascending j
+    unsigned long long m = 0;
+    if (tid < W)
+    {
+      m = bits[(int64_t) i * W + tid] & alive[tid];
+      wcnt[tid] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      int n = 0;
+      for (int w = 0; w < W; w++)
+      {
+        const int c = wcnt[w];
+        wcnt[w] = n;
+        n += c;
+      }
+      s_n = n;
+      s_gap = 0x7fffffff;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n < min_inliers)
+      continue;  // handle_search.cpp:47-48 (uniform: everybody read the same s_n; the next barrier is in the next pass)
+    if (n > kHandleListCap)
+    {
+      if (tid == 0)
+        counts->error = 1;
+      break;
+    }
+    if (tid < W)
+    {
+      const agh_hypothesis& hi = hands[i];
+      int pos = wcnt[tid];
+      while (m)
+      {
+        const int j = tid * 64 + __ffsll((long long) m) - 1;
+        m &= m - 1ull;
+        const double d[3] = { hands[j].bottom[0] - hi.bottom[0], hands[j].bottom[1] - hi.bottom[1],
+          hands[j].bottom[2] - hi.bottom[2] };
+        ld[pos] = dot3d(hi.axis, d);  // dist_along_line (:34)
+        lj[pos] = j;
+        pos++;
+      }
+    }
+    __syncthreads();
+    // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
+    for (int e = tid; e < n; e += 1024)
+    {
+      const double de = ld[e];
+      const int je = lj[e];
+      int rank = 0;
+      for (int k = 0; k < n; k++)
+        rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
+      sd[rank] = de;
+      sj[rank] = je;
+    }
+    __syncthreads();
+    for (int k = tid; k + 1 < n; k += 1024)  // shortenHandle: first gap > 2 cm (:95-99)
+      if (sd[k + 1] - sd[k] > 0.02)
+        atomicMin(&s_gap, k);
+    __syncthreads();
+    const int kept = s_gap == 0x7fffffff ? n : s_gap;  // the elements before the gap position (:111)
+    bool accept = kept >= min_inliers && kept > 0;
+    if (accept)
+    {
+      // :62-72: minimum and maximum over the kept list with the reference's +-1e7 start values (the list is sorted,
+      // so they are its ends)
+      const double mn = sd[0] < 10000000 ? sd[0] : 10000000;
+      const double mx = sd[kept - 1] > -10000000 ? sd[kept - 1] : -10000000;
+      accept = (mx - mn > min_length);
+    }
+    if (accept)
+    {
+      const int h = s_nh, base = s_nidx;
+      for (int k = tid; k < kept; k += 1024)
+      {
+        inlier_idx[base + k] = sj[k];
+        atomicAnd(&alive[sj[k] >> 6], ~(1ull << (sj[k] & 63)));  // :75-78
+      }
+      __syncthreads();
+      if (tid == 0)
+      {
+        h_first[h] = base;
+        h_n[h] = kept;
+        s_nh = h + 1;
+        s_nidx = base + kept;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    counts->n_handles = s_nh;
+    counts->n_idx = s_nidx;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __restrict__ hands, const int* __restrict__ h_first,
+  const int* __restrict__ h_n, const int* __restrict__ inlier_idx, const HandleCounts* __restrict__ counts,
+  agh_handle* __restrict__ out)
+{
+  const int h = blockIdx.x, lane = threadIdx.x;
+  if (h >= counts->n_handles)
+    return;
+  const int n = h_n[h];
+  const int* in = inlier_idx + h_first[h];
+  // axis_mat * axis_mat^T in the oracle's LaneSum64 order (handle.cpp:14-20)
+  double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+  for (int k = lane; k < n; k += 64)
+  {
+    const double* a = hands[in[k]].axis;
+    m[0] += a[0] * a[0];
+    m[1] += a[0] * a[1];
+    m[2] += a[0] * a[2];
+    m[3] += a[1] * a[1];
+    m[4] += a[1] * a[2];
+    m[5] += a[2] * a[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+    for (int o = 32; o > 0; o >>= 1)
+      m[k] = m[k] + __shfl_xor(m[k], o);
+  double axis[3] = { 0.0, 0.0, 0.0 };
+  if (lane == 0)
+  {
+    double A[3][3] = { { m[0], m[1], m[2] }, { m[1], m[3], m[4] }, { m[2], m[4], m[5] } };
+    double V[3][3], dd[3];
+    jacobi3_serial(A, V, dd);
+    int mx = 0;
+    for (int r = 1; r < 3; r++)
+      if (dd[r] > dd[mx])
+        mx = r;  // maxCoeff: first maximum (handle.cpp:24)
+    for (int r = 0; r < 3; r++)
+      axis[r] = V[r][mx];
+    if (dot3d(axis, hands[in[0]].axis) < 0)  // the sign the oracle fixes (EigenSolver's is arbitrary)
+      for (int r = 0; r < 3; r++)
+        axis[r] *= -1.0;
+  }
+  for (int r = 0; r < 3; r++)
+    axis[r] = __shfl(axis[r], 0);
+  // dist_along_handle, its extremes, the inlier nearest the middle (handle.cpp:28-56)
+  double dmin = INFINITY, dmax = -INFINITY;
+  for (int k = lane; k < n; k += 64)
+  {
+    const double al = dot3d(axis, hands[in[k]].bottom);
+    dmin = fmin(dmin, al);
+    dmax = fmax(dmax, al);
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    dmin = fmin(dmin, __shfl_xor(dmin, o));
+    dmax = fmax(dmax, __shfl_xor(dmax, o));
+  }
+  const double center_dist = (dmax + dmin) / 2.0;
+  double best = 10000000;
+  int best_k = 0x7fffffff;
+  for (int k = lane; k < n; k += 64)
+  {
+    const double dist = fabs(dot3d(axis, hands[in[k]].bottom) - center_dist);
+    if (dist < best)  // strict: the first minimum of this lane's (ascending) positions
+    {
+      best = dist;
+      best_k = k;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    const double ob = __shfl_xor(best, o);
+    const int ok = __shfl_xor(best_k, o);
+    if (ok != 0x7fffffff && (best_k == 0x7fffffff || ob < best || (ob == best && ok < best_k)))
+    {
+      best = ob;
+      best_k = ok;
+    }
+  }
+  if (lane == 0)
+  {
+    const int min_idx = best_k == 0x7fffffff ? 0 : best_k;
+    const agh_hypothesis& c = hands[in[min_idx]];
+    double wsum = 0.0;
+    for (int k = 0; k < n; k++)  // handle.cpp:66-73: an explicit loop, kept sequential
+      wsum += hands[in[k]].width;
+    agh_handle hd;
+    for (int r = 0; r < 3; r++)
+    {
+      hd.axis[r] = axis[r];
+      hd.center[r] = c.bottom[r];
+      hd.approach[r] = c.approach[r];
+      hd.hands_center[r] = c.surface[r];
+    }
+    hd.binormal[0] = c.approach[1] * axis[2] - c.approach[2] * axis[1];
+    hd.binormal[1] = c.approach[2] * axis[0] - c.approach[0] * axis[2];
+    hd.binormal[2] = c.approach[0] * axis[1] - c.approach[1] * axis[0];
+    hd.width = wsum / (double) n;
+    hd.n_inliers = n;
+    hd.first_inlier = h_first[h];
+    out[h] = hd;
+  }
+}
+
+int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st)
+{
+  const int Hi = (int) H, W = (Hi + 63) / 64;
+  hipMemsetAsync(c->d_h_counts, 0, sizeof(HandleCounts), st);
+  if (Hi == 0)
+    return AGH_OK;
+  hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
+    c->d_h_bits, W, c->d_h_rowcnt);
+  hipLaunchKernelGGL(k_handle_greedy, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+    (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+    c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
+  hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
+    (const int*) c->d_h_first, (const int*) c->d_h_n, (const int*) c->d_h_idx,
+    (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+}  // namespace agh

@@ -828,67 +828,6 @@ __device__ __forceinline__ double wave_max_f64_(double v)
   return v;
 }
 
-__device__ inline void jacobi3_serial(double A[3][3], double V[3][3], double d[3])
-{
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++)
-      V[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 30; sweep++)
-  {
-    double off = 0.0;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++)
-        off += A[p][q] * A[p][q];
-    if (off == 0.0)
-      break;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++)
-      {
-        const double apq = A[p][q];
-        if (apq == 0.0)
-          continue;
-        const double app = A[p][p], aqq = A[q][q];
-        const double aabs = fabs(apq);
-        if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
-        {
-          A[p][q] = 0.0;
-          A[q][p] = 0.0;
-          continue;
-        }
-        const double theta = (aqq - app) / (2.0 * apq);
-        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-        if (theta < 0.0)
-          t = -t;
-        const double c = 1.0 / sqrt(t * t + 1.0);
-        const double s = t * c;
-        A[p][p] = app - t * apq;
-        A[q][q] = aqq + t * apq;
-        A[p][q] = 0.0;
-        A[q][p] = 0.0;
-        for (int k = 0; k < 3; k++)
-        {
-          if (k == p || k == q)
-            continue;
-          const double akp = A[k][p], akq = A[k][q];
-          const double np_ = c * akp - s * akq;
-          const double nq_ = s * akp + c * akq;
-          A[k][p] = np_;
-          A[p][k] = np_;
-          A[k][q] = nq_;
-          A[q][k] = nq_;
-        }
-        for (int k = 0; k < 3; k++)
-        {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < 3; i++)
-    d[i] = A[i][i];
-}
-
 template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,

@@ -136,6 +136,24 @@ int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t
   const double workspace[6], double cell_size, int64_t* n_voxels_out);
 int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
   int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream);
+/* HandleSearch::findHandles + Handle (handle_search.cpp:4-128, handle.cpp:3-74) on a list of hypotheses (normally the
+ * ones Learning::classify kept; grasp_localizer.cpp:103 passes min_inliers from the launch file and min_length 0.005).
+ * handles_out receives up to handle_cap records, inlier_idx_out the concatenated inlier lists (indices into hands, in
+ * the order handle.cpp sees them).  At most 8192 hands and 2048 inliers per seed (AGH_ERR_CAPACITY beyond). */
+typedef struct agh_handle
+{
+  double axis[3];         /* Handle::getAxis: principal direction of the inliers' axes (sign: that of the first inlier) */
+  double center[3];       /* getCenter: grasp bottom of the inlier nearest the middle of the handle */
+  double approach[3];     /* getApproach */
+  double binormal[3];     /* approach x axis */
+  double hands_center[3]; /* getHandsCenter: grasp surface of that inlier */
+  double width;           /* getWidth: mean grasp width of the inliers */
+  int32_t n_inliers;
+  int32_t first_inlier;   /* offset of this handle's inliers in inlier_idx_out */
+} agh_handle;
+int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, int64_t* n_handles_out);
+
 /* The context's current cloud: packed xyz (3 floats per point) and camera ids; returns the number of points. */
 int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
 

@@ -1692,4 +1692,162 @@ int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64
   return k;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// f2: HandleSearch::findHandles (/root/reference/src/agile_grasp/handle_search.cpp:4-128) and Handle
+// (/root/reference/src/agile_grasp/handle.cpp:3-74), literal, with three places given a defined meaning:
+//  * shortenHandle reads inliers[i](2) of a Vector2d (handle_search.cpp:103).  In the reference's build
+//    (-DNDEBUG -O3, CMakeLists.txt:18) that is the first component of the NEXT vector element, an inlier index >= 0,
+//    so the `< 0` branch is never taken: the list is cut to the elements BEFORE position i (element i itself is
+//    dropped, :111) and the loop in findHandles runs once.
+//  * std::sort with LastElementComparator leaves the order of equal distances open; here ties are ordered by index.
+//  * Eigen::EigenSolver returns the axis with an arbitrary sign; here it agrees with the first inlier's axis.
+//    axis_mat * axis_mat^T is an Eigen product: LaneSum64 order, like M3 in fit_frame.
+static double safe_acos(double x) /* handle_search.cpp:120-127 */
+{
+  if (x < -1.0)
+    x = -1.0;
+  else if (x > 1.0)
+    x = 1.0;
+  return std::acos(x);
+}
+
+int64_t orc_find_handles(const orc_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
+  orc_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx, int64_t idx_cap)
+{
+  const int64_t H = n_hands;
+  std::vector<double> width((size_t) H);
+  for (int64_t i = 0; i < H; i++)
+    width[(size_t) i] = hands[i].width;
+  int64_t n_handles = 0, n_idx = 0;
+  for (int64_t i = 0; i < H; i++)
+  {
+    if (width[(size_t) i] == -1)
+      continue;
+    const double* ia = hands[i].axis;
+    const double* ip = hands[i].bottom;
+    const double* in_ = hands[i].approach;
+    std::vector<std::pair<double, int32_t>> inl; /* (dist_along_line, j) */
+    for (int64_t j = 0; j < H; j++)
+    {
+      if (width[(size_t) j] == -1)
+        continue;
+      const double* ja = hands[j].axis;
+      const double* jp = hands[j].bottom;
+      const double* jn = hands[j].approach;
+      const double d[3] = { jp[0] - ip[0], jp[1] - ip[1], jp[2] - ip[2] };
+      double v[3];
+      for (int r = 0; r < 3; r++) /* (I - a a^T) d, row by row, left to right */
+      {
+        const double p0 = ((r == 0) ? 1.0 : 0.0) - ia[r] * ia[0];
+        const double p1 = ((r == 1) ? 1.0 : 0.0) - ia[r] * ia[1];
+        const double p2 = ((r == 2) ? 1.0 : 0.0) - ia[r] * ia[2];
+        v[r] = (p0 * d[0] + p1 * d[1]) + p2 * d[2];
+      }
+      const double dist_from_line = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+      const double dist_along_line = (ia[0] * d[0] + ia[1] * d[1]) + ia[2] * d[2];
+      const double aa = (ia[0] * ja[0] + ia[1] * ja[1]) + ia[2] * ja[2];
+      const double ang0 = safe_acos(aa), ang1 = M_PI - safe_acos(aa);
+      const double dist_angle_axis = ang1 < ang0 ? ang1 : ang0; /* Eigen minCoeff */
+      const double dist_from_normal = safe_acos((in_[0] * jn[0] + in_[1] * jn[1]) + in_[2] * jn[2]);
+      if (dist_from_line < 0.01 && dist_angle_axis < 0.34 && dist_from_normal < 0.34)
+        inl.push_back(std::make_pair(dist_along_line, (int32_t) j));
+    }
+    if ((int64_t) inl.size() < min_inliers)
+      continue;
+    std::sort(inl.begin(), inl.end()); /* (distance, index) */
+    for (size_t k = 0; k + 1 < inl.size(); k++)
+      if (inl[k + 1].first - inl[k].first > 0.02) /* handle_gap_threshold */
+      {
+        inl.resize(k);
+        break;
+      }
+    if ((int64_t) inl.size() < min_inliers)
+      continue;
+    double min_dist = 10000000, max_dist = -10000000;
+    for (size_t k = 0; k < inl.size(); k++)
+    {
+      if (inl[k].first < min_dist)
+        min_dist = inl[k].first;
+      if (inl[k].first > max_dist)
+        max_dist = inl[k].first;
+    }
+    if (!(max_dist - min_dist > min_length))
+      continue;
+    /* ---- Handle(hand_list, in) ---- */
+    const int n = (int) inl.size();
+    orc_handle hd;
+    std::memset(&hd, 0, sizeof(hd));
+    double M3[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int q = r; q < 3; q++)
+      {
+        LaneSum64 acc;
+        for (int k = 0; k < n; k++)
+          acc.add(k, hands[inl[(size_t) k].second].axis[r] * hands[inl[(size_t) k].second].axis[q]);
+        M3[r][q] = acc.total();
+        M3[q][r] = M3[r][q];
+      }
+    double V3[3][3], d3[3];
+    jacobi_sym<3>(M3, V3, d3);
+    int mx = 0;
+    for (int r = 1; r < 3; r++)
+      if (d3[r] > d3[mx])
+        mx = r; /* maxCoeff: first maximum */
+    double axis[3] = { V3[0][mx], V3[1][mx], V3[2][mx] };
+    if (dot3(axis, hands[inl[0].second].axis) < 0)
+      for (int r = 0; r < 3; r++)
+        axis[r] *= -1.0;
+    double dmin = 0, dmax = 0;
+    std::vector<double> along((size_t) n);
+    for (int k = 0; k < n; k++)
+    {
+      along[(size_t) k] = dot3(axis, hands[inl[(size_t) k].second].bottom);
+      if (k == 0 || along[(size_t) k] < dmin)
+        dmin = along[(size_t) k];
+      if (k == 0 || along[(size_t) k] > dmax)
+        dmax = along[(size_t) k];
+    }
+    const double center_dist = (dmax + dmin) / 2.0;
+    double best = 10000000;
+    int min_idx = -1;
+    for (int k = 0; k < n; k++)
+    {
+      const double dist = std::fabs(along[(size_t) k] - center_dist);
+      if (dist < best)
+      {
+        best = dist;
+        min_idx = k;
+      }
+    }
+    if (min_idx < 0)
+      min_idx = 0; /* (the reference would index with -1 if every distance were >= 1e7 or NaN) */
+    const orc_hypothesis& c = hands[inl[(size_t) min_idx].second];
+    double wsum = 0.0;
+    for (int k = 0; k < n; k++)
+      wsum += hands[inl[(size_t) k].second].width;
+    for (int r = 0; r < 3; r++)
+    {
+      hd.axis[r] = axis[r];
+      hd.center[r] = c.bottom[r];
+      hd.approach[r] = c.approach[r];
+      hd.hands_center[r] = c.surface[r];
+    }
+    cross3(c.approach, axis, hd.binormal);
+    hd.width = wsum / (double) n;
+    hd.n_inliers = n;
+    hd.first_inlier = (int32_t) n_idx;
+    if (n_handles < handle_cap)
+      handles_out[n_handles] = hd;
+    for (int k = 0; k < n; k++)
+    {
+      if (n_idx < idx_cap)
+        inlier_idx[n_idx] = inl[(size_t) k].second;
+      n_idx++;
+      width[(size_t) inl[(size_t) k].second] = -1; /* eliminate from future search (handle_search.cpp:75-78) */
+    }
+    n_handles++;
+  }
+  return n_handles;
+}
+
 } // extern "C"

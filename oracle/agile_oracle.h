@@ -118,6 +118,25 @@ void orc_glibc_rand(uint32_t seed, int32_t* out, int64_t count);
 /* generalized eigen reduction exposed for the LAPACK goldens: M,N 10x10 row-major; v_out 10. */
 int orc_solve_taubin(const double* M, const double* N, double* v_out, double* lambda_out);
 
+/* f2: HandleSearch::findHandles + Handle (handle_search.cpp:4-128, handle.cpp:3-74). */
+typedef struct orc_handle
+{
+  double axis[3];         /* eigenvector of the largest eigenvalue of sum(axis axis^T) (handle.cpp:12-26), sign made
+                             to agree with the first inlier's axis (Eigen::EigenSolver's sign is arbitrary) */
+  double center[3];       /* grasp bottom of the inlier nearest the middle of the handle (handle.cpp:39-56) */
+  double approach[3];
+  double binormal[3];     /* approach x axis */
+  double hands_center[3]; /* grasp surface of that inlier */
+  double width;           /* mean grasp width of the inliers (handle.cpp:66-74) */
+  int32_t n_inliers;
+  int32_t first_inlier;   /* offset of this handle's inlier list in the index array */
+} orc_handle;
+
+/* Returns the number of handles (<0 on error); inlier_idx receives the concatenated inlier lists (indices into hands,
+ * in the order handle.cpp sees them: ascending distance along the seed hand's axis). */
+int64_t orc_find_handles(const orc_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
+  orc_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx, int64_t idx_cap);
+
 /* f1: NaN removal + workspace box + per-camera voxelisation (localization.cpp:17-45,216-355).  xyz_out 3*cap floats,
  * cam_out cap ints; returns the number of voxels (may exceed cap: then only cap are written). */
 int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,

@@ -242,3 +242,24 @@ def preprocess(xyz: np.ndarray, size_left: int, workspace, cell_size: float = 0.
           C.c_int(1 if dense else 0), _fp(ws, C.c_double), C.c_double(cell_size), _fp(out, C.c_float),
           _fp(cam, C.c_int32), C.c_int64(out.shape[0]))
     return out[:k].copy(), cam[:k].copy()
+
+
+HANDLE_DTYPE = np.dtype([("axis", "<f8", 3), ("center", "<f8", 3), ("approach", "<f8", 3), ("binormal", "<f8", 3),
+                         ("hands_center", "<f8", 3), ("width", "<f8"), ("n_inliers", "<i4"), ("first_inlier", "<i4")])
+assert HANDLE_DTYPE.itemsize == 136
+
+
+def find_handles(hands: np.ndarray, min_inliers: int = 3, min_length: float = 0.005):
+    """HandleSearch::findHandles + Handle (handle_search.cpp:4-128, handle.cpp:3-74) on hypothesis records."""
+    hands = np.ascontiguousarray(hands, HYP_DTYPE)
+    H = hands.shape[0]
+    out = np.zeros(max(H, 1), HANDLE_DTYPE)
+    idx = np.zeros(max(H, 1), np.int32)
+    f = lib().orc_find_handles
+    f.restype = C.c_int64
+    n = f(hands.ctypes.data_as(C.c_void_p), C.c_int64(H), C.c_int32(min_inliers), C.c_double(min_length),
+          out.ctypes.data_as(C.c_void_p), C.c_int64(out.shape[0]), _fp(idx, C.c_int32), C.c_int64(idx.shape[0]))
+    assert n >= 0
+    out = out[:n].copy()
+    total = int(out["n_inliers"].sum())
+    return out, idx[:total].copy()

@@ -185,3 +185,47 @@ def preprocess(xyz, size_left, ws, cell=0.003, dense=False):
         outs.append((vx.astype(np.float64) * cell + mn).astype(np.float32))
         cams.append(np.full(len(vx), c, np.int32))
     return np.concatenate(outs), np.concatenate(cams)
+
+
+def find_handles(hands, min_inliers=3, min_length=0.005):
+    """Second transcription of HandleSearch::findHandles + Handle (handle_search.cpp:4-128, handle.cpp:3-74), with the
+    oracle's three stated choices (cut keeps the elements before the gap position, ties by index, axis sign).  Returns
+    [(inlier index list, axis, center, approach, binormal, hands_center, width)]."""
+    H = len(hands)
+    width = hands["width"].astype(np.float64).copy()
+    res = []
+    for i in range(H):
+        if width[i] == -1:
+            continue
+        ia, ip, inn = hands["axis"][i], hands["bottom"][i], hands["approach"][i]
+        inl = []
+        for j in range(H):
+            if width[j] == -1:
+                continue
+            d = hands["bottom"][j] - ip
+            P = np.eye(3) - np.outer(ia, ia)
+            v = np.array([(P[r, 0] * d[0] + P[r, 1] * d[1]) + P[r, 2] * d[2] for r in range(3)])
+            dist_line = math.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+            along = (ia[0] * d[0] + ia[1] * d[1]) + ia[2] * d[2]
+            sa = lambda x: math.acos(min(1.0, max(-1.0, x)))
+            aa = (ia[0] * hands["axis"][j][0] + ia[1] * hands["axis"][j][1]) + ia[2] * hands["axis"][j][2]
+            nn = (inn[0] * hands["approach"][j][0] + inn[1] * hands["approach"][j][1]) + inn[2] * hands["approach"][j][2]
+            if dist_line < 0.01 and min(sa(aa), math.pi - sa(aa)) < 0.34 and sa(nn) < 0.34:
+                inl.append((along, j))
+        if len(inl) < min_inliers:
+            continue
+        inl.sort()
+        for k in range(len(inl) - 1):
+            if inl[k + 1][0] - inl[k][0] > 0.02:
+                inl = inl[:k]
+                break
+        if len(inl) < min_inliers:
+            continue
+        ds = [a for a, _ in inl]
+        if not (max(ds) - min(ds) > min_length):
+            continue
+        idx = [j for _, j in inl]
+        res.append(idx)
+        for j in idx:
+            width[j] = -1
+    return res
