@@ -54,6 +54,26 @@ public:
   void setHalfAntipodal(bool b) { half_antipodal_ = b; }
   void setGraspWidth(double w) { grasp_width_ = w; }
 
+  /** The geometric fields as an ABI record (input of agh_find_handles). */
+  void toRecord(agh_hypothesis& h) const
+  {
+    h = agh_hypothesis();
+    for (int r = 0; r < 3; r++)
+    {
+      h.axis[r] = axis_(r);
+      h.approach[r] = approach_(r);
+      h.binormal[r] = binormal_(r);
+      h.bottom[r] = grasp_bottom_(r);
+      h.surface[r] = grasp_surface_(r);
+    }
+    h.width = grasp_width_;
+    h.cam_source = cam_source_;
+    h.n_in_box = n_points_for_learning_;
+    h.half_antipodal = half_antipodal_ ? 1 : 0;
+    h.full_antipodal = full_antipodal_ ? 1 : 0;
+    h.valid = 1;
+  }
+
   /** Number of columns the reference's points_for_learning_ would have (grasp_hypothesis.h:220).  The points
    *  themselves stay on the GPU as the 80x100 occupancy image that Learning::classify consumes. */
   int getNumPointsForLearning() const { return n_points_for_learning_; }

@@ -4,8 +4,7 @@
 // predictAntipodalHands(hand_list, svm_filename), filterHands.  The preprocessing that precedes the hot path
 // (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355; its output ORDER defines
 // the point indices the search works on) runs on the GPU as well (agh_preprocess).  Not carried over: the RANSAC table-plane removal behind
-// uses_clustering (localization.cpp:51-98, pcl::SACSegmentation; training path only), findHandles (HandleSearch, out of
-// scope), the Plot members, and the PCD-filename overloads unless PCL is available.
+// uses_clustering (localization.cpp:51-98, pcl::SACSegmentation; training path only), the Plot members, and the PCD-filename overloads unless PCL is available.
 #ifndef AGILE_GRASP_AMD_LOCALIZATION_H
 #define AGILE_GRASP_AMD_LOCALIZATION_H
 
@@ -16,6 +15,7 @@
 #include <vector>
 
 #include "hand_search.h"
+#include "handle_search.h"
 #include "learning.h"
 
 namespace agile_grasp_amd
@@ -136,6 +136,18 @@ public:
     std::vector<GraspHypothesis> antipodal_hands = learn.classify(hand_list, svm_filename, cams_mat);
     std::cout << antipodal_hands.size() << " antipodal hand configurations found\n";
     return antipodal_hands;
+  }
+
+  /** localization.cpp:390-409 (the plotting branches aside) */
+  std::vector<Handle> findHandles(const std::vector<GraspHypothesis>& hand_list, int min_inliers, double min_length)
+  {
+    if (!search_)
+    {
+      std::cout << " Error: findHandles needs a preceding localizeHands\n";
+      return std::vector<Handle>();
+    }
+    HandleSearch handle_search(*search_);
+    return handle_search.findHandles(hand_list, min_inliers, min_length);
   }
 
   /** the voxelised cloud and camera ids the last localizeHands searched (what the reference plots) */

@@ -72,5 +72,10 @@ int main(int argc, char** argv)
   for (size_t i = 0; i < hands.size(); i++)
     std::printf("H %.17g %.17g %.17g %.17g\n", hands[i].getGraspSurface()(0), hands[i].getGraspBottom()(1),
       hands[i].getApproach()(2), hands[i].getGraspWidth());
+  // grasp_localizer.cpp:103 runs the handle search on the SVM-positive hands; all hands give the test more material
+  std::vector<Handle> handles = loc.findHandles(hands, 3, 0.005);
+  for (size_t i = 0; i < handles.size(); i++)
+    std::printf("HANDLE %zu %d %.17g %.17g %.17g %.17g\n", handles[i].getInliers().size(), handles[i].getInliers()[0],
+      handles[i].getAxis()(0), handles[i].getCenter()(1), handles[i].getBinormal()(2), handles[i].getWidth());
   return 0;
 }

@@ -200,3 +200,11 @@ def test_localization_facade_matches_c_abi(tmp_path, svm_model):
     hl = [[float(v) for v in l.split()[1:]] for l in lines if l.startswith("H ")]
     for row, h in zip(hl, hyps):
         assert row == [float(h["surface"][0]), float(h["bottom"][1]), float(h["approach"][2]), float(h["width"])]
+    # Localization::findHandles (handle_search.cpp) through the facade = agh_find_handles on the same records
+    hd, idx = ctx.find_handles(hyps, 3, 0.005)
+    rows = [l.split()[1:] for l in lines if l.startswith("HANDLE ")]
+    assert len(rows) == len(hd)
+    for r, h in zip(rows, hd):
+        assert int(r[0]) == h["n_inliers"] and int(r[1]) == idx[h["first_inlier"]]
+        assert [float(v) for v in r[2:]] == [float(h["axis"][0]), float(h["center"][1]), float(h["binormal"][2]),
+                                              float(h["width"])]
