@@ -10,7 +10,7 @@
 //                        its available inliers, sort by distance along the seed's axis, cut at the first 2 cm gap
 //                        (shortenHandle, :88-118, with the meaning the oracle states for its out-of-range read), accept
 //                        if long enough, retire the members.  One work-group: the loop is inherently serial, the work
-//                        inside an iteration (mask, compaction, rank sort, gap search) is spread over its 1024 threads.
+//                        inside an iteration (mask, compaction, rank sort, gap search) is spread over its 256 threads.
 //   K5c k_handle_build   Handle::Handle per accepted handle, one wave each.
 #include "agh_internal.h"
 
@@ -69,11 +69,12 @@ struct HandleCounts
   int n_handles, n_idx, error;
 };
 
-__global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
+__global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
   const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
   int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts)
 {
   __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
+  __shared__ unsigned long long elig[128];   // rows with at least min_inliers inliers at all (no global load per seed)
   __shared__ int wcnt[128];
   __shared__ double ld[kHandleListCap], sd[kHandleListCap];
   __shared__ int lj[kHandleListCap], sj[kHandleListCap];
@@ -81,14 +82,17 @@ __global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __
   const int tid = threadIdx.x;
   if (tid < W)
   {
-    unsigned long long m = 0;
+    unsigned long long m = 0, el = 0;
     for (int b = 0; b < 64; b++)
     {
       const int j = tid * 64 + b;
       if (j < H && hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
         m |= 1ull << b;
+      if (j < H && rowcnt[j] >= min_inliers)
+        el |= 1ull << b;
     }
     alive[tid] = m;
+    elig[tid] = el;
   }
   if (tid == 0)
   {
@@ -98,10 +102,8 @@ __global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __
   __syncthreads();
   for (int i = 0; i < H; i++)
   {
-    if (!((alive[i >> 6] >> (i & 63)) & 1ull))
-      continue;
-    if (rowcnt[i] < min_inliers)
-      continue;  // (the available inliers are a subset of the row)
+    if (!(((alive[i >> 6] & elig[i >> 6]) >> (i & 63)) & 1ull))
+      continue;  // retired, or too few inliers even with every hand available (the available ones are a subset)
     // available inliers of seed i: mask, count, compact in ascending j
     unsigned long long m = 0;
     if (tid < W)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __
     }
     __syncthreads();
     // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
-    for (int e = tid; e < n; e += 1024)
+    for (int e = tid; e < n; e += 256)
     {
       const double de = ld[e];
       const int je = lj[e];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __
       sj[rank] = je;
     }
     __syncthreads();
-    for (int k = tid; k + 1 < n; k += 1024)  // shortenHandle: first gap > 2 cm (:95-99)
+    for (int k = tid; k + 1 < n; k += 256)  // shortenHandle: first gap > 2 cm (:95-99)
       if (sd[k + 1] - sd[k] > 0.02)
         atomicMin(&s_gap, k);
     __syncthreads();
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_handle_greedy(const agh_hypothesis* __
     if (accept)
     {
       const int h = s_nh, base = s_nidx;
-      for (int k = tid; k < kept; k += 1024)
+      for (int k = tid; k < kept; k += 256)
       {
         inlier_idx[base + k] = sj[k];
         atomicAnd(&alive[sj[k] >> 6], ~(1ull << (sj[k] & 63)));  // :75-78
@@ -312,7 +314,7 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
     return AGH_OK;
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
     c->d_h_bits, W, c->d_h_rowcnt);
-  hipLaunchKernelGGL(k_handle_greedy, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+  hipLaunchKernelGGL(k_handle_greedy, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
     (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
     c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
   hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
