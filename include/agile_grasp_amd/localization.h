@@ -1,10 +1,12 @@
 // localization.h -- the Localization facade (include/agile_grasp/localization.h:64-351) over the MI355X hand search.
 //
-// Kept: constructors, every setter, localizeHands(cloud, size_left, indices, calculates_antipodal, uses_clustering),
-// predictAntipodalHands(hand_list, svm_filename), filterHands.  The preprocessing that precedes the hot path
-// (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355; its output ORDER defines
-// the point indices the search works on) runs on the GPU as well (agh_preprocess).  Not carried over: the RANSAC table-plane removal behind
-// uses_clustering (localization.cpp:51-98, pcl::SACSegmentation; training path only), the Plot members, and the PCD-filename overloads unless PCL is available.
+// Kept: constructors, every setter, localizeHands(cloud, size_left, indices, calculates_antipodal, uses_clustering) and
+// its two PCD-filename overloads (pcd_io.h reads PCD files when PCL is absent), predictAntipodalHands(hand_list,
+// svm_filename), findHandles(hand_list, min_inliers, min_length), filterHands.  The preprocessing that precedes the hot
+// path (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355; its output ORDER
+// defines the point indices the search works on) runs on the GPU as well (agh_preprocess).
+// Not carried over: the RANSAC table-plane removal behind uses_clustering (localization.cpp:51-98,
+// pcl::SACSegmentation; training path only) and the Plot members.
 #ifndef AGILE_GRASP_AMD_LOCALIZATION_H
 #define AGILE_GRASP_AMD_LOCALIZATION_H
 
@@ -17,6 +19,7 @@
 #include "hand_search.h"
 #include "handle_search.h"
 #include "learning.h"
+#include "pcd_io.h"
 
 namespace agile_grasp_amd
 {
@@ -120,6 +123,45 @@ public:
     last_cloud_ = voxels;
     last_cam_ = pts_cam_source;
     return hand_list;
+  }
+
+  /** localization.cpp:168-173 */
+  std::vector<GraspHypothesis> localizeHands(const std::string& pcd_filename_left, const std::string& pcd_filename_right,
+    bool calculates_antipodal = false, bool uses_clustering = false)
+  {
+    return localizeHands(pcd_filename_left, pcd_filename_right, std::vector<int>(), calculates_antipodal, uses_clustering);
+  }
+
+  /** localization.cpp:175-212 */
+  std::vector<GraspHypothesis> localizeHands(const std::string& pcd_filename_left, const std::string& pcd_filename_right,
+    const std::vector<int>& indices, bool calculates_antipodal = false, bool uses_clustering = false)
+  {
+    PointCloud::Ptr cloud_left(new PointCloud);
+    if (loadPCDFile(pcd_filename_left, *cloud_left) == -1)
+    {
+      std::cout << "Couldn't read pcd_filename_left file: " << pcd_filename_left << " \n";
+      return std::vector<GraspHypothesis>();
+    }
+    if (pcd_filename_right.length() > 0)
+      std::cout << "Loaded left point cloud with " << cloud_left->size() << " data points.\n";
+    else
+      std::cout << "Loaded point cloud with " << cloud_left->size() << " data points.\n";
+    PointCloud::Ptr cloud_right(new PointCloud);
+    if (pcd_filename_right.length() > 0)
+    {
+      if (loadPCDFile(pcd_filename_right, *cloud_right) == -1)
+      {
+        std::cout << "Couldn't read pcd_filename_left file: " << pcd_filename_right << " \n";
+        return std::vector<GraspHypothesis>();
+      }
+      std::cout << "Loaded right point cloud with " << cloud_right->size() << " data points.\n";
+    }
+    std::cout << "Concatenating point clouds ...\n";
+    PointCloud::Ptr cloud(new PointCloud);
+    *cloud = *cloud_left;  // *cloud_left + *cloud_right (pcl::PointCloud::operator+ also ANDs is_dense)
+    cloud->points.insert(cloud->points.end(), cloud_right->points.begin(), cloud_right->points.end());
+    cloud->is_dense = cloud_left->is_dense && cloud_right->is_dense;
+    return localizeHands(cloud, (int) cloud_left->size(), indices, calculates_antipodal, uses_clustering);
   }
 
   /** localization.cpp:142-167 */

@@ -20,6 +20,7 @@
 
 #ifdef AGILE_GRASP_AMD_HAVE_PCL_EIGEN
 #include <Eigen/Dense>
+#include <pcl/io/pcd_io.h>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
 
@@ -34,6 +35,7 @@ typedef Eigen::VectorXd VectorXd;
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
 inline bool cloud_is_dense(const PointCloud& c) { return c.is_dense; }
+inline int loadPCDFile(const std::string& f, PointCloud& c) { return pcl::io::loadPCDFile<pcl::PointXYZRGBA>(f, c); }
 }  // namespace agile_grasp_amd
 
 #else  // stand-ins

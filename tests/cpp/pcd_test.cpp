@@ -1,0 +1,81 @@
+// pcd_test.cpp -- the PCD-filename entry point of the facade (localization.cpp:175-212) and the message builders
+// (grasp_localizer.cpp:107-180), the way src/nodes/test.cpp and src/tests/test_local_axes.cpp use the reference.
+//   pcd_test parse <file.pcd>                       -> point count, is_dense and a checksum (no GPU needed)
+//   pcd_test run <left.pcd> <right.pcd> <svm> <ws6 as "a,b,c,d,e,f"> <cam_left3> <cam_right3> <idx,idx,...>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "agile_grasp_amd/localization.h"
+
+using namespace agile_grasp_amd;
+
+static std::vector<double> parse_list(const char* s)
+{
+  std::vector<double> v;
+  std::stringstream ss(s);
+  for (std::string tok; std::getline(ss, tok, ',');)
+    v.push_back(std::atof(tok.c_str()));
+  return v;
+}
+
+int main(int argc, char** argv)
+{
+  if (argc >= 3 && std::strcmp(argv[1], "parse") == 0)
+  {
+    PointCloud c;
+    if (loadPCDFile(argv[2], c) == -1)
+    {
+      std::printf("LOAD_FAILED\n");
+      return 0;
+    }
+    double sum = 0;
+    unsigned long long col = 0;
+    size_t nan = 0;
+    for (size_t i = 0; i < c.points.size(); i++)
+    {
+      const PointXYZRGBA& p = c.points[i];
+      if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))
+        sum += (double) p.x + 2.0 * (double) p.y + 3.0 * (double) p.z;
+      else
+        nan++;
+      col += p.rgba;
+    }
+    std::printf("PCD %zu %d %zu %.17g %llu\n", c.points.size(), c.is_dense ? 1 : 0, nan, sum, col);
+    return 0;
+  }
+  if (argc < 9 || std::strcmp(argv[1], "run") != 0)
+    return 2;
+  const std::vector<double> ws = parse_list(argv[5]), cl = parse_list(argv[6]), cr = parse_list(argv[7]), ix = parse_list(argv[8]);
+  Matrix4d tl, tr;
+  for (int r = 0; r < 3; r++)
+  {
+    tl(r, 3) = cl[(size_t) r];
+    tr(r, 3) = cr[(size_t) r];
+  }
+  Localization loc(1, false, 0);
+  loc.setCameraTransforms(tl, tr);
+  VectorXd w(6);
+  for (int i = 0; i < 6; i++)
+    w(i) = ws[(size_t) i];
+  loc.setWorkspace(w);
+  loc.setDeterministicNormalEstimation(true);
+  std::vector<int> idx;
+  for (size_t i = 0; i < ix.size(); i++)
+    idx.push_back((int) ix[i]);
+  std::vector<GraspHypothesis> hands = loc.localizeHands(std::string(argv[2]), std::string(argv[3]), idx, false, false);
+  std::vector<GraspHypothesis> kept = loc.predictAntipodalHands(hands, argv[4]);
+  std::vector<Handle> handles = loc.findHandles(hands, 3, 0.005);
+  const Grasps m_hands = createGraspsMsg(hands), m_handles = createGraspsMsg(handles), m_in = createGraspsMsgFromHands(handles);
+  std::printf("RESULT %zu %zu %zu %zu %zu %zu\n", loc.getSearchedCloud() ? loc.getSearchedCloud()->size() : (size_t) 0,
+    hands.size(), kept.size(), handles.size(), m_handles.grasps.size(), m_in.grasps.size());
+  for (size_t i = 0; i < m_hands.grasps.size(); i++)
+    std::printf("G %.17g %.17g %.17g %.17g %.9g\n", m_hands.grasps[i].center(0), m_hands.grasps[i].axis(1),
+      m_hands.grasps[i].approach(2), m_hands.grasps[i].surface_center(0), (double) m_hands.grasps[i].width);
+  for (size_t i = 0; i < m_handles.grasps.size(); i++)
+    std::printf("HG %.17g %.17g %.17g %.17g %.9g\n", m_handles.grasps[i].center(0), m_handles.grasps[i].axis(1),
+      m_handles.grasps[i].approach(2), m_handles.grasps[i].surface_center(0), (double) m_handles.grasps[i].width);
+  return 0;
+}

@@ -208,3 +208,100 @@ def test_localization_facade_matches_c_abi(tmp_path, svm_model):
         assert int(r[0]) == h["n_inliers"] and int(r[1]) == idx[h["first_inlier"]]
         assert [float(v) for v in r[2:]] == [float(h["axis"][0]), float(h["center"][1]), float(h["binormal"][2]),
                                               float(h["width"])]
+
+
+# ---- row f3: PCD files and message fields without PCL / ROS ----
+def _build_pcd(tmp_path):
+    from agile_grasp_amd import build
+
+    build.build()
+    exe = str(tmp_path / "pcd_test")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "pcd_test.cpp"), "-o", exe, "-L" + libdir,
+                           "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _write_pcd(path, xyz, binary, with_rgb=True):
+    """A PCD v0.7 file as pcl::io::savePCDFile{ASCII,Binary} writes pcl::PointXYZRGBA clouds (x y z rgba, rgba TYPE U)."""
+    n = len(xyz)
+    rgba = (np.arange(n, dtype=np.uint32) * 2654435761 & 0xffffffff).astype(np.uint32)
+    hdr = ["# .PCD v0.7 - Point Cloud Data file format", "VERSION 0.7"]
+    if with_rgb:
+        hdr += ["FIELDS x y z rgba", "SIZE 4 4 4 4", "TYPE F F F U", "COUNT 1 1 1 1"]
+    else:
+        hdr += ["FIELDS x y z", "SIZE 4 4 4", "TYPE F F F", "COUNT 1 1 1"]
+    hdr += [f"WIDTH {n}", "HEIGHT 1", "VIEWPOINT 0 0 0 1 0 0 0", f"POINTS {n}", "DATA " + ("binary" if binary else "ascii")]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode())
+        if binary:
+            rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")] + ([("c", "<u4")] if with_rgb else []))
+            rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+            if with_rgb:
+                rec["c"] = rgba
+            f.write(rec.tobytes())
+        else:
+            for i in range(n):
+                vals = ["nan" if not np.isfinite(v) else repr(float(np.float32(v))) for v in xyz[i]]
+                f.write((" ".join(vals) + (f" {int(rgba[i])}" if with_rgb else "") + "\n").encode())
+    return rgba
+
+
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("with_rgb", [False, True])
+def test_pcd_reader(tmp_path, binary, with_rgb):
+    exe = _build_pcd(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    xyz = xyz[:3000]
+    path = str(tmp_path / "c.pcd")
+    rgba = _write_pcd(path, xyz, binary, with_rgb)
+    out = subprocess.run([exe, "parse", path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    tok = [l for l in out.stdout.splitlines() if l.startswith("PCD")][0].split()
+    fin = np.isfinite(xyz).all(1)
+    x = xyz[fin].astype(np.float64)
+    exp = 0.0
+    for r in x:  # the same left-to-right accumulation as the test executable
+        exp += r[0] + 2.0 * r[1] + 3.0 * r[2]
+    assert int(tok[1]) == len(xyz) and int(tok[2]) == int(fin.all()) and int(tok[3]) == int((~fin).sum())
+    assert float(tok[4]) == exp
+    assert int(tok[5]) == (int(rgba.astype(np.uint64).sum()) if with_rgb else 0)
+    bad = subprocess.run([exe, "parse", str(tmp_path / "missing.pcd")], capture_output=True, text=True, timeout=120)
+    assert "LOAD_FAILED" in bad.stdout
+
+
+@pytest.mark.gpu
+def test_pcd_entry_point_and_messages(tmp_path, svm_model):
+    from agile_grasp_amd import binding
+
+    exe = _build_pcd(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    left, right = str(tmp_path / "l.pcd"), str(tmp_path / "r.pcd")
+    _write_pcd(left, xyz[:size_left], True)
+    _write_pcd(right, xyz[size_left:], False)
+    vox, vcam = _preprocess_numpy(xyz, size_left, ws)
+    idx = np.sort(np.random.default_rng(0).permutation(len(vox))[:48]).astype(np.int32)
+    args = [exe, "run", left, right, os.path.join(GOLD, "svm_032015_linear_20_20_same"), ",".join(repr(float(v)) for v in ws),
+            ",".join(repr(float(v)) for v in cams[0]), ",".join(repr(float(v)) for v in cams[1]),
+            ",".join(str(int(i)) for i in idx)]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    res = [l for l in lines if l.startswith("RESULT")][0].split()
+    ctx = binding.Context(cams)
+    ctx.set_cloud(vox, vcam)
+    hyps = ctx.find_hands(idx)
+    ctx.load_svm(*svm_model)
+    keep = ctx.classify()
+    hd, hidx = ctx.find_handles(hyps, 3, 0.005)
+    assert [int(v) for v in res[1:]] == [len(vox), len(hyps), int(keep.sum()), len(hd), len(hd), len(hidx)]
+    g = [[float(v) for v in l.split()[1:]] for l in lines if l.startswith("G ")]
+    assert len(g) == len(hyps) > 0
+    for row, h in zip(g, hyps):  # msg/Grasp.msg fields as grasp_localizer.cpp:137-146 fills them (width is Float32)
+        assert row[:4] == [float(h["bottom"][0]), float(h["axis"][1]), float(h["approach"][2]), float(h["surface"][0])]
+        assert np.float32(row[4]) == np.float32(h["width"])  # (%.9g round-trips a float32)
+    hg = [[float(v) for v in l.split()[1:]] for l in lines if l.startswith("HG ")]
+    for row, h in zip(hg, hd):
+        assert row[:4] == [float(h["center"][0]), float(h["axis"][1]), float(h["approach"][2]), float(h["hands_center"][0])]
+        assert np.float32(row[4]) == np.float32(h["width"])
