@@ -355,3 +355,30 @@ def test_full_size_c2_against_oracle(svm_model):
     okeep, _ = O.classify(ref["images"], w, rho)
     assert np.array_equal(keep, okeep)
     assert len(hyps) > 300
+
+
+def test_large_sample_list_matches_small_one(tiny_scene):
+    """70 000 samples (the list of 64 repeated) take the large-S paths -- three-kernel concatenation, many tiles in the
+    scheduling sort, thousands of eigen work-groups -- and must give, position by position, what the 64 give."""
+    sc = tiny_scene
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    base = ctx.find_hands(sc.samples)
+    reps = 70_000 // sc.samples.size + 1
+    big_idx = np.tile(sc.samples, reps)[:70_000].astype(np.int32)
+    big = ctx.find_hands(big_idx)
+    per = {}
+    for h in base:
+        per.setdefault(int(h["sample"]), []).append(h)
+    exp_n = sum(len(per.get(p % sc.samples.size, [])) for p in range(len(big_idx)))
+    assert len(big) == exp_n and len(base) > 0
+    # sample-major order, orientation ascending inside a sample
+    assert (np.diff(big["sample"]) >= 0).all()
+    pos = 0
+    for p in range(0, len(big_idx), 997):  # spot-check every 997th position in full
+        rows = big[big["sample"] == p]
+        ref = per.get(p % sc.samples.size, [])
+        assert len(rows) == len(ref)
+        for r, q in zip(rows, ref):
+            for f in FLOAT_FIELDS + ("orientation", "cam_source", "n_in_box", "finger_index", "depth_index"):
+                assert np.array_equal(r[f], q[f]), (p, f)
