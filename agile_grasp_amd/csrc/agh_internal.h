@@ -297,11 +297,17 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
       const double dy = fmax(fmax(y0 - (double) qy, (double) qy - (y0 + g.cell)), 0.0);
       const double dz = fmax(fmax(z0 - (double) qz, (double) qz - (z0 + g.cell)), 0.0);
       int b = 0, len = 0;
-      if (dy * dy + dz * dz <= rpad * rpad)
+      const double rem = rpad * rpad - (dy * dy + dz * dz);
+      if (rem >= 0.0)
       {
+        // the ball's chord along x at this row: a point of the row within rpad of q has |x - qx| <= sqrt(rem)
+        // (dy, dz are the smallest possible offsets), so only the cells under the chord are candidates -- about a
+        // third fewer than the bounding box's
+        const double xr = sqrt(rem);
+        const int lxr = max(lx, cell_coord(g, (double) qx - xr, 0)), hxr = min(hx, cell_coord(g, (double) qx + xr, 0));
         const int base = (cz * g.dim[1] + cy) * g.dim[0];
-        b = gv.cell_start[base + lx];
-        len = gv.cell_start[base + hx + 1] - b;
+        b = gv.cell_start[base + lxr];
+        len = gv.cell_start[base + hxr + 1] - b;
       }
       rt.begin[t] = b;
       rt.prefix[t + 1] = len;

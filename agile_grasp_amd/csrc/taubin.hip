@@ -82,8 +82,17 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
     for (int t = lane; t < nrw && t < kMaxRows; t += 64)
     {
       const int cy = ly + t % ny, cz = lz + t / ny;
-      const int base = (cz * g.dim[1] + cy) * g.dim[0];
-      w += gv.cell_start[base + hx + 1] - gv.cell_start[base + lx];
+      const double y0 = g.mn[1] + cy * g.cell, z0 = g.mn[2] + cz * g.cell;  // the row's chord, as build_rows clips it
+      const double dy = fmax(fmax(y0 - (double) qy, (double) qy - (y0 + g.cell)), 0.0);
+      const double dz = fmax(fmax(z0 - (double) qz, (double) qz - (z0 + g.cell)), 0.0);
+      const double rem = rpad_w * rpad_w - (dy * dy + dz * dz);
+      if (rem >= 0.0)
+      {
+        const double xr = sqrt(rem);
+        const int lxr = max(lx, cell_coord(g, (double) qx - xr, 0)), hxr = min(hx, cell_coord(g, (double) qx + xr, 0));
+        const int base = (cz * g.dim[1] + cy) * g.dim[0];
+        w += gv.cell_start[base + hxr + 1] - gv.cell_start[base + lxr];
+      }
     }
     for (int o = 32; o > 0; o >>= 1)
       w += __shfl_xor(w, o);
