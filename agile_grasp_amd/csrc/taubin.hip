@@ -6,17 +6,21 @@
 //
 // Three kernels, one launch each per batch of samples:
 //   k_taubin_moments<CAP>  one 256-thread workgroup per sample: coalesced float4 reads of the cell-sorted cloud
-//                          for the <= 16 grid rows the ball touches, FLANN float32 distance filter, LDS compaction,
-//                          LDS bucket sort into the radius search's (d2, index) order, then the 37 distinct sums
-//                          behind M and N accumulated SEQUENTIALLY in that order (64-neighbour chunks: all four
-//                          waves form the products, 37 lanes run the 37 dependent add chains) -- the same fp64
-//                          operation order as the reference loop, so the sums are bit-identical to the CPU path.
+//                          for the <= 16 chord-clipped grid rows the ball touches (row per wave, loads one segment
+//                          ahead), FLANN float32 distance filter, LDS compaction, LDS bucket sort into the radius
+//                          search's (d2, index) order, then the 37 distinct sums behind M and N accumulated
+//                          SEQUENTIALLY in that order (56-neighbour chunks: all four waves form the products, 37 lanes
+//                          run the 37 dependent add chains) -- the same fp64 operation order as the reference loop, so
+//                          the sums are bit-identical to the CPU path.  One wave also computes the sample's
+//                          scheduling weight for the kernels that follow.
 //   k_taubin_eigen         four samples per wave, 9 lanes each: builds M, N, reduces the 10x10 pencil to the 9x9
-//                          symmetric-definite problem, Cholesky + round-robin Jacobi in LDS (same rotation order and
-//                          arithmetic as the CPU path), smallest eigenpair -> quadric parameters.
-//   k_taubin_frame         one workgroup per sample: quadric-gradient normals, the 3x3 scatter of normals
-//                          (sequential sums again) and its Jacobi eigenvectors on wave 0 while the other waves
-//                          already run the n x n (n_i . n_j)^6 column sums; argmax, projection, camera orientation.
+//                          symmetric-definite problem, Cholesky in LDS, round-robin Jacobi in registers without a
+//                          divergent branch (same rotation order and arithmetic as the CPU path), smallest eigenpair
+//                          -> quadric parameters.  One extra work-group sorts the samples longest-first.
+//   k_taubin_frame         one workgroup per sample: quadric-gradient normals; the 3x3 scatter of the normals and the
+//                          n x n (n_i . n_j)^6 column sums in the oracle's LaneSum64 order (64 interleaved partials +
+//                          tree), the latter only for the columns a moment-based estimate cannot rule out; argmax,
+//                          projection, camera orientation.
 // No MFMA: fp64 separately-rounded mul/add is required for bit parity (MFMA fuses), and the work is LDS/VALU bound.
 #include "agh_internal.h"
 
