@@ -70,6 +70,12 @@ def test_full_path_bit_exact(scene_name, svm_model):
     dict(finger_width=0.012, hand_outer_diameter=0.11, hand_depth=0.07, hand_height=0.025, init_bite=0.015),
     dict(finger_width=0.008, hand_outer_diameter=0.075, hand_depth=0.045, hand_height=0.015, init_bite=0.005),
     dict(nn_radius_taubin=0.025, nn_radius_hands=0.07),
+    # radii that change the grid (cell = max(0.02, r_hands / 4)) and the number of rows a ball touches
+    dict(nn_radius_taubin=0.02, nn_radius_hands=0.05),
+    dict(nn_radius_taubin=0.04, nn_radius_hands=0.1, hand_outer_diameter=0.12, hand_depth=0.08),
+    # finger width = slot spacing: coincident thresholds share a look-up cell (the 4-probe kernel instantiation)
+    dict(finger_width=0.01, hand_outer_diameter=0.1),
+    dict(finger_width=0.015, hand_outer_diameter=0.105, hand_depth=0.05, init_bite=0.02, hand_height=0.03),
 ])
 def test_other_hand_geometries_bit_exact(tiny_scene, geom):
     """Finger-slot thresholds, bite depths, look-up tables and radii all derive from the parameters: check parity for
