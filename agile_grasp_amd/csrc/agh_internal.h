@@ -118,6 +118,9 @@ struct Ctx
   float* own_xyz = nullptr;
   int32_t* own_cam = nullptr;
   int64_t own_cap = 0;
+  int64_t own_cap_floats = 0;
+  int32_t* d_idx_own = nullptr;  // device copy of a host sample list
+  int64_t idx_cap = 0;
 
   // preprocessing (K-1)
   VoxDesc* d_vox_desc = nullptr;
@@ -131,7 +134,7 @@ struct Ctx
   int32_t* d_vox_cam = nullptr;
   int64_t vox_cap = 0;
   float* d_raw_xyz = nullptr;      // device copy of a raw host cloud
-  int64_t raw_cap = 0;
+  int64_t raw_cap = 0;             // floats
 
   // handle search (K5)
   agh_hypothesis* d_h_hands = nullptr;

@@ -397,7 +397,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
-    c->d_weight, c->d_order, c->d_vmask, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
+    c->d_weight, c->d_order, c->d_vmask, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
     c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
@@ -459,23 +459,35 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
     return AGH_ERR_INVALID_ARGUMENT;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  if (n > c->own_cap)
+  // The points are uploaded as they lie in host memory (one contiguous copy: a strided 2-D copy of 12 of every 32
+  // bytes runs at a fraction of the PCIe rate) and the kernels read them with the caller's stride; strides above 32
+  // bytes are repacked to 12.
+  const bool as_is = stride_bytes <= 32;
+  const int64_t dev_stride = as_is ? stride_bytes : 12;
+  const int64_t need = n * (dev_stride / 4);
+  if (need > c->own_cap_floats || n > c->own_cap)
   {
     int rc;
-    if ((rc = dev_alloc(c, &c->own_xyz, (size_t) n * 3)) || (rc = dev_alloc(c, &c->own_cam, (size_t) n)))
+    if ((rc = dev_alloc(c, &c->own_xyz, (size_t) std::max<int64_t>(need, c->own_cap_floats))) ||
+        (rc = dev_alloc(c, &c->own_cam, (size_t) std::max<int64_t>(n, c->own_cap))))
       return rc;
-    c->own_cap = n;
+    c->own_cap_floats = std::max<int64_t>(need, c->own_cap_floats);
+    c->own_cap = std::max<int64_t>(n, c->own_cap);
   }
   if (n > 0)
   {
-    HIPCHK(c, hipMemcpy2DAsync(c->own_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
-                c->stream));
+    if (as_is)
+      HIPCHK(c, hipMemcpyAsync(c->own_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice,
+                  c->stream));  // (the last point's padding may lie outside the caller's buffer)
+    else
+      HIPCHK(c, hipMemcpy2DAsync(c->own_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
+                  c->stream));
     if (cam_source)
       HIPCHK(c, hipMemcpyAsync(c->own_cam, cam_source, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
     else
       HIPCHK(c, hipMemsetAsync(c->own_cam, 0, sizeof(int32_t) * n, c->stream));
   }
-  int rc = agh_set_cloud_device(ctx, c->own_xyz, 12, c->own_cam, n, nullptr);
+  int rc = agh_set_cloud_device(ctx, c->own_xyz, dev_stride, c->own_cam, n, nullptr);
   if (rc != AGH_OK)
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -558,17 +570,27 @@ int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t
     return AGH_ERR_INVALID_ARGUMENT;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  if (n > c->raw_cap || !c->d_raw_xyz)
+  const bool as_is = stride_bytes <= 32;  // one contiguous upload, read with the caller's stride (see agh_set_cloud)
+  const int64_t dev_stride = as_is ? stride_bytes : 12;
+  const int64_t need = n * (dev_stride / 4);
+  if (need > c->raw_cap || !c->d_raw_xyz)
   {
     int rc;
-    if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) n * 3)))
+    if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
       return rc;
-    c->raw_cap = n;
+    c->raw_cap = need;
   }
   if (n > 0)
-    HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
-                c->stream));
-  int rc = agh_preprocess_device(ctx, c->d_raw_xyz, 12, n, size_left, dense, workspace, cell_size, n_voxels_out, nullptr);
+  {
+    if (as_is)
+      HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice,
+                  c->stream));
+    else
+      HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
+                  c->stream));
+  }
+  int rc = agh_preprocess_device(ctx, c->d_raw_xyz, dev_stride, n, size_left, dense, workspace, cell_size, n_voxels_out,
+    nullptr);
   if (rc != AGH_OK)
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -810,11 +832,18 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
   return AGH_OK;
 }
 
+static int flags_to_status(Ctx* c, const int32_t* flags);
+
 static int check_flags(Ctx* c, hipStream_t st)
 {
   int32_t flags[8];
   HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  return flags_to_status(c, flags);
+}
+
+static int flags_to_status(Ctx* c, const int32_t* flags)
+{
   if (flags[0] & 1)
   {
     c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
@@ -863,20 +892,30 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
   if (rc != AGH_OK)
     return rc;
   // own sample buffer (d_samples doubles as the iota scratch of the normals pass)
-  int32_t* d_idx = nullptr;
-  HIPCHK(c, hipMalloc((void**) &d_idx, sizeof(int32_t) * std::max<int64_t>(n_samples, 1)));
+  if (n_samples > c->idx_cap || !c->d_idx_own)
+  {
+    if ((rc = dev_alloc(c, &c->d_idx_own, (size_t) std::max<int64_t>(n_samples, 1024))))
+      return rc;
+    c->idx_cap = std::max<int64_t>(n_samples, 1024);
+  }
+  int32_t* d_idx = c->d_idx_own;
   if (n_samples > 0)
     HIPCHK(c, hipMemcpyAsync(d_idx, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
   rc = agh_find_hands_device(ctx, d_idx, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
     c->stream);
+  int64_t n = 0;
   if (rc == AGH_OK)
-    rc = check_flags(c, c->stream);
-  (void) hipStreamSynchronize(c->stream);
-  (void) hipFree(d_idx);
+  {
+    int32_t flags[8];  // error flags and the count come back with one synchronisation
+    HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = flags_to_status(c, flags);
+  }
+  else
+    (void) hipStreamSynchronize(c->stream);
   if (rc != AGH_OK)
     return rc;
-  int64_t n = 0;
-  HIPCHK(c, hipMemcpy(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost));
   c->last_nout = n;
   *n_out = n;
   if (n > cap)
