@@ -37,6 +37,7 @@ def test_struct_layouts_match_the_header():
     from oracle import oracle_py as O
 
     assert O.HYP_DTYPE == binding.HYP_DTYPE and O.FRAME_DTYPE == binding.FRAME_DTYPE
+    assert binding.HANDLE_DTYPE.itemsize == 136 and O.HANDLE_DTYPE == binding.HANDLE_DTYPE
 
 
 def test_no_cpu_fallback_without_a_gpu():
