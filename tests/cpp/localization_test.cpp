@@ -1,6 +1,6 @@
 // localization_test.cpp -- drives the Localization facade (include/agile_grasp_amd/localization.h) on a RAW cloud
 // (NaNs, points outside the workspace, no voxelisation), like src/tests/test_local_axes.cpp drives the reference's.
-//   localization_test <raw.bin> <svm file> <mode: voxels|hands>
+//   localization_test <raw.bin> <svm file> <mode: voxels|hands|antipodal>   (antipodal: src/tests/antipodal_test.cpp)
 // raw.bin: int64 n, int64 size_left, int64 n_idx, double ws[6], double cam_left[3], double cam_right[3], n*3 float xyz,
 // n_idx int32 indices (into the voxelised cloud).
 #include <cstdio>
@@ -65,7 +65,14 @@ int main(int argc, char** argv)
         (int) loc.getSearchedCamSource()((int) i));
     return 0;
   }
-  std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, false, false);
+  const bool antipodal = std::strcmp(argv[3], "antipodal") == 0;  // calculates_antipodal (antipodal_test.cpp:61)
+  std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, antipodal, false);
+  if (antipodal)
+  {
+    for (size_t i = 0; i < hands.size(); i++)
+      std::printf("A %d %d\n", hands[i].isHalfAntipodal() ? 1 : 0, hands[i].isFullAntipodal() ? 1 : 0);
+    return 0;
+  }
   std::vector<GraspHypothesis> kept = loc.predictAntipodalHands(hands, argv[2]);
   std::printf("RESULT %zu %zu %zu\n", loc.getSearchedCloud() ? loc.getSearchedCloud()->size() : (size_t) 0, hands.size(),
     kept.size());

@@ -210,6 +210,28 @@ def test_localization_facade_matches_c_abi(tmp_path, svm_model):
                                               float(h["width"])]
 
 
+@pytest.mark.gpu
+def test_localization_facade_antipodal_labels(tmp_path):
+    """src/tests/antipodal_test.cpp: localizeHands with calculates_antipodal = true (all-points normals pass + 20 degree
+    antipodal test); the half / full labels must be the ones the C ABI gives for the same voxelised cloud."""
+    from agile_grasp_amd import binding
+
+    exe = _build_loc(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    vox, vcam = _preprocess_numpy(xyz, size_left, ws)
+    idx = np.sort(np.random.default_rng(0).permutation(len(vox))[:48]).astype(np.int32)
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, idx, ws, cams)
+    out = subprocess.run([exe, path, "none", "antipodal"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = [[int(v) for v in l.split()[1:]] for l in out.stdout.splitlines() if l.startswith("A ")]
+    ctx = binding.Context(cams)
+    ctx.set_cloud(vox, vcam)
+    hyps = ctx.find_hands(idx, calculates_antipodal=True)
+    assert len(got) == len(hyps) > 0
+    assert got == [[int(h["half_antipodal"]), int(h["full_antipodal"])] for h in hyps]
+
+
 # ---- row f3: PCD files and message fields without PCL / ROS ----
 def _build_pcd(tmp_path):
     from agile_grasp_amd import build
