@@ -764,7 +764,7 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
       return rc;
   }
   timing_begin(c, st);
-  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
+  c->zero_flags_pending = true;  // the first kernel of the call clears the error flags (no memset launch)
   c->last_s = S;
   c->last_nout = -1;
   c->last_cap = cap;
@@ -772,6 +772,8 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
   c->d_nout_last = d_n_out;
   if (S == 0 || c->n == 0)
   {
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
+    c->zero_flags_pending = false;
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     c->last_s = 0;
     return AGH_OK;

@@ -37,7 +37,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points, double rpad_w, int* __restrict__ weight)
+  int n_points, double rpad_w, int* __restrict__ weight, int32_t* __restrict__ zero_flags)
 {
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (zero_flags && blockIdx.x == 0 && tid < 8)
+    zero_flags[tid] = 0;  // first kernel of an agh_find_hands call: the flags are only set by later kernels
   if (!first_class && status[s] != kStatusOverflow)
     return;  // an earlier (smaller) capacity class already handled this sample
   if (samples[s] < 0 || samples[s] >= n_points)
@@ -1267,16 +1269,22 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   // capacity classes: smallest first; later classes only touch samples flagged kStatusOverflow
   const bool small_first = radius <= 0.015;
   bool first = true;
+  int32_t* zf = c->zero_flags_pending ? c->d_flags : nullptr;
+  c->zero_flags_pending = false;
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      zf);
+    zf = nullptr;
     first = false;
   }
   hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
+    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+    zf);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight);
+    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+    (int32_t*) nullptr);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
