@@ -79,6 +79,8 @@ void hog_tables_host(HogTablesDev* t)
       if (hidx >= nbins)
         hidx = 0;
       t->bin1[id] = hidx;
+      for (int k = 0; k < nbins; k++)
+        t->coef[id][k] = (k == t->bin0[id]) ? t->mag0[id] : ((k == t->bin1[id]) ? t->mag1[id] : 0.f);
     }
   // pixData: Gaussian window (sigma = 4) x bilinear cell weights, grouped 1-cell | 2-cell | 4-cell pixels
   const int bs = 16, csz = 8, nc = 2;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   __shared__ int nzc[kNBlocks];
   __shared__ float hist[kNBlocks][36];
   __shared__ float grp[882];
-  __shared__ HogTablesDev Ts;  // the 11 KiB of tables are hit on every vote: keep them in LDS
+  __shared__ __attribute__((aligned(16))) HogTablesDev Ts;  // the 11 KiB of tables are hit on every vote: keep them in LDS
 
   const int h = blockIdx.x;
   if ((int64_t) h >= *n_hyp)
@@ -257,11 +259,19 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
       const int k = nzk[b][q];
       const float w = T->pix_wcell[k][cell];
       const int cd = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]];
-      const int h0 = T->bin0[cd], h1 = T->bin1[cd];
-      const float v0 = T->mag0[cd] * w, v1 = T->mag1[cd] * w;
-#pragma unroll
-      for (int k2 = 0; k2 < 9; k2++)
-        hh[k2] = hh[k2] + ((k2 == h0) ? v0 : ((k2 == h1) ? v1 : 0.f));
+      const float4 c0 = *reinterpret_cast<const float4*>(&T->coef[cd][0]);
+      const float4 c1 = *reinterpret_cast<const float4*>(&T->coef[cd][4]);
+      const float c8 = T->coef[cd][8];
+      // mag * w for the pixel's two bins, +0.0f for the other seven (w >= 0, mag >= 0: the zero products are +0.0f)
+      hh[0] = hh[0] + c0.x * w;
+      hh[1] = hh[1] + c0.y * w;
+      hh[2] = hh[2] + c0.z * w;
+      hh[3] = hh[3] + c0.w * w;
+      hh[4] = hh[4] + c1.x * w;
+      hh[5] = hh[5] + c1.y * w;
+      hh[6] = hh[6] + c1.z * w;
+      hh[7] = hh[7] + c1.w * w;
+      hh[8] = hh[8] + c8 * w;
     }
 #pragma unroll
     for (int k = 0; k < 9; k++)
