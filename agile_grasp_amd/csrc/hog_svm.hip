@@ -14,6 +14,8 @@
 //    with zero gradient (adding +0.0f is exact), so every float sum has the reference's order.
 //  * L2-Hys per block with the reference's sequential loops; the SVM dot product keeps OpenCV's shape: float
 //    products summed four at a time in float, accumulated in double in index order by one lane.
+#include <cstdlib>
+
 #include "agh_internal.h"
 
 #include <cmath>
@@ -189,7 +191,7 @@ constexpr int kCodeW = 96, kCodeH = 64;
 __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ images,
   const int32_t* __restrict__ slot_of_hyp, const int64_t* __restrict__ n_hyp, const HogTablesDev* __restrict__ Tg,
   const float* __restrict__ svm_w, double rho, agh_hypothesis* __restrict__ out, uint8_t* __restrict__ keep,
-  double* __restrict__ sums, float* __restrict__ desc_out)
+  double* __restrict__ sums, float* __restrict__ desc_out, int debug_stop)
 {
   __shared__ uint32_t bm[kImageWords + 2];
   __shared__ uint8_t code[kCodeH * kCodeW];
@@ -224,24 +226,34 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
     code[p] = (uint8_t) ((sx + 1) * 3 + (sy + 1));
   }
   __syncthreads();
+  if (debug_stop == 1)  // (AGH_DEBUG_STOP_HOG: phase-timing aid, like the other kernels' debug stops)
+    return;
   // per block: ordered list of the pixData entries with a non-zero gradient (all other pixels vote +0.0f: nothing)
   for (int b = wave; b < kNBlocks; b += 4)
   {
     const int x0 = (b / 7) * 8, y0 = (b % 7) * 8;
     int cnt = 0;
-    for (int c = 0; c < 4; c++)
+    bool nzq[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)  // the four chained look-ups (pixel position -> gradient code) are issued together
     {
       const int k = c * 64 + lane;
-      const bool nz = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]] != 4;
-      const unsigned long long m = __ballot(nz);
-      if (nz)
-        nzk[b][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t) k;
+      nzq[c] = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]] != 4;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+      const unsigned long long m = __ballot(nzq[c]);
+      if (nzq[c])
+        nzk[b][cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t) (c * 64 + lane);
       cnt += __popcll(m);
     }
     if (lane == 0)
       nzc[b] = cnt;
   }
   __syncthreads();
+  if (debug_stop == 2)
+    return;
   // block histograms (HOGCache::getBlock): one (block, cell) per work item, votes in pixData order.  The nine bins live
   // in registers; every listed pixel adds mag * weight to its two bins and +0.0f (exact) to the others, and a pixel
   // that does not vote for this cell has weight 0 -- so there is no data-dependent branch and no LDS read-modify-write.
@@ -278,6 +290,8 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
       hist[b][cell * 9 + k] = hh[k];
   }
   __syncthreads();
+  if (debug_stop == 3)
+    return;
   // L2-Hys (HOGCache::normalizeBlockHistogram), sequential per block
   if (tid < kNBlocks)
   {
@@ -298,6 +312,8 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
       hh[k] *= scale;
   }
   __syncthreads();
+  if (debug_stop == 4)
+    return;
   // descriptor layout: window-major, block bx*7+by, cell cx*2+cy, 9 bins; window 1 starts at block column 4
   for (int m = tid; m < 882; m += 256)
   {
@@ -312,6 +328,8 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
         desc_out[(int64_t) h * 3528 + m * 4 + q] = d[q];
   }
   __syncthreads();
+  if (debug_stop == 5)
+    return;
   if (tid == 0)
   {
     double s = 0;
@@ -343,7 +361,8 @@ int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st)
     return AGH_OK;
   timing_mark(c, "start", st);
   hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n_hyp_cap), dim3(256), 0, st, c->d_images, c->d_slot_index, c->d_nout_last,
-    c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out);
+    c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out,
+    std::getenv("AGH_DEBUG_STOP_HOG") ? std::atoi(std::getenv("AGH_DEBUG_STOP_HOG")) : 0);
   timing_mark(c, "hog_svm", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
