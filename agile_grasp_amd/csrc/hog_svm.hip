@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   double* __restrict__ sums, float* __restrict__ desc_out, int debug_stop)
 {
   __shared__ uint32_t bm[kImageWords + 2];
-  __shared__ uint8_t code[kCodeH * kCodeW];
+  __shared__ __attribute__((aligned(4))) uint8_t code[kCodeH * kCodeW];
   __shared__ uint8_t nzk[kNBlocks][256];  // per block: pixData entries with a non-zero gradient, in order
   __shared__ int nzc[kNBlocks];
   __shared__ float hist[kNBlocks][36];
@@ -212,18 +212,35 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   for (int k = tid; k < kImageWords; k += 256)
     bm[k] = im[k];
   __syncthreads();
-  auto pixel = [&](int y, int x) -> int {
+  // gradient code per pixel: centred differences, BORDER_REFLECT_101 at x = 0 and y = 0 (hog.cpp computeGradient).
+  // One thread per (row, 32-pixel word): the four neighbour rows come as 32-bit vectors (funnel shifts of the packed
+  // image), then code = 4 + 3 (right - left) + (down - up) per pixel, four codes per LDS word.
+  auto row_bits = [&](int y, int x) -> unsigned {  // pixels (y, x) .. (y, x + 31)
     const int b = y * 100 + x;
-    return (bm[b >> 5] >> (b & 31)) & 1u;
+    return __funnelshift_r(bm[b >> 5], bm[(b >> 5) + 1], b & 31);
   };
-  // gradient code per pixel: centred differences, BORDER_REFLECT_101 at x = 0 and y = 0 (hog.cpp computeGradient)
-  for (int p = tid; p < kCodeH * kCodeW; p += 256)
+  for (int unit = tid; unit < kCodeH * (kCodeW / 32); unit += 256)
   {
-    const int y = p / kCodeW, x = p % kCodeW;
-    const int xl = (x == 0) ? 1 : x - 1, yp = (y == 0) ? 1 : y - 1;
-    const int sx = pixel(y, x + 1) - pixel(y, xl);
-    const int sy = pixel(y + 1, x) - pixel(yp, x);
-    code[p] = (uint8_t) ((sx + 1) * 3 + (sy + 1));
+    const int y = unit / (kCodeW / 32), x0 = (unit % (kCodeW / 32)) * 32;
+    const unsigned C = row_bits(y, x0);
+    const unsigned R = row_bits(y, x0 + 1);
+    const unsigned L = x0 == 0 ? ((C << 1) | ((C >> 1) & 1u)) : row_bits(y, x0 - 1);  // x = 0 reflects to x = 1
+    const unsigned D = row_bits(y + 1, x0);
+    const unsigned U = row_bits(y == 0 ? 1 : y - 1, x0);                               // y = 0 reflects to y = 1
+    unsigned* dst = reinterpret_cast<unsigned*>(&code[y * kCodeW + x0]);
+#pragma unroll
+    for (int i = 0; i < 32; i += 4)
+    {
+      unsigned w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const int sx = (int) ((R >> (i + j)) & 1u) - (int) ((L >> (i + j)) & 1u);
+        const int sy = (int) ((D >> (i + j)) & 1u) - (int) ((U >> (i + j)) & 1u);
+        w |= (unsigned) ((sx + 1) * 3 + (sy + 1)) << (8 * j);
+      }
+      dst[i >> 2] = w;
+    }
   }
   __syncthreads();
   if (debug_stop == 1)  // (AGH_DEBUG_STOP_HOG: phase-timing aid, like the other kernels' debug stops)
