@@ -69,30 +69,30 @@ struct HandleCounts
   int n_handles, n_idx, error;
 };
 
-__global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
+constexpr int kHandleLdsHands = 640;  // hands whose axis, bottom and pair-matrix rows fit the LDS of the small variant
+constexpr int kHandleLdsWords = kHandleLdsHands / 64;
+
+// SMALL: H <= kHandleLdsHands.  The loop is a chain of dependent look-ups per seed (seed row -> inliers -> their
+// positions): the small variant keeps every hand's axis and grasp bottom AND the pair matrix in LDS (106 KiB of the
+// CU's 160), so a seed costs LDS latency only; the general variant prefetches the next seed's row from global memory.  The general variant reads both from global memory.
+template <bool SMALL>
+__global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
   const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
   int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts)
 {
+  constexpr int kCap = SMALL ? 1024 : kHandleListCap;
   __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
   __shared__ unsigned long long elig[128];   // rows with at least min_inliers inliers at all (no global load per seed)
-  __shared__ int wcnt[128];
-  __shared__ double ld[kHandleListCap], sd[kHandleListCap];
-  __shared__ int lj[kHandleListCap], sj[kHandleListCap];
-  __shared__ int s_n, s_gap, s_nh, s_nidx;
+  __shared__ double ld[kCap], sd[kCap];
+  __shared__ int lj[kCap], sj[kCap];
+  __shared__ double hpos[SMALL ? kHandleLdsHands : 1][6];  // axis, bottom
+  __shared__ unsigned long long lbits[SMALL ? kHandleLdsHands * kHandleLdsWords : 1];  // the pair matrix (51 KiB)
+  __shared__ int s_gap, s_nh, s_nidx;
   const int tid = threadIdx.x;
-  if (tid < W)
+  for (int t = tid; t < 128; t += 64)
   {
-    unsigned long long m = 0, el = 0;
-    for (int b = 0; b < 64; b++)
-    {
-      const int j = tid * 64 + b;
-      if (j < H && hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
-        m |= 1ull << b;
-      if (j < H && rowcnt[j] >= min_inliers)
-        el |= 1ull << b;
-    }
-    alive[tid] = m;
-    elig[tid] = el;
+    alive[t] = 0ull;
+    elig[t] = 0ull;
   }
   if (tid == 0)
   {
@@ -100,86 +100,158 @@ __global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __r
     s_nidx = 0;
   }
   __syncthreads();
-  for (int i = 0; i < H; i++)
+  for (int j = tid; j < H; j += 64)
   {
-    if (!(((alive[i >> 6] & elig[i >> 6]) >> (i & 63)) & 1ull))
-      continue;  // retired, or too few inliers even with every hand available (the available ones are a subset)
-    // available inliers of seed i: mask, count, compact in ascending j
-    unsigned long long m = 0;
-    if (tid < W)
-    {
-      m = bits[(int64_t) i * W + tid] & alive[tid];
-      wcnt[tid] = __popcll(m);
-    }
-    __syncthreads();
-    if (tid == 0)
-    {
-      int n = 0;
-      for (int w = 0; w < W; w++)
+    if (hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
+      atomicOr(&alive[j >> 6], 1ull << (j & 63));
+    if (rowcnt[j] >= min_inliers)
+      atomicOr(&elig[j >> 6], 1ull << (j & 63));
+    if (SMALL)
+      for (int r = 0; r < 3; r++)
       {
-        const int c = wcnt[w];
-        wcnt[w] = n;
-        n += c;
+        hpos[j][r] = hands[j].axis[r];
+        hpos[j][3 + r] = hands[j].bottom[r];
       }
-      s_n = n;
-      s_gap = 0x7fffffff;
+  }
+  if (SMALL)
+    for (int k = tid; k < H * W; k += 64)
+      lbits[k] = bits[k];
+  __syncthreads();
+  auto next_seed = [&](int from) -> int {  // first available, eligible seed >= from (H if none)
+    for (int w = from >> 6; w < W; w++)
+    {
+      unsigned long long m = alive[w] & elig[w];
+      if (w == (from >> 6))
+        m &= ~0ull << (from & 63);
+      if (m)
+        return w * 64 + __ffsll((long long) m) - 1;
     }
-    __syncthreads();
-    const int n = s_n;
-    if (n < min_inliers)
-      continue;  // handle_search.cpp:47-48 (uniform: everybody read the same s_n; the next barrier is in the next pass)
-    if (n > kHandleListCap)
+    return H;
+  };
+  int i = next_seed(0);
+  // the seed's row of the pair matrix: lane t holds words t and 64 + t
+  auto load_row = [&](int seed, unsigned long long& r0, unsigned long long& r1) {
+    if (SMALL)
+    {
+      r0 = (tid < W && seed < H) ? lbits[seed * W + tid] : 0ull;
+      r1 = 0ull;  // (W <= 10)
+    }
+    else
+    {
+      r0 = (tid < W && seed < H) ? bits[(int64_t) seed * W + tid] : 0ull;
+      r1 = (64 + tid < W && seed < H) ? bits[(int64_t) seed * W + 64 + tid] : 0ull;
+    }
+  };
+  unsigned long long row0, row1;
+  load_row(i, row0, row1);
+  while (i < H)
+  {
+    // the row of the seed that will most likely come next travels while this seed is processed
+    const int guess = next_seed(i + 1);
+    unsigned long long nrow0, nrow1;
+    load_row(guess, nrow0, nrow1);
+    // available inliers of seed i: mask, count, compact in ascending j
+    // (one wave runs the whole loop: the count and the exclusive offsets of the words are a wave scan, no barrier and
+    // no serial pass over the words)
+    unsigned long long m0 = tid < W ? (row0 & alive[tid]) : 0ull;
+    unsigned long long m1 = 64 + tid < W ? (row1 & alive[64 + tid]) : 0ull;
+    const int c0 = __popcll(m0), c1 = __popcll(m1);
+    int i0 = c0, i1 = c1, tot0;
+    if (SMALL)
+    {
+      // W <= 10: all counts sit in the first DPP row; an inclusive scan by four row shifts (no LDS crossbar: a
+      // __shfl_up scan is twelve dependent ds_bpermute round trips, most of a rejected seed's time)
+      i0 += __builtin_amdgcn_update_dpp(0, i0, 0x111, 0xf, 0xf, true);  // row_shr:1
+      i0 += __builtin_amdgcn_update_dpp(0, i0, 0x112, 0xf, 0xf, true);  // row_shr:2
+      i0 += __builtin_amdgcn_update_dpp(0, i0, 0x114, 0xf, 0xf, true);  // row_shr:4
+      i0 += __builtin_amdgcn_update_dpp(0, i0, 0x118, 0xf, 0xf, true);  // row_shr:8
+      tot0 = __builtin_amdgcn_readlane(i0, 15);
+      i1 = 0;
+    }
+    else
+    {
+      for (int o = 1; o < 64; o <<= 1)
+      {
+        const int y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o);
+        if (tid >= o)
+        {
+          i0 += y0;
+          i1 += y1;
+        }
+      }
+      tot0 = __shfl(i0, 63);
+    }
+    const int ofs0 = i0 - c0, ofs1 = tot0 + i1 - c1;
+    if (tid == 0)
+      s_gap = 0x7fffffff;
+    const int n = SMALL ? tot0 : tot0 + __shfl(i1, 63);
+    bool accept = n >= min_inliers;  // handle_search.cpp:47-48
+    if (accept && n > kCap)
     {
       if (tid == 0)
         counts->error = 1;
       break;
     }
-    if (tid < W)
-    {
-      const agh_hypothesis& hi = hands[i];
-      int pos = wcnt[tid];
-      while (m)
-      {
-        const int j = tid * 64 + __ffsll((long long) m) - 1;
-        m &= m - 1ull;
-        const double d[3] = { hands[j].bottom[0] - hi.bottom[0], hands[j].bottom[1] - hi.bottom[1],
-          hands[j].bottom[2] - hi.bottom[2] };
-        ld[pos] = dot3d(hi.axis, d);  // dist_along_line (:34)
-        lj[pos] = j;
-        pos++;
-      }
-    }
-    __syncthreads();
-    // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
-    for (int e = tid; e < n; e += 256)
-    {
-      const double de = ld[e];
-      const int je = lj[e];
-      int rank = 0;
-      for (int k = 0; k < n; k++)
-        rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
-      sd[rank] = de;
-      sj[rank] = je;
-    }
-    __syncthreads();
-    for (int k = tid; k + 1 < n; k += 256)  // shortenHandle: first gap > 2 cm (:95-99)
-      if (sd[k + 1] - sd[k] > 0.02)
-        atomicMin(&s_gap, k);
-    __syncthreads();
-    const int kept = s_gap == 0x7fffffff ? n : s_gap;  // the elements before the gap position (:111)
-    bool accept = kept >= min_inliers && kept > 0;
+    int kept = 0;
     if (accept)
     {
-      // :62-72: minimum and maximum over the kept list with the reference's +-1e7 start values (the list is sorted,
-      // so they are its ends)
-      const double mn = sd[0] < 10000000 ? sd[0] : 10000000;
-      const double mx = sd[kept - 1] > -10000000 ? sd[kept - 1] : -10000000;
-      accept = (mx - mn > min_length);
+      {
+        double ia[3], ib[3];
+        for (int r = 0; r < 3; r++)
+        {
+          ia[r] = SMALL ? hpos[i][r] : hands[i].axis[r];
+          ib[r] = SMALL ? hpos[i][3 + r] : hands[i].bottom[r];
+        }
+        for (int half = 0; half < 2; half++)
+        {
+          unsigned long long m = half ? m1 : m0;
+          int pos = half ? ofs1 : ofs0;
+          const int wbase = (half ? 64 + tid : tid) * 64;
+          while (m)
+          {
+            const int j = wbase + __ffsll((long long) m) - 1;
+            m &= m - 1ull;
+            double d[3];
+            for (int r = 0; r < 3; r++)
+              d[r] = (SMALL ? hpos[j][3 + r] : hands[j].bottom[r]) - ib[r];
+            ld[pos] = dot3d(ia, d);  // dist_along_line (:34)
+            lj[pos] = j;
+            pos++;
+          }
+        }
+      }
+      __syncthreads();
+      // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
+      for (int e = tid; e < n; e += 64)
+      {
+        const double de = ld[e];
+        const int je = lj[e];
+        int rank = 0;
+        for (int k = 0; k < n; k++)
+          rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
+        sd[rank] = de;
+        sj[rank] = je;
+      }
+      __syncthreads();
+      for (int k = tid; k + 1 < n; k += 64)  // shortenHandle: first gap > 2 cm (:95-99)
+        if (sd[k + 1] - sd[k] > 0.02)
+          atomicMin(&s_gap, k);
+      __syncthreads();
+      kept = s_gap == 0x7fffffff ? n : s_gap;  // the elements before the gap position (:111)
+      accept = kept >= min_inliers && kept > 0;
+      if (accept)
+      {
+        // :62-72: minimum and maximum over the kept list with the reference's +-1e7 start values (the list is sorted,
+        // so they are its ends)
+        const double mn = sd[0] < 10000000 ? sd[0] : 10000000;
+        const double mx = sd[kept - 1] > -10000000 ? sd[kept - 1] : -10000000;
+        accept = (mx - mn > min_length);
+      }
     }
     if (accept)
     {
       const int h = s_nh, base = s_nidx;
-      for (int k = tid; k < kept; k += 256)
+      for (int k = tid; k < kept; k += 64)
       {
         inlier_idx[base + k] = sj[k];
         atomicAnd(&alive[sj[k] >> 6], ~(1ull << (sj[k] & 63)));  // :75-78
@@ -194,6 +266,15 @@ __global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __r
       }
     }
     __syncthreads();
+    const int nxt = next_seed(i + 1);  // (retiring the members may have removed the guessed seed)
+    if (nxt == guess)
+    {
+      row0 = nrow0;
+      row1 = nrow1;
+    }
+    else
+      load_row(nxt, row0, row1);
+    i = nxt;
   }
   __syncthreads();
   if (tid == 0)
@@ -314,9 +395,14 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
     return AGH_OK;
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
     c->d_h_bits, W, c->d_h_rowcnt);
-  hipLaunchKernelGGL(k_handle_greedy, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
-    (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-    c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
+  if (Hi <= kHandleLdsHands)
+    hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
+  else
+    hipLaunchKernelGGL(k_handle_greedy<false>, dim3(1), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
   hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
     (const int*) c->d_h_first, (const int*) c->d_h_n, (const int*) c->d_h_idx,
     (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles);
