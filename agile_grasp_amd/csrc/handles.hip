@@ -157,9 +157,9 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
     unsigned long long m1 = 64 + tid < W ? (row1 & alive[64 + tid]) : 0ull;
     const int c0 = __popcll(m0), c1 = __popcll(m1);
     int i0 = c0, i1 = c1, tot0;
-    if (SMALL)
+    if (W <= 16)
     {
-      // W <= 10: all counts sit in the first DPP row; an inclusive scan by four row shifts (no LDS crossbar: a
+      // all counts sit in the first DPP row; an inclusive scan by four row shifts (no LDS crossbar: a
       // __shfl_up scan is twelve dependent ds_bpermute round trips, most of a rejected seed's time)
       i0 += __builtin_amdgcn_update_dpp(0, i0, 0x111, 0xf, 0xf, true);  // row_shr:1
       i0 += __builtin_amdgcn_update_dpp(0, i0, 0x112, 0xf, 0xf, true);  // row_shr:2
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
     const int ofs0 = i0 - c0, ofs1 = tot0 + i1 - c1;
     if (tid == 0)
       s_gap = 0x7fffffff;
-    const int n = SMALL ? tot0 : tot0 + __shfl(i1, 63);
+    const int n = W <= 16 ? tot0 : tot0 + __shfl(i1, 63);
     bool accept = n >= min_inliers;  // handle_search.cpp:47-48
     if (accept && n > kCap)
     {
@@ -222,16 +222,37 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
       }
       __syncthreads();
       // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
-      for (int e = tid; e < n; e += 64)
+      if (n <= 64)
       {
-        const double de = ld[e];
-        const int je = lj[e];
+        // one list entry per lane; the other entries arrive as wave-uniform scalars (v_readlane), so a rank costs n
+        // compares and no LDS round trip
+        const double de = tid < n ? ld[tid] : 0.0;
+        const int je = tid < n ? lj[tid] : 0;
+        const int dlo = __double2loint(de), dhi = __double2hiint(de);
         int rank = 0;
         for (int k = 0; k < n; k++)
-          rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
-        sd[rank] = de;
-        sj[rank] = je;
+        {
+          const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+          const int jk = __builtin_amdgcn_readlane(je, k);
+          rank += (dk < de || (dk == de && jk < je)) ? 1 : 0;
+        }
+        if (tid < n)
+        {
+          sd[rank] = de;
+          sj[rank] = je;
+        }
       }
+      else
+        for (int e = tid; e < n; e += 64)
+        {
+          const double de = ld[e];
+          const int je = lj[e];
+          int rank = 0;
+          for (int k = 0; k < n; k++)
+            rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
+          sd[rank] = de;
+          sj[rank] = je;
+        }
       __syncthreads();
       for (int k = tid; k + 1 < n; k += 64)  // shortenHandle: first gap > 2 cm (:95-99)
         if (sd[k + 1] - sd[k] > 0.02)
