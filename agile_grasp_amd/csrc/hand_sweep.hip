@@ -47,6 +47,18 @@ __device__ __forceinline__ double wave_max_f64(double v)
     v = fmax(v, __shfl_xor(v, o));
   return v;
 }
+// Inclusive OR scan over the 64 lanes: row_shr 1, 2, 4, 8 inside each 16-lane row, then row_bcast:15 into rows 1 and 3
+// and row_bcast:31 into rows 2 and 3 (the compiler fuses each step into one v_or_b32_dpp).
+__device__ __forceinline__ unsigned wave_prefix_or(unsigned v)
+{
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);
+  v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);
+  return v;
+}
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
   for (int o = 32; o > 0; o >>= 1)
@@ -445,24 +457,16 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     auto half = [&](int key) -> unsigned { return (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu; };
     const unsigned v0 = lane < R ? half(lane) : 0u;
     const unsigned v1 = (64 + lane) < R ? half(64 + lane) : 0u;
-    unsigned p0 = v0, p1 = v1, s0 = v0, s1 = v1;
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      const unsigned a = __shfl_up(p0, d), b = __shfl_up(p1, d);
-      const unsigned c2 = __shfl_down(s0, d), e2 = __shfl_down(s1, d);
-      if (lane >= d)
-      {
-        p0 |= a;
-        p1 |= b;
-      }
-      if (lane + d < 64)
-      {
-        s0 |= c2;
-        s1 |= e2;
-      }
-    }
-    p1 |= __shfl(p0, 63);
-    s0 |= __shfl(s1, 0);
+    // inclusive prefix / suffix ORs over the 128 keys: six v_or_b32_dpp per scan (row shifts, then row broadcasts);
+    // the suffix scans run on lane-reversed data (one ds_bpermute there, one back)
+    const int rev = (63 - lane) << 2;
+    unsigned p0 = wave_prefix_or(v0);
+    unsigned p1 = wave_prefix_or(v1) | (unsigned) __builtin_amdgcn_readlane((int) p0, 63);
+    unsigned s1 = wave_prefix_or((unsigned) __builtin_amdgcn_ds_bpermute(rev, (int) v1));
+    unsigned s0 = wave_prefix_or((unsigned) __builtin_amdgcn_ds_bpermute(rev, (int) v0)) |
+                  (unsigned) __builtin_amdgcn_readlane((int) s1, 63);  // lane 63 of the reversed scan = OR of all of v1
+    s1 = (unsigned) __builtin_amdgcn_ds_bpermute(rev, (int) s1);
+    s0 = (unsigned) __builtin_amdgcn_ds_bpermute(rev, (int) s0);
     pre_s[wave][lane] = p0;
     suf_s[wave][lane] = s0;
     if (lane < 24)
