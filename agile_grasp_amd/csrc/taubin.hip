@@ -937,126 +937,139 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   // the error bound, so the true (sequentially rounded) maximum and all its exact ties are among them -- gets the
   // reference's exact sequential sum; the argmax (first index on ties) is taken over those.  The result is the
   // same index the exhaustive n^2 evaluation yields (asserted against the exhaustive oracle by the parity tests).
+  // With at most 64 normals (always in the reference's production mode, which subsamples 50) a column's exact sum is
+  // one term per lane plus the butterfly: evaluating all columns exactly is cheaper than estimating them first
+  // (measured; with up to 128 it is not).
+  if (ks <= 64)
   {
-    double T[28];
-#pragma unroll
-    for (int k = 0; k < 28; k++)
-      T[k] = 0.0;
-    for (int t = tid; t < ks; t += 256)
-    {
-      const double x = nx[t], y = ny[t], z = nz[t];
-      double px[7], py[7], pz[7];
-      px[0] = py[0] = pz[0] = 1.0;
-#pragma unroll
-      for (int k = 1; k < 7; k++)
-      {
-        px[k] = px[k - 1] * x;
-        py[k] = py[k - 1] * y;
-        pz[k] = pz[k - 1] * z;
-      }
-      int k = 0;
-#pragma unroll
-      for (int a = 6; a >= 0; a--)
-#pragma unroll
-        for (int b = 6 - a; b >= 0; b--)
-          T[k++] += (px[a] * py[b]) * pz[6 - a - b];
-    }
-    // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
-    // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
-    // full butterflies (168 exchanges) would; lane l ends with the total of moment l >> 1.
-    double R[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++)
-      R[k] = k < 28 ? T[k] : 0.0;
-#pragma unroll
-    for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1)
-    {
-      const bool upper = (lane & o) != 0;
-#pragma unroll
-      for (int k = 0; k < half; k++)
-      {
-        const double send = upper ? R[k] : R[k + half];
-        const double keep = upper ? R[k + half] : R[k];
-        R[k] = keep + __shfl_xor(send, o);
-      }
-    }
-    R[0] = R[0] + __shfl_xor(R[0], 1);
-    if ((lane & 1) == 0 && (lane >> 1) < 28)
-      sT[wave][lane >> 1] = R[0];
+    for (int j = tid; j < ks; j += 256)
+      cand[j] = (unsigned short) j;
+    if (tid == 0)
+      ncand = ks;
   }
-  __syncthreads();
-  if (tid < 28)  // multinomial-weighted moments, once per block
+  else
   {
-    const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
-    int k = 0, ea = 0, eb = 0;
-    for (int a = 6; a >= 0; a--)
-      for (int b = 6 - a; b >= 0; b--)
-      {
-        if (k == tid)
-        {
-          ea = a;
-          eb = b;
-        }
-        k++;
-      }
-    const double tsum = ((sT[0][tid] + sT[1][tid]) + sT[2][tid]) + sT[3][tid];
-    sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
-  }
-  __syncthreads();
-  double est[CAP / 256];
-  double est_max = -1.0;
-  {
-    double W[28];
-#pragma unroll
-    for (int k = 0; k < 28; k++)
-      W[k] = sW[k];
-#pragma unroll
-    for (int m = 0; m < CAP / 256; m++)
     {
-      const int j = tid + 256 * m;
-      double e_ = -2.0;
-      if (j < ks)
+      double T[28];
+  #pragma unroll
+      for (int k = 0; k < 28; k++)
+        T[k] = 0.0;
+      for (int t = tid; t < ks; t += 256)
       {
-        const double x = nx[j], y = ny[j], z = nz[j];
+        const double x = nx[t], y = ny[t], z = nz[t];
         double px[7], py[7], pz[7];
         px[0] = py[0] = pz[0] = 1.0;
+  #pragma unroll
         for (int k = 1; k < 7; k++)
         {
           px[k] = px[k - 1] * x;
           py[k] = py[k - 1] * y;
           pz[k] = pz[k - 1] * z;
         }
-        e_ = 0.0;
         int k = 0;
+  #pragma unroll
         for (int a = 6; a >= 0; a--)
+  #pragma unroll
           for (int b = 6 - a; b >= 0; b--)
-            e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
-        if (!(e_ == e_))
-          e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
+            T[k++] += (px[a] * py[b]) * pz[6 - a - b];
       }
-      est[m] = e_;
-      est_max = fmax(est_max, e_);
+      // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
+      // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
+      // full butterflies (168 exchanges) would; lane l ends with the total of moment l >> 1.
+      double R[32];
+  #pragma unroll
+      for (int k = 0; k < 32; k++)
+        R[k] = k < 28 ? T[k] : 0.0;
+  #pragma unroll
+      for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1)
+      {
+        const bool upper = (lane & o) != 0;
+  #pragma unroll
+        for (int k = 0; k < half; k++)
+        {
+          const double send = upper ? R[k] : R[k + half];
+          const double keep = upper ? R[k + half] : R[k];
+          R[k] = keep + __shfl_xor(send, o);
+        }
+      }
+      R[0] = R[0] + __shfl_xor(R[0], 1);
+      if ((lane & 1) == 0 && (lane >> 1) < 28)
+        sT[wave][lane >> 1] = R[0];
     }
-  }
-  est_max = wave_max_f64_(est_max);
-  if (lane == 0)
-    wmax_s[wave] = est_max;
-  __syncthreads();
-  est_max = fmax(fmax(wmax_s[0], wmax_s[1]), fmax(wmax_s[2], wmax_s[3]));
-  {
-    const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
-#pragma unroll
-    for (int m = 0; m < CAP / 256; m++)
+    __syncthreads();
+    if (tid < 28)  // multinomial-weighted moments, once per block
     {
-      const int j = tid + 256 * m;
-      const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
-      const unsigned long long mk = __ballot(is_c);
-      int base = 0;
-      if (lane == 0 && mk)
-        base = atomicAdd(&ncand, __popcll(mk));
-      base = __shfl(base, 0);
-      if (is_c)
-        cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
+      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
+      int k = 0, ea = 0, eb = 0;
+      for (int a = 6; a >= 0; a--)
+        for (int b = 6 - a; b >= 0; b--)
+        {
+          if (k == tid)
+          {
+            ea = a;
+            eb = b;
+          }
+          k++;
+        }
+      const double tsum = ((sT[0][tid] + sT[1][tid]) + sT[2][tid]) + sT[3][tid];
+      sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
+    }
+    __syncthreads();
+    double est[CAP / 256];
+    double est_max = -1.0;
+    {
+      double W[28];
+  #pragma unroll
+      for (int k = 0; k < 28; k++)
+        W[k] = sW[k];
+  #pragma unroll
+      for (int m = 0; m < CAP / 256; m++)
+      {
+        const int j = tid + 256 * m;
+        double e_ = -2.0;
+        if (j < ks)
+        {
+          const double x = nx[j], y = ny[j], z = nz[j];
+          double px[7], py[7], pz[7];
+          px[0] = py[0] = pz[0] = 1.0;
+          for (int k = 1; k < 7; k++)
+          {
+            px[k] = px[k - 1] * x;
+            py[k] = py[k - 1] * y;
+            pz[k] = pz[k - 1] * z;
+          }
+          e_ = 0.0;
+          int k = 0;
+          for (int a = 6; a >= 0; a--)
+            for (int b = 6 - a; b >= 0; b--)
+              e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
+          if (!(e_ == e_))
+            e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
+        }
+        est[m] = e_;
+        est_max = fmax(est_max, e_);
+      }
+    }
+    est_max = wave_max_f64_(est_max);
+    if (lane == 0)
+      wmax_s[wave] = est_max;
+    __syncthreads();
+    est_max = fmax(fmax(wmax_s[0], wmax_s[1]), fmax(wmax_s[2], wmax_s[3]));
+    {
+      const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
+  #pragma unroll
+      for (int m = 0; m < CAP / 256; m++)
+      {
+        const int j = tid + 256 * m;
+        const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
+        const unsigned long long mk = __ballot(is_c);
+        int base = 0;
+        if (lane == 0 && mk)
+          base = atomicAdd(&ncand, __popcll(mk));
+        base = __shfl(base, 0);
+        if (is_c)
+          cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
+      }
     }
   }
   __syncthreads();
