@@ -843,8 +843,10 @@ __device__ __forceinline__ double wave_max_f64_(double v)
   return v;
 }
 
-template <int CAP>
-__global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
+// THREADS = 256 (one work-group of four waves per sample) or 64 (one wave per sample: the class for at most 128 normals
+// of the r = 0.01 all-points pass).
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
@@ -856,11 +858,12 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   __shared__ int next_col;
   __shared__ double sM3[6];
   __shared__ double sAxis[3];
-  __shared__ double wbest[4];
-  __shared__ int wbest_j[4];
-  __shared__ double sT[4][28];
+  constexpr int NW = THREADS / 64;
+  __shared__ double wbest[NW];
+  __shared__ int wbest_j[NW];
+  __shared__ double sT[NW][28];
   __shared__ double sW[28];
-  __shared__ double wmax_s[4];
+  __shared__ double wmax_s[NW];
   __shared__ unsigned short cand[CAP];
   __shared__ int ncand;
 
@@ -871,7 +874,8 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   const bool ok = status[s] == kStatusOk && ev[11] != 0.0;
   // capacity classes: this instantiation owns the valid samples with nmin < n <= CAP; the first one (nmin == 0) also
   // writes the records of invalid samples
-  if (ok ? (n <= nmin || n > CAP) : (nmin != 0))
+  const int ks_class = (rand_mode && n > 50) ? 50 : n;  // normals the sample needs room for
+  if (ok ? (ks_class <= nmin || ks_class > CAP) : (nmin != 0))
     return;
   const bool valid = ok;
   const bool bad_index = status[s] == kStatusBadIndex;
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   }
   __syncthreads();
   const float4* nb = nbr + (int64_t) s * nbr_stride;
-  for (int t = tid; t < ks; t += 256)
+  for (int t = tid; t < ks; t += THREADS)
   {
     const int pick = sub ? (draws[draw_ofs[s] + t] % n) : t;
     const float4 p = nb[pick];
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   // (measured; with up to 128 it is not).
   if (ks <= 64)
   {
-    for (int j = tid; j < ks; j += 256)
+    for (int j = tid; j < ks; j += THREADS)
       cand[j] = (unsigned short) j;
     if (tid == 0)
       ncand = ks;
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   #pragma unroll
       for (int k = 0; k < 28; k++)
         T[k] = 0.0;
-      for (int t = tid; t < ks; t += 256)
+      for (int t = tid; t < ks; t += THREADS)
       {
         const double x = nx[t], y = ny[t], z = nz[t];
         double px[7], py[7], pz[7];
@@ -1011,11 +1015,13 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
           }
           k++;
         }
-      const double tsum = ((sT[0][tid] + sT[1][tid]) + sT[2][tid]) + sT[3][tid];
+      double tsum = sT[0][tid];
+      for (int w = 1; w < NW; w++)
+        tsum = tsum + sT[w][tid];
       sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
     }
     __syncthreads();
-    double est[CAP / 256];
+    double est[(CAP + THREADS - 1) / THREADS];
     double est_max = -1.0;
     {
       double W[28];
@@ -1023,9 +1029,9 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
       for (int k = 0; k < 28; k++)
         W[k] = sW[k];
   #pragma unroll
-      for (int m = 0; m < CAP / 256; m++)
+      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
       {
-        const int j = tid + 256 * m;
+        const int j = tid + THREADS * m;
         double e_ = -2.0;
         if (j < ks)
         {
@@ -1054,13 +1060,15 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
     if (lane == 0)
       wmax_s[wave] = est_max;
     __syncthreads();
-    est_max = fmax(fmax(wmax_s[0], wmax_s[1]), fmax(wmax_s[2], wmax_s[3]));
+    est_max = wmax_s[0];
+    for (int w = 1; w < NW; w++)
+      est_max = fmax(est_max, wmax_s[w]);
     {
       const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
   #pragma unroll
-      for (int m = 0; m < CAP / 256; m++)
+      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
       {
-        const int j = tid + 256 * m;
+        const int j = tid + THREADS * m;
         const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
         const unsigned long long mk = __ballot(is_c);
         int base = 0;
@@ -1177,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_taubin_frame(const float4* __restrict__
   __syncthreads();
   if (tid == 0)
   {
-    for (int w = 1; w < 4; w++)
+    for (int w = 1; w < NW; w++)
     {
       const double ob = wbest[w];
       const int oj = wbest_j[w];
@@ -1308,14 +1316,25 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   if (rand_mode)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
   const double* co = &c->p.cam_origin[0][0];
-  // capacity classes (LDS = 24 B per normal): voxelised clouds fit the 1280 class (4 blocks per CU); the 4096 class
-  // only does work for the samples that need it
-  hipLaunchKernelGGL(k_taubin_frame<1280>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
-    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 0, c->debug_stop_frame, (const int*) c->d_order);
-  hipLaunchKernelGGL(k_taubin_frame<4096>, dim3(Si), dim3(256), 0, st, c->d_nbr, c->nbr_stride, d_nt, c->d_eig,
-    c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], co[2],
-    co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, 1280, c->debug_stop_frame, (const int*) c->d_order);
+  // capacity classes (LDS = 24 B per normal) by the number of normals a sample needs: at most 128 (typical of the
+  // r = 0.01 all-points pass) -> one wave per sample; voxelised clouds at r = 0.03 fit the 1280 class (4 blocks per CU); the 4096 class only does work for the
+  // samples that need it
+  // (measured: in the production mode the four-wave kernel is faster -- its 50 exact column sums are shared by four
+  // waves -- so the one-wave class serves the all-points pass only: 5.3 -> 4.0 ms at 300k points)
+  const bool small_class = radius <= 0.015;
+#define AGH_LAUNCH_FRAME(CAP, THREADS, NMIN)                                                                            \
+  hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(Si), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,      \
+    c->d_eig, c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], \
+    co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, NMIN, c->debug_stop_frame,           \
+    (const int*) c->d_order)
+  if (small_class)
+    AGH_LAUNCH_FRAME(128, 64, 0);
+  if (small_class)
+    AGH_LAUNCH_FRAME(1280, 256, 128);
+  else
+    AGH_LAUNCH_FRAME(1280, 256, 0);
+  AGH_LAUNCH_FRAME(4096, 256, 1280);
+#undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
