@@ -327,3 +327,39 @@ def test_pcd_entry_point_and_messages(tmp_path, svm_model):
     for row, h in zip(hg, hd):
         assert row[:4] == [float(h["center"][0]), float(h["axis"][1]), float(h["approach"][2]), float(h["hands_center"][0])]
         assert np.float32(row[4]) == np.float32(h["width"])
+
+
+# ---- the example program (examples/localize_pcd.cpp): compiles everywhere, runs on a GPU box ----
+def _build_example(tmp_path):
+    from agile_grasp_amd import build
+
+    build.build()
+    exe = str(tmp_path / "localize_pcd")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "localize_pcd.cpp"), "-o", exe, "-L" + libdir,
+                           "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_example_compiles(tmp_path):
+    exe = _build_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "usage" in out.stdout
+
+
+@pytest.mark.gpu
+def test_example_runs_on_pcd_files(tmp_path):
+    exe = _build_example(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    left, right = str(tmp_path / "l.pcd"), str(tmp_path / "r.pcd")
+    _write_pcd(left, xyz[:size_left], True)
+    _write_pcd(right, xyz[size_left:], True)
+    out = subprocess.run([exe, os.path.join(GOLD, "svm_032015_linear_20_20_same"), left, right, "300", "3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    summary = [l for l in out.stdout.splitlines() if " hands, " in l and " handles" in l]
+    assert len(summary) == 1
+    n_hands, n_anti, n_handles = (int(t) for t in summary[0].replace(",", "").split()[0:6:2])
+    assert n_hands >= n_anti >= 0 and n_handles >= 0
+    assert len([l for l in out.stdout.splitlines() if l.startswith("grasp ")]) == n_handles
