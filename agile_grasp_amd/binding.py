@@ -83,7 +83,27 @@ EXPORTS = [
     "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
+    "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
 ]
+
+
+def pack_images(images: np.ndarray) -> np.ndarray:
+    """(n, 8000) uint8 images (0 / 255) -> (n, 250) uint32 words, bit (b & 31) of word (b >> 5) = pixel b."""
+    im = np.ascontiguousarray(images, np.uint8).reshape(-1, 8000) != 0
+    return np.packbits(im, axis=1, bitorder="little").view("<u4").reshape(-1, 250).copy()
+
+
+def unpack_images(words: np.ndarray) -> np.ndarray:
+    w = np.ascontiguousarray(words, "<u4").reshape(-1, 250)
+    return (np.unpackbits(w.view(np.uint8), axis=1, bitorder="little") * np.uint8(255)).reshape(-1, 8000)
+
+
+def save_svm_file(path: str, w: np.ndarray, rho: float) -> None:
+    """CvSVM::save of the compacted linear model (needs no device)."""
+    w = np.ascontiguousarray(w, np.float32)
+    rc = load_library().agh_save_svm_file(path.encode(), _p(w, C.c_float), C.c_int32(w.size), C.c_double(rho))
+    if rc != 0:
+        raise AghError(rc, f"cannot write {path}")
 
 
 class AghError(RuntimeError):
@@ -252,6 +272,37 @@ class Context:
         nr = np.zeros((self.n, 3), np.float64)
         self._check(self.lib.agh_get_normals(self._h, _p(nr, C.c_double), C.c_int64(self.n)))
         return nr
+
+    # ---- training side (learning.cpp:3-163, 249-318) ----
+    def set_training_images(self, on: bool = True):
+        self._check(self.lib.agh_set_training_images(self._h, C.c_int(1 if on else 0)))
+
+    def training_images(self) -> np.ndarray:
+        """(H, 3, 250) packed images of the last find_hands(calculates_antipodal=True): cam = -1, 0, 1."""
+        last_n = getattr(self, "last_n", 0)
+        im = np.zeros((max(last_n, 1), 3, 250), "<u4")
+        n = self._check(self.lib.agh_get_training_images(self._h, _p(im, C.c_uint32), C.c_int64(last_n)))
+        return im[:n]
+
+    def hog_images(self, packed: np.ndarray) -> np.ndarray:
+        packed = np.ascontiguousarray(packed, "<u4").reshape(-1, 250)
+        desc = np.zeros((packed.shape[0], 3528), np.float32)
+        self._check(self.lib.agh_hog_images(self._h, _p(packed, C.c_uint32), C.c_int64(packed.shape[0]), _p(desc, C.c_float)))
+        return desc
+
+    def train_svm(self, packed: np.ndarray, labels: np.ndarray, C_: float = 1.0, max_iter: int = 1000,
+                  eps: float = 1.1920928955078125e-07) -> dict:
+        packed = np.ascontiguousarray(packed, "<u4").reshape(-1, 250)
+        lab = np.ascontiguousarray(np.where(np.asarray(labels) > 0, 1, -1), np.int8)
+        assert lab.shape[0] == packed.shape[0]
+        w = np.zeros(3528, np.float32)
+        rho = C.c_double(0)
+        info = np.zeros(4, np.int32)
+        self._check(self.lib.agh_train_svm(self._h, _p(packed, C.c_uint32), _p(lab, C.c_int8), C.c_int64(packed.shape[0]),
+                                           C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _p(w, C.c_float),
+                                           C.byref(rho), _p(info, C.c_int32)))
+        return {"w": w, "rho": rho.value, "iterations": int(info[0]), "n_sv": int(info[1]), "n_neg": int(info[2]),
+                "n_pos": int(info[3])}
 
     def load_svm(self, w: np.ndarray, rho: float):
         w = np.ascontiguousarray(w, np.float32)

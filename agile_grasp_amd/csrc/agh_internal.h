@@ -185,6 +185,10 @@ struct Ctx
   agh_hypothesis* d_out_own = nullptr;  // compacted hypotheses when the caller gave host memory
   int64_t* d_nout = nullptr;
   uint32_t* d_out_images = nullptr;     // compacted images (s_cap * 8 * kImageWords)
+  uint32_t* d_images_cam = nullptr;     // training side: per slot the camera-0 and camera-1 images (s_cap * 16 * kImageWords)
+  int64_t images_cam_cap = 0;           // in samples
+  bool training_images = false;         // agh_set_training_images
+  bool last_has_cam_images = false;     // the last hand sweep filled d_images_cam
   int32_t* d_draw_ofs = nullptr;        // RAND50: offset of each sample's 50 draws
   int32_t* d_draws = nullptr;
   int64_t draws_cap = 0;
@@ -235,6 +239,7 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
 int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
+int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st);
 void hog_tables_host(HogTablesDev* t);
 int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);
 

@@ -76,14 +76,20 @@ __device__ __forceinline__ unsigned lowmask(int n)
 
 // PX / PY: look-up probes per finger-slot threshold cell / bite-depth cell (HandGeom::x_probes, y_probes): the default
 // hand needs 2 and 1, any admissible geometry at most kLutProbe.
-template <bool NORMALS, int PX, int PY>
+// MODE: 0 = occupancy sweep only; 1 = with the antipodal counts (cloud normals); 2 = mode 1 plus one image per camera
+// for the training instances createInstance(h, cam_pos, cam = 0 / 1) (learning.cpp:389-397).
+template <int MODE, int PX, int PY>
 __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
-  const int* __restrict__ order, uint8_t* __restrict__ vmask, double2* __restrict__ spill_all, int spill_cap)
+  const int* __restrict__ order, uint8_t* __restrict__ vmask, double2* __restrict__ spill_all, int spill_cap,
+  uint32_t* __restrict__ images_cam)
 {
-  constexpr int kTile = NORMALS ? 1728 : 2176;  // the block must stay under a third of the CU's 160 KiB (512-B granules)
+  constexpr bool NORMALS = MODE != 0, TRAIN = MODE == 2;
+  constexpr int kImgPlanes = TRAIN ? 16 : 8;  // TRAIN: plane o = camera 0's points, plane 8 + o = camera 1's
+  // the block must stay under a third of the CU's 160 KiB (512-B granules)
+  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : 2176);
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   __shared__ OriState ori[8];
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
-  __shared__ unsigned img[8][kImageWords + 2];
+  __shared__ unsigned img[kImgPlanes][kImageWords + 2];
   __shared__ int cnt_ball, cnt_crop, any_hand, pending, tile_end;
 
   const int s = order[blockIdx.x];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   }
   for (int k = tid; k < 8 * 44; k += 256)
     (&regmask[0][0])[k] = 0u;
-  for (int k = tid; k < 8 * (kImageWords + 2); k += 256)
+  for (int k = tid; k < kImgPlanes * (kImageWords + 2); k += 256)
     (&img[0][0])[k] = 0u;
   const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
   build_rows(gv, sx, sy, sz, rpad, rt);  // ends with barriers: G and counters are visible afterwards
@@ -619,7 +625,10 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
               hc = min(99, max(0, hc));
               vc = min(79, max(0, vc));
               const int bit = (79 - vc) * 100 + hc;
-              atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
+              if (TRAIN)  // pid = (index << 1) | camera
+                atomicOr(&img[o + 8 * (int) (pid[t0 + 64 * u] & 1u)][bit >> 5], 1u << (bit & 31));
+              else
+                atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
               if (NORMALS)
               {
                 const double* nn = normals + 3 * (int64_t) (pid[t0 + 64 * u] >> 1);
@@ -688,7 +697,17 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     for (int k = lane; k < kImageWords; k += 64)
-      images[((int64_t) s * 8 + o) * kImageWords + k] = img[o][k];
+    {
+      if (TRAIN)  // ins.pts of cam = -1 is the union of the two cameras' points
+      {
+        const unsigned a = img[o][k], b = img[o + 8][k];
+        images[((int64_t) s * 8 + o) * kImageWords + k] = a | b;
+        images_cam[(((int64_t) s * 8 + o) * 2 + 0) * kImageWords + k] = a;
+        images_cam[(((int64_t) s * 8 + o) * 2 + 1) * kImageWords + k] = b;
+      }
+      else
+        images[((int64_t) s * 8 + o) * kImageWords + k] = img[o][k];
+    }
   }
   if (debug_stop == 6)
     return;
@@ -881,15 +900,19 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
   hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
     r2f, rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
-    (const int*) c->d_order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride)
-  if (nrm && few)
-    AGH_LAUNCH_SWEEP(true, 2, 1);
+    (const int*) c->d_order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
+  const bool train = nrm && c->training_images && c->d_images_cam;
+  if (train)
+    AGH_LAUNCH_SWEEP(2, kLutProbe, kLutProbe);  // (offline path: one instantiation covers every geometry)
+  else if (nrm && few)
+    AGH_LAUNCH_SWEEP(1, 2, 1);
   else if (nrm)
-    AGH_LAUNCH_SWEEP(true, kLutProbe, kLutProbe);
+    AGH_LAUNCH_SWEEP(1, kLutProbe, kLutProbe);
   else if (few)
-    AGH_LAUNCH_SWEEP(false, 2, 1);
+    AGH_LAUNCH_SWEEP(0, 2, 1);
   else
-    AGH_LAUNCH_SWEEP(false, kLutProbe, kLutProbe);
+    AGH_LAUNCH_SWEEP(0, kLutProbe, kLutProbe);
+  c->last_has_cam_images = train;
 #undef AGH_LAUNCH_SWEEP
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;

@@ -202,13 +202,13 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   __shared__ __attribute__((aligned(16))) HogTablesDev Ts;  // the 11 KiB of tables are hit on every vote: keep them in LDS
 
   const int h = blockIdx.x;
-  if ((int64_t) h >= *n_hyp)
+  if (n_hyp && (int64_t) h >= *n_hyp)  // (n_hyp == nullptr: the grid is exact -- the training path's descriptor pass)
     return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = tid; k < (int) (sizeof(HogTablesDev) / 4); k += 256)
     ((unsigned*) &Ts)[k] = ((const unsigned*) Tg)[k];
   const HogTablesDev* T = &Ts;
-  const uint32_t* im = images + (int64_t) slot_of_hyp[h] * kImageWords;
+  const uint32_t* im = images + (int64_t) (slot_of_hyp ? slot_of_hyp[h] : h) * kImageWords;
   for (int k = tid; k < kImageWords; k += 256)
     bm[k] = im[k];
   __syncthreads();
@@ -338,14 +338,17 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
     const int bw = idx / 36, j = idx % 36;
     const int b = (win * 4 + bw / 7) * 7 + bw % 7;
     const float* d = &hist[b][j];
-    const float* w = svm_w + m * 4;
-    grp[m] = w[0] * d[0] + w[1] * d[1] + w[2] * d[2] + w[3] * d[3];  // CvSVMKernel::calc_non_rbf_base
+    if (svm_w)
+    {
+      const float* w = svm_w + m * 4;
+      grp[m] = w[0] * d[0] + w[1] * d[1] + w[2] * d[2] + w[3] * d[3];  // CvSVMKernel::calc_non_rbf_base
+    }
     if (desc_out)
       for (int q = 0; q < 4; q++)
         desc_out[(int64_t) h * 3528 + m * 4 + q] = d[q];
   }
   __syncthreads();
-  if (debug_stop == 5)
+  if (debug_stop == 5 || !svm_w)  // (no model: descriptors only)
     return;
   if (tid == 0)
   {
@@ -381,6 +384,17 @@ int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st)
     c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out,
     std::getenv("AGH_DEBUG_STOP_HOG") ? std::atoi(std::getenv("AGH_DEBUG_STOP_HOG")) : 0);
   timing_mark(c, "hog_svm", st);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+// Descriptors of `n` packed images (image index order[h] -> descriptor row h; order may be null): the feature pass of
+// Learning::convertData (learning.cpp:253-288).
+int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st)
+{
+  if (n <= 0)
+    return AGH_OK;
+  hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n), dim3(256), 0, st, d_images, d_order, (const int64_t*) nullptr, c->d_hog,
+    (const float*) nullptr, 0.0, (agh_hypothesis*) nullptr, (uint8_t*) nullptr, (double*) nullptr, d_desc, 0);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 

@@ -1,0 +1,665 @@
+// train.hip -- f4, the training side: Learning::convertData (src/agile_grasp/learning.cpp:249-318).
+//
+//   image list -> cv::HOGDescriptor::compute (learning.cpp:253-281)    k_hog_svm without a model (hog_svm.hip)
+//   CvSVM::train(features, labels, C_SVC, LINEAR)   (296-311)          the kernels below
+//   CvSVM::save                                     (312)              agh_save_svm_file
+//
+// CvSVM::train is OpenCV 2.4 modules/ml/src/svm.cpp (THIRD PARTY, not in the reference tree, not in this image).  Its
+// solver is a sequential SMO -- one maximal-violating pair per step, at most term_crit.max_iter = 1000 steps -- whose
+// per-step work is data parallel over the n training instances:
+//   * select_working_set: two arg-max reductions over the gradient (strict '>': lowest index wins a tie);
+//   * two kernel rows Q_i, Q_j: n dot products of 3528 floats each against x_i and x_j (calc_non_rbf_base: float
+//     products summed four at a time in float, accumulated in double in index order, stored as float);
+//   * G[k] += Q_i[k] * d_alpha_i + Q_j[k] * d_alpha_j.
+// k_svm_select (one work-group) does the reductions, the K(i,j) dot product and the clipped two-variable update;
+// k_svm_update (one thread per instance) computes its entry of both rows from the transposed feature matrix (so a
+// wavefront reads 64 consecutive instances of one feature: coalesced) and updates its gradient entry.  Every float
+// and double operation keeps the order of the CPU code, so the model is bit-identical to the oracle's restatement
+// (oracle/agile_oracle.cpp orc_train_svm; parity with OpenCV itself is unpinned -- see DESIGN.md).
+//
+// HBM traffic per step: the transposed features once (n x 3528 x 4 B) + O(n) vectors; the kernel is bound by the
+// dependent double-precision accumulation chain (882 links per row), not by bandwidth, unless n is large.
+#include "agh_internal.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace agh
+{
+
+constexpr int kDesc = 3528;  // 2 windows x 49 blocks x 36
+constexpr int kGroups = kDesc / 4;
+
+struct SvmState
+{
+  int i, j;
+  int stop;
+  int iter;
+  double d_i, d_j;
+  double gap;  // Gmax1 + Gmax2 of the last selection
+};
+
+// X (n x kDesc, row-major) -> XT (kDesc x n)
+__global__ __launch_bounds__(256) void k_svm_transpose(const float* __restrict__ X, float* __restrict__ XT, int n)
+{
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int k0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8)
+  {
+    const int t = t0 + r, k = k0 + tx;
+    tile[r][tx] = (t < n && k < kDesc) ? X[(int64_t) t * kDesc + k] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+  {
+    const int k = k0 + r, t = t0 + tx;
+    if (k < kDesc && t < n)
+      XT[(int64_t) k * n + t] = tile[tx][r];
+  }
+}
+
+// CvSVMKernel::calc_non_rbf_base for one pair of vectors: `a` strided (transposed matrix), `b` contiguous.
+__device__ __forceinline__ float qfloat(double s)
+{
+  float q = (float) (s * 1.0 + 0.0);
+  const float max_val = (float) (FLT_MAX * 1e-3);
+  return q > max_val ? max_val : q;  // CvSVMKernel::calc
+}
+
+__global__ __launch_bounds__(256) void k_svm_init(const float* __restrict__ XT, int n, float* __restrict__ Kdiag,
+  double* __restrict__ alpha, double* __restrict__ G, int8_t* __restrict__ status, SvmState* __restrict__ st)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0)
+  {
+    st->i = st->j = -1;
+    st->stop = 0;
+    st->iter = 0;
+    st->d_i = st->d_j = 0.0;
+    st->gap = 0.0;
+  }
+  if (t >= n)
+    return;
+  double s = 0;
+  for (int g = 0; g < kGroups; g++)
+  {
+    const float a0 = XT[(int64_t) (4 * g + 0) * n + t], a1 = XT[(int64_t) (4 * g + 1) * n + t];
+    const float a2 = XT[(int64_t) (4 * g + 2) * n + t], a3 = XT[(int64_t) (4 * g + 3) * n + t];
+    s += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+  }
+  Kdiag[t] = qfloat(s);
+  alpha[t] = 0.0;  // solve_c_svc: alpha = 0, b = -1  =>  G = b, every alpha at its lower bound
+  G[t] = -1.0;
+  status[t] = -1;
+}
+
+struct ArgMax
+{
+  double v;
+  int idx;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b)  // larger value; on a tie the lower index (sequential '>')
+{
+  const bool take_b = b.v > a.v || (b.v == a.v && b.idx >= 0 && (a.idx < 0 || b.idx < a.idx));
+  return take_b ? b : a;
+}
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
+{
+  for (int off = 32; off >= 1; off >>= 1)
+  {
+    ArgMax b;
+    b.v = __shfl_xor(a.v, off);
+    b.idx = __shfl_xor(a.idx, off);
+    a = better(a, b);
+  }
+  return a;
+}
+
+// CvSVMSolver::select_working_set + the two-variable update of solve_generic.  y[k] = +1 for class 0 (label -1).
+__global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X, int n, const int8_t* __restrict__ y,
+  double* __restrict__ alpha, int8_t* __restrict__ status, const double* __restrict__ G, const float* __restrict__ Kdiag,
+  SvmState* __restrict__ st, double C, double eps, int max_iter)
+{
+  __shared__ ArgMax red1[16], red2[16];
+  __shared__ int sel[2];
+  __shared__ float grp[kGroups];
+  if (st->stop)
+    return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ArgMax m1{ -DBL_MAX, -1 }, m2{ -DBL_MAX, -1 };
+  for (int t = tid; t < n; t += 1024)
+  {
+    const double g = G[t];
+    const int s = status[t];
+    const bool ub = s > 0, lb = s < 0;
+    if (y[t] > 0)
+    {
+      if (!ub && -g > m1.v)
+        m1 = ArgMax{ -g, t };
+      if (!lb && g > m2.v)
+        m2 = ArgMax{ g, t };
+    }
+    else
+    {
+      if (!ub && -g > m2.v)
+        m2 = ArgMax{ -g, t };
+      if (!lb && g > m1.v)
+        m1 = ArgMax{ g, t };
+    }
+  }
+  m1 = wave_argmax(m1);
+  m2 = wave_argmax(m2);
+  if (lane == 0)
+  {
+    red1[wave] = m1;
+    red2[wave] = m2;
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    for (int w = 1; w < 16; w++)
+    {
+      m1 = better(m1, red1[w]);
+      m2 = better(m2, red2[w]);
+    }
+    int stop = 0;
+    if (m1.v + m2.v < eps)
+      stop = 1;
+    else if (st->iter >= max_iter)  // `select() != 0 || iter++ >= max_iter`
+      stop = 1;
+    else
+      st->iter = st->iter + 1;
+    st->gap = m1.v + m2.v;
+    if (stop)
+      st->stop = 1;
+    sel[0] = stop ? -1 : m1.idx;
+    sel[1] = stop ? -1 : m2.idx;
+  }
+  __syncthreads();
+  const int i = sel[0], j = sel[1];
+  if (i < 0 || j < 0)
+  {
+    if (tid == 0)
+      st->stop = 1;
+    return;
+  }
+  // K(i, j), calc_non_rbf_base order: 882 float group sums, then one double chain
+  const float* xi = X + (int64_t) i * kDesc;
+  const float* xj = X + (int64_t) j * kDesc;
+  if (tid < kGroups)
+  {
+    const float4 a = reinterpret_cast<const float4*>(xj)[tid];  // sample = vecs[j], another = x_i
+    const float4 b = reinterpret_cast<const float4*>(xi)[tid];
+    grp[tid] = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  __syncthreads();
+  if (tid != 0)
+    return;
+  double s = 0;
+  for (int g0 = 0; g0 < kGroups; g0 += 14)  // 882 = 63 x 14
+  {
+    float v[14];
+#pragma unroll
+    for (int u = 0; u < 14; u++)
+      v[u] = grp[g0 + u];
+#pragma unroll
+    for (int u = 0; u < 14; u++)
+      s += v[u];
+  }
+  const float kij = qfloat(s);
+  const int yi = y[i], yj = y[j];
+  const float Qii = Kdiag[i], Qjj = Kdiag[j];               // get_row_svc: y_i * y_i = 1
+  const float Qij = yi > 0 ? yj * kij : -yj * kij;          // row_i[j]
+  const double C_i = C, C_j = C;
+  double alpha_i = alpha[i], alpha_j = alpha[j];
+  const double old_i = alpha_i, old_j = alpha_j;
+  const double Gi = G[i], Gj = G[j];
+  if (yi != yj)
+  {
+    const double denom = Qii + Qjj + 2 * Qij;  // float arithmetic, as the Qfloat expression in the reference
+    const double delta = (-Gi - Gj) / fmax(fabs(denom), (double) FLT_EPSILON);
+    const double diff = alpha_i - alpha_j;
+    alpha_i += delta;
+    alpha_j += delta;
+    if (diff > 0 && alpha_j < 0)
+    {
+      alpha_j = 0;
+      alpha_i = diff;
+    }
+    else if (diff <= 0 && alpha_i < 0)
+    {
+      alpha_i = 0;
+      alpha_j = -diff;
+    }
+    if (diff > C_i - C_j && alpha_i > C_i)
+    {
+      alpha_i = C_i;
+      alpha_j = C_i - diff;
+    }
+    else if (diff <= C_i - C_j && alpha_j > C_j)
+    {
+      alpha_j = C_j;
+      alpha_i = C_j + diff;
+    }
+  }
+  else
+  {
+    const double denom = Qii + Qjj - 2 * Qij;
+    const double delta = (Gi - Gj) / fmax(fabs(denom), (double) FLT_EPSILON);
+    const double sum = alpha_i + alpha_j;
+    alpha_i -= delta;
+    alpha_j += delta;
+    if (sum > C_i && alpha_i > C_i)
+    {
+      alpha_i = C_i;
+      alpha_j = sum - C_i;
+    }
+    else if (sum <= C_i && alpha_j < 0)
+    {
+      alpha_j = 0;
+      alpha_i = sum;
+    }
+    if (sum > C_j && alpha_j > C_j)
+    {
+      alpha_j = C_j;
+      alpha_i = sum - C_j;
+    }
+    else if (sum <= C_j && alpha_i < 0)
+    {
+      alpha_i = 0;
+      alpha_j = sum;
+    }
+  }
+  alpha[i] = alpha_i;
+  alpha[j] = alpha_j;
+  status[i] = alpha_i >= C_i ? 1 : (alpha_i <= 0 ? -1 : 0);
+  status[j] = alpha_j >= C_j ? 1 : (alpha_j <= 0 ? -1 : 0);
+  st->i = i;
+  st->j = j;
+  st->d_i = alpha_i - old_i;
+  st->d_j = alpha_j - old_j;
+}
+
+// Rows Q_i, Q_j of the step's pair (one entry per thread) and the gradient update.
+__global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X, const float* __restrict__ XT, int n,
+  const int8_t* __restrict__ y, double* __restrict__ G, const SvmState* __restrict__ st)
+{
+  __shared__ __attribute__((aligned(16))) float xi[kDesc];
+  __shared__ __attribute__((aligned(16))) float xj[kDesc];
+  if (st->stop)
+    return;
+  const int i = st->i, j = st->j;
+  const double d_i = st->d_i, d_j = st->d_j;
+  for (int k = threadIdx.x; k < kGroups; k += 256)
+  {
+    reinterpret_cast<float4*>(xi)[k] = reinterpret_cast<const float4*>(X + (int64_t) i * kDesc)[k];
+    reinterpret_cast<float4*>(xj)[k] = reinterpret_cast<const float4*>(X + (int64_t) j * kDesc)[k];
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int tc = t < n ? t : n - 1;
+  const float* col = XT + tc;
+  double si = 0, sj = 0;
+#pragma unroll 2
+  for (int g = 0; g < kGroups; g++)
+  {
+    const float a0 = col[(int64_t) (4 * g + 0) * n], a1 = col[(int64_t) (4 * g + 1) * n];
+    const float a2 = col[(int64_t) (4 * g + 2) * n], a3 = col[(int64_t) (4 * g + 3) * n];
+    const float4 bi = reinterpret_cast<const float4*>(xi)[g];
+    const float4 bj = reinterpret_cast<const float4*>(xj)[g];
+    si += a0 * bi.x + a1 * bi.y + a2 * bi.z + a3 * bi.w;
+    sj += a0 * bj.x + a1 * bj.y + a2 * bj.z + a3 * bj.w;
+  }
+  if (t >= n)
+    return;
+  const float ki = qfloat(si), kj = qfloat(sj);
+  const int yt = y[t];
+  const float Qi = y[i] > 0 ? yt * ki : -yt * ki;  // get_row_svc
+  const float Qj = y[j] > 0 ? yt * kj : -yt * kj;
+  G[t] = G[t] + (Qi * d_i + Qj * d_j);
+}
+
+// CvSVM::optimize_linear_svm: v[k] = sum over the support vectors, in order, of sv[k] * alpha (double), stored as float.
+__global__ __launch_bounds__(256) void k_svm_compress(const float* __restrict__ X, int n, const double* __restrict__ a_signed,
+  float* __restrict__ w)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kDesc)
+    return;
+  double v = 0;
+  for (int t = 0; t < n; t++)
+  {
+    const double a = a_signed[t];
+    if (fabs(a) > 0)
+      v += X[(int64_t) t * kDesc + k] * a;
+  }
+  w[k] = (float) v;
+}
+
+// images (n_images x kImageWords, packed) + order (instance k of the solver = image order[k]; class 0 first) -> model.
+int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t* h_order, const int8_t* h_y, int64_t n,
+  double C, int max_iter, double eps, float* weights_out, double* rho_out, int32_t* info_out, float* desc_out_host,
+  hipStream_t st)
+{
+  uint32_t* d_img = nullptr;
+  int32_t* d_ord = nullptr;
+  int8_t *d_y = nullptr, *d_status = nullptr;
+  float *d_X = nullptr, *d_XT = nullptr, *d_diag = nullptr, *d_w = nullptr;
+  double *d_alpha = nullptr, *d_G = nullptr, *d_as = nullptr;
+  SvmState* d_st = nullptr;
+  int rc = AGH_OK;
+  auto fail = [&](const char* what, hipError_t e) {
+    c->err = std::string("agh_train_svm: ") + what + ": " + hipGetErrorString(e);
+    rc = AGH_ERR_HIP;
+  };
+#define TRY(expr)                     \
+  do                                  \
+  {                                   \
+    hipError_t e__ = (expr);          \
+    if (rc == AGH_OK && e__ != hipSuccess) \
+      fail(#expr, e__);               \
+  } while (0)
+  TRY(hipMalloc((void**) &d_img, (size_t) n_images * kImageWords * 4));
+  TRY(hipMalloc((void**) &d_ord, (size_t) n * 4));
+  TRY(hipMalloc((void**) &d_y, (size_t) n));
+  TRY(hipMalloc((void**) &d_status, (size_t) n));
+  TRY(hipMalloc((void**) &d_X, (size_t) n * kDesc * 4));
+  TRY(hipMalloc((void**) &d_XT, (size_t) n * kDesc * 4));
+  TRY(hipMalloc((void**) &d_diag, (size_t) n * 4));
+  TRY(hipMalloc((void**) &d_w, (size_t) kDesc * 4));
+  TRY(hipMalloc((void**) &d_alpha, (size_t) n * 8));
+  TRY(hipMalloc((void**) &d_G, (size_t) n * 8));
+  TRY(hipMalloc((void**) &d_as, (size_t) n * 8));
+  TRY(hipMalloc((void**) &d_st, sizeof(SvmState)));
+  std::vector<double> alpha((size_t) n), G((size_t) n), a_signed((size_t) n);
+  std::vector<int8_t> status((size_t) n);
+  SvmState hs;
+  std::memset(&hs, 0, sizeof(hs));
+  if (rc == AGH_OK)
+  {
+    TRY(hipMemcpyAsync(d_img, h_images, (size_t) n_images * kImageWords * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_ord, h_order, (size_t) n * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(d_y, h_y, (size_t) n, hipMemcpyHostToDevice, st));
+    if (rc == AGH_OK)
+      rc = hog_images(c, d_img, d_ord, n, d_X, st);
+    const int ni = (int) n;
+    hipLaunchKernelGGL(k_svm_transpose, dim3((kDesc + 31) / 32, (unsigned) ((n + 31) / 32)), dim3(256), 0, st, d_X, d_XT, ni);
+    hipLaunchKernelGGL(k_svm_init, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_XT, ni, d_diag, d_alpha, d_G,
+      d_status, d_st);
+    const int batch = 50;  // steps between looks at the stop flag (a finished solve turns the rest into empty launches)
+    for (int done = 0; rc == AGH_OK && done <= max_iter; done += batch)
+    {
+      for (int b = 0; b < batch; b++)
+      {
+        hipLaunchKernelGGL(k_svm_select, dim3(1), dim3(1024), 0, st, d_X, ni, d_y, d_alpha, d_status, d_G, d_diag, d_st, C,
+          eps, max_iter);
+        hipLaunchKernelGGL(k_svm_update, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_X, d_XT, ni, d_y, d_G,
+          d_st);
+      }
+      TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
+      TRY(hipStreamSynchronize(st));
+      if (hs.stop)
+        break;
+    }
+    if (rc == AGH_OK && !hs.stop)
+    {
+      c->err = "agh_train_svm: the solver did not reach its stop state";
+      rc = AGH_ERR_STATE;
+    }
+  }
+  if (rc == AGH_OK)
+  {
+    TRY(hipMemcpyAsync(alpha.data(), d_alpha, (size_t) n * 8, hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(G.data(), d_G, (size_t) n * 8, hipMemcpyDeviceToHost, st));
+    TRY(hipMemcpyAsync(status.data(), d_status, (size_t) n, hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+  }
+  if (rc == AGH_OK)
+  {
+    // CvSVMSolver::calc_rho (host: one pass over n values)
+    int nr_free = 0, n_sv = 0;
+    double ub = DBL_MAX, lb = -DBL_MAX, sum_free = 0;
+    for (int64_t k = 0; k < n; k++)
+    {
+      const double yG = h_y[k] * G[(size_t) k];
+      if (status[(size_t) k] < 0)
+      {
+        if (h_y[k] > 0)
+          ub = std::fmin(ub, yG);
+        else
+          lb = std::fmax(lb, yG);
+      }
+      else if (status[(size_t) k] > 0)
+      {
+        if (h_y[k] < 0)
+          ub = std::fmin(ub, yG);
+        else
+          lb = std::fmax(lb, yG);
+      }
+      else
+      {
+        ++nr_free;
+        sum_free += yG;
+      }
+      a_signed[(size_t) k] = alpha[(size_t) k] * h_y[k];  // do_train: alpha *= y
+      n_sv += std::fabs(a_signed[(size_t) k]) > 0 ? 1 : 0;
+    }
+    *rho_out = nr_free > 0 ? sum_free / nr_free : (ub + lb) * 0.5;
+    TRY(hipMemcpyAsync(d_as, a_signed.data(), (size_t) n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_svm_compress, dim3((kDesc + 255) / 256), dim3(256), 0, st, d_X, (int) n, d_as, d_w);
+    TRY(hipMemcpyAsync(weights_out, d_w, (size_t) kDesc * 4, hipMemcpyDeviceToHost, st));
+    if (desc_out_host)
+      TRY(hipMemcpyAsync(desc_out_host, d_X, (size_t) n * kDesc * 4, hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    TRY(hipGetLastError());
+    if (info_out)
+    {
+      info_out[0] = hs.iter;
+      info_out[1] = n_sv;
+    }
+  }
+#undef TRY
+  for (void* p : { (void*) d_img, (void*) d_ord, (void*) d_y, (void*) d_status, (void*) d_X, (void*) d_XT, (void*) d_diag,
+         (void*) d_w, (void*) d_alpha, (void*) d_G, (void*) d_as, (void*) d_st })
+    if (p)
+      (void) hipFree(p);
+  return rc;
+}
+
+}  // namespace agh
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------
+using namespace agh;
+
+extern "C" {
+
+int agh_set_training_images(agh_ctx* ctx, int on)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  c->training_images = on != 0;
+  if (!on)
+    return AGH_OK;
+  if (hipSetDevice(c->device) != hipSuccess)
+    return AGH_ERR_HIP;
+  if (c->s_cap > c->images_cam_cap)  // (otherwise allocated with the per-call buffers)
+  {
+    if (c->d_images_cam)
+      (void) hipFree(c->d_images_cam);
+    c->d_images_cam = nullptr;
+    c->images_cam_cap = 0;
+    if (hipMalloc((void**) &c->d_images_cam, (size_t) c->s_cap * 16 * kImageWords * 4) != hipSuccess)
+    {
+      c->err = "agh_set_training_images: out of device memory";
+      return AGH_ERR_HIP;
+    }
+    c->images_cam_cap = c->s_cap;
+  }
+  return AGH_OK;
+}
+
+int agh_get_training_images(agh_ctx* ctx, uint32_t* images, int64_t cap_hyp)
+{
+  if (!ctx || !images)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (c->last_nout < 0 || !c->last_has_cam_images)
+  {
+    c->err = "agh_get_training_images: needs agh_set_training_images(1) and a completed "
+             "agh_find_hands(calculates_antipodal = 1) call";
+    return AGH_ERR_STATE;
+  }
+  const int64_t n = std::min<int64_t>(cap_hyp, c->last_nout);
+  if (n == 0)
+    return 0;
+  if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    return AGH_ERR_HIP;
+  std::vector<int32_t> slot((size_t) n);
+  std::vector<uint32_t> all((size_t) c->last_s * 8 * kImageWords), cam((size_t) c->last_s * 16 * kImageWords);
+  if (hipMemcpy(slot.data(), c->d_slot_index, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(all.data(), c->d_images, all.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(cam.data(), c->d_images_cam, cam.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+  {
+    c->err = "agh_get_training_images: copy failed";
+    return AGH_ERR_HIP;
+  }
+  for (int64_t h = 0; h < n; h++)  // instance order of Learning::train: cam = -1, 0, 1 (learning.cpp:93-97)
+  {
+    uint32_t* dst = images + h * 3 * kImageWords;
+    std::memcpy(dst, &all[(size_t) slot[h] * kImageWords], kImageWords * 4);
+    std::memcpy(dst + kImageWords, &cam[(size_t) slot[h] * 2 * kImageWords], 2 * kImageWords * 4);
+  }
+  return (int) n;
+}
+
+int agh_hog_images(agh_ctx* ctx, const uint32_t* images, int64_t n, float* desc)
+{
+  if (!ctx || n < 0 || (n > 0 && (!images || !desc)))
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n == 0)
+    return AGH_OK;
+  if (hipSetDevice(c->device) != hipSuccess)
+    return AGH_ERR_HIP;
+  uint32_t* d_img = nullptr;
+  float* d_desc = nullptr;
+  int rc = AGH_OK;
+  if (hipMalloc((void**) &d_img, (size_t) n * kImageWords * 4) != hipSuccess ||
+      hipMalloc((void**) &d_desc, (size_t) n * kDesc * 4) != hipSuccess)
+    rc = AGH_ERR_HIP;
+  if (rc == AGH_OK && hipMemcpyAsync(d_img, images, (size_t) n * kImageWords * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = AGH_ERR_HIP;
+  if (rc == AGH_OK)
+    rc = hog_images(c, d_img, nullptr, n, d_desc, c->stream);
+  if (rc == AGH_OK && (hipMemcpyAsync(desc, d_desc, (size_t) n * kDesc * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                        hipStreamSynchronize(c->stream) != hipSuccess))
+    rc = AGH_ERR_HIP;
+  if (rc != AGH_OK)
+    c->err = "agh_hog_images: device allocation, copy or launch failed";
+  if (d_img)
+    (void) hipFree(d_img);
+  if (d_desc)
+    (void) hipFree(d_desc);
+  return rc;
+}
+
+int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, double C, int32_t max_iter,
+  double eps, float* weights_out, double* rho_out, int32_t* info_out)
+{
+  if (!ctx || !images || !labels || !weights_out || !rho_out || n <= 0 || n >= (1ll << 24) || !(C > 0) || max_iter < 0)
+  {
+    if (ctx)
+      ctx->c.err = "agh_train_svm: need images, labels, 0 < n < 2^24, C > 0, max_iter >= 0 and the two outputs";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  Ctx* c = &ctx->c;
+  // cvSortSamplesByClasses: class 0 (label -1, y = +1) first, original order inside a class
+  std::vector<int32_t> order;
+  order.reserve((size_t) n);
+  for (int64_t k = 0; k < n; k++)
+    if (labels[k] <= 0)
+      order.push_back((int32_t) k);
+  const int64_t n0 = (int64_t) order.size();
+  for (int64_t k = 0; k < n; k++)
+    if (labels[k] > 0)
+      order.push_back((int32_t) k);
+  if (n0 == 0 || n0 == n)
+  {
+    c->err = "agh_train_svm: the training set holds a single class";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<int8_t> y((size_t) n);
+  for (int64_t k = 0; k < n; k++)
+    y[(size_t) k] = k < n0 ? 1 : -1;
+  if (hipSetDevice(c->device) != hipSuccess)
+    return AGH_ERR_HIP;
+  int32_t info[2] = { 0, 0 };
+  const int rc = svm_train(c, images, n, order.data(), y.data(), n, C, max_iter, eps, weights_out, rho_out, info, nullptr,
+    c->stream);
+  if (rc == AGH_OK && info_out)
+  {
+    info_out[0] = info[0];
+    info_out[1] = info[1];
+    info_out[2] = (int32_t) n0;
+    info_out[3] = (int32_t) (n - n0);
+  }
+  return rc;
+}
+
+// CvSVM::save of the compacted linear model, laid out as cv::FileStorage's YAML emitter does (reals "%.8e" / "%.16e",
+// integers-valued reals "%d.", flow sequences wrapped before column 72): the reference's shipped model file is
+// reproduced byte for byte from its weights and rho (tests/test_training.py).
+int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights, double rho)
+{
+  if (!path || !weights || n_weights <= 0)
+    return AGH_ERR_INVALID_ARGUMENT;
+  FILE* f = std::fopen(path, "wb");
+  if (!f)
+    return AGH_ERR_IO;
+  auto real = [](double v, const char* fmt, char* buf) {
+    const long iv = std::lrint(v);
+    if ((double) iv == v)
+      std::snprintf(buf, 64, "%ld.", iv);
+    else
+      std::snprintf(buf, 64, fmt, v);
+  };
+  std::string txt = "%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n   kernel: { type:LINEAR }\n   C: 1.\n"
+                    "   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n";
+  txt += "   var_all: " + std::to_string(n_weights) + "\n   var_count: " + std::to_string(n_weights) + "\n";
+  txt += "   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n      dt: i\n"
+         "      data: [ -1, 1 ]\n   sv_total: 1\n   support_vectors:\n";
+  const size_t indent = 10, margin = 71;
+  std::string line = "      - [";
+  char buf[64];
+  for (int k = 0; k < n_weights; k++)
+  {
+    real((double) weights[k], "%.8e", buf);
+    if (k)
+      line += ',';
+    const size_t off = line.size() + std::strlen(buf);
+    if (off > margin && off - indent > 10)
+    {
+      txt += line + "\n";
+      line = std::string(indent, ' ') + buf;
+    }
+    else
+    {
+      line += ' ';
+      line += buf;
+    }
+  }
+  txt += line + " ]\n";
+  real(rho, "%.16e", buf);
+  txt += std::string("   decision_functions:\n      -\n         sv_count: 1\n         rho: ") + buf +
+         "\n         alpha: [ 1. ]\n         index: [ 0 ]\n";
+  const bool ok = std::fwrite(txt.data(), 1, txt.size(), f) == txt.size();
+  return (std::fclose(f) == 0 && ok) ? AGH_OK : AGH_ERR_IO;
+}
+
+}  // extern "C"

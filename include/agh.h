@@ -174,6 +174,30 @@ int agh_load_svm_file(agh_ctx* ctx, const char* path);
 int agh_classify(agh_ctx* ctx, uint8_t* keep, int64_t cap, int64_t* n_kept);
 int agh_classify_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream);
 
+/* ---- training side: Learning::train / trainBalanced / convertData, learning.cpp:3-163, 249-318
+ * The reference keeps, in every GraspHypothesis, the points of its hand box and their split by camera
+ * (rotating_hand.cpp:143-151) so that Learning::train can later rasterise three instances per hand: all points, camera
+ * 0's and camera 1's (createInstance, learning.cpp:375-400; same source_to_center for the three).  Here the three
+ * 80x100 occupancy images are produced by the hand sweep itself and stand for the instance.
+ * Packed image: 250 uint32 words, bit (b & 31) of word (b >> 5) is pixel b = row * 100 + col (set = 255). */
+/* on != 0: every following agh_find_hands*(calculates_antipodal = 1) also rasterises the per-camera images. */
+int agh_set_training_images(agh_ctx* ctx, int on);
+/* The three images (cam = -1, 0, 1) of each hypothesis of the last such call: cap_hyp x 3 x 250 words.  Returns the
+ * number of hypotheses written. */
+int agh_get_training_images(agh_ctx* ctx, uint32_t* images, int64_t cap_hyp);
+/* cv::HOGDescriptor(winSize 64x64).compute(image, winStride 32x32) as convertData calls it (learning.cpp:253-281):
+ * n packed images -> n x 3528 floats. */
+int agh_hog_images(agh_ctx* ctx, const uint32_t* images, int64_t n, float* desc);
+/* convertData's CvSVM::train (C_SVC, LINEAR) on the images' descriptors, then CvSVM::optimize_linear_svm: one weight
+ * vector + rho, usable with agh_load_svm.  labels[k] > 0 marks a positive (label 1), anything else label -1.  The
+ * reference's CvSVMParams defaults are C = 1, max_iter = 1000, eps = FLT_EPSILON.  info_out (optional, 4 ints):
+ * solver steps taken, support vectors, instances of label -1, instances of label +1.
+ * OpenCV's solver is third-party code restated from its published algorithm: see DESIGN.md for what is pinned. */
+int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, double C, int32_t max_iter,
+  double eps, float* weights_out, double* rho_out, int32_t* info_out);
+/* CvSVM::save (learning.cpp:312) of that model in OpenCV's YAML layout (what agh_load_svm_file and CvSVM::load read). */
+int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights, double rho);
+
 /* Introspection for parity tests / plotting (host buffers). */
 int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap);
 int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, int64_t cap);

@@ -17,6 +17,7 @@
 #include "agile_oracle.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -949,10 +950,11 @@ struct HandOut
 {
   orc_hypothesis h;
   std::vector<uint8_t> image;
+  std::vector<uint8_t> image_cam[2]; /* createInstance(h, cam_pos, cam = 0 / 1): only that camera's points */
 };
 
 void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>& nb, const orc_frame& F,
-  const double* normals, int sample_pos, int sample_cam, bool want_images, std::vector<HandOut>& out)
+  const double* normals, int sample_pos, int sample_cam, int want_images, std::vector<HandOut>& out)
 {
   out.clear();
   if (!F.valid)
@@ -1049,6 +1051,7 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
       mat3vec(T, bot_l, bottom);
       const double box_y = finger_hand.back_of_hand + finger_hand.depth; /* rotating_hand.cpp:127 */
       std::vector<double> bx, by;
+      std::vector<double> bxc[2], byc[2]; /* indices_cam1 / indices_cam2 (rotating_hand.cpp:143-151) */
       int numl = 0, numr = 0, nbox = 0;
       const double cos_thresh = std::cos(20 * M_PI / 180.0); /* antipodal.cpp:16 */
       for (int j = 0; j < nc; j++)
@@ -1057,6 +1060,11 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
           nbox++;
           bx.push_back(XR[j] - surface[0]); /* rotating_hand.cpp:138 (world-frame offset, replicated as-is) */
           by.push_back(YR[j] - surface[1]);
+          if (want_images > 1 && (CAMS[j] == 0 || CAMS[j] == 1))
+          {
+            bxc[CAMS[j]].push_back(bx.back());
+            byc[CAMS[j]].push_back(by.back());
+          }
           if (normals)
           {
             if (-1.0 * NXR[j] > cos_thresh)
@@ -1097,6 +1105,11 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
           s2c[r] = ho.h.surface[r] - P.cam_origin[cs_i][r];
         ho.image.resize(8000);
         make_image(bx, by, dot3(binormal, s2c) > 0, ho.image.data());
+        for (int c = 0; c < 2 && want_images > 1; c++) /* same source_to_center, the camera's subset of pts */
+        {
+          ho.image_cam[c].resize(8000);
+          make_image(bxc[c], byc[c], dot3(binormal, s2c) > 0, ho.image_cam[c].data());
+        }
       }
       out.push_back(std::move(ho));
     }
@@ -1429,7 +1442,7 @@ void fit_frames_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid
 
 int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, const int32_t* sample_idx, int64_t S,
   const orc_frame* frames, const double* normals, orc_hypothesis* out, int64_t cap, int64_t* n_out, int32_t* nh_out,
-  uint8_t* images_out)
+  uint8_t* images_out, uint8_t* cam_images_out = nullptr)
 {
   std::vector<std::vector<HandOut>> lists(S);
 #pragma omp parallel for num_threads(P.num_threads) schedule(static)
@@ -1441,7 +1454,8 @@ int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, cons
     if (nh_out)
       nh_out[i] = (int32_t) nb.size();
     /* hands_cam_source(i) = pts_cam_source(indices[i]) (hand_search.cpp:40-42; defined so for explicit indices) */
-    hands_for_sample(P, cl, nb, frames[i], normals, (int) i, cl.cam[sample_idx[i]], images_out != nullptr, lists[i]);
+    hands_for_sample(P, cl, nb, frames[i], normals, (int) i, cl.cam[sample_idx[i]],
+      cam_images_out ? 2 : (images_out != nullptr ? 1 : 0), lists[i]);
   }
   int64_t k = 0;
   for (int64_t i = 0; i < S; i++) /* concatenation, hand_search.cpp:194-200 */
@@ -1452,6 +1466,8 @@ int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, cons
         out[k] = lists[i][j].h;
         if (images_out)
           std::memcpy(images_out + k * 8000, lists[i][j].image.data(), 8000);
+        for (int c = 0; c < 2 && cam_images_out; c++)
+          std::memcpy(cam_images_out + (k * 2 + c) * 8000, lists[i][j].image_cam[c].data(), 8000);
       }
       k++;
     }
@@ -1490,9 +1506,9 @@ int orc_fit_frames(const orc_params* p, const float* xyz, int64_t stride_floats,
   return 0;
 }
 
-int orc_find_hands(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+static int find_hands_full(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
   const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal, orc_hypothesis* out, int64_t cap,
-  int64_t* n_out, orc_frame* frames_out, int32_t* nh_out, uint8_t* images_out)
+  int64_t* n_out, orc_frame* frames_out, int32_t* nh_out, uint8_t* images_out, uint8_t* cam_images_out)
 {
   Cloud cl{ xyz, stride_floats, cam, n };
   GridIndex g_t, g_h;
@@ -1526,7 +1542,23 @@ int orc_find_hands(const orc_params* p, const float* xyz, int64_t stride_floats,
   if (frames_out)
     std::memcpy(frames_out, frames.data(), sizeof(orc_frame) * n_samples);
   return hands_impl(*p, cl, g_h, sample_idx, n_samples, frames.data(), calculates_antipodal ? normals.data() : nullptr,
-    out, cap, n_out, nh_out, images_out);
+    out, cap, n_out, nh_out, images_out, cam_images_out);
+}
+
+int orc_find_hands(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal, orc_hypothesis* out, int64_t cap,
+  int64_t* n_out, orc_frame* frames_out, int32_t* nh_out, uint8_t* images_out)
+{
+  return find_hands_full(p, xyz, stride_floats, cam, n, sample_idx, n_samples, calculates_antipodal, out, cap, n_out,
+    frames_out, nh_out, images_out, nullptr);
+}
+
+int orc_find_hands_training(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, orc_hypothesis* out, int64_t cap, int64_t* n_out, uint8_t* images_out,
+  uint8_t* cam_images_out)
+{
+  return find_hands_full(p, xyz, stride_floats, cam, n, sample_idx, n_samples, 1, out, cap, n_out, nullptr, nullptr,
+    images_out, cam_images_out);
 }
 
 int orc_hands_from_frames(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam,
@@ -1848,6 +1880,302 @@ int64_t orc_find_handles(const orc_hypothesis* hands, int64_t n_hands, int32_t m
     n_handles++;
   }
   return n_handles;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// f4: the training side, Learning::convertData (/root/reference/src/agile_grasp/learning.cpp:249-318):
+//   CvSVMParams{C_SVC, LINEAR} (defaults C = 1, term_crit = {1000 iterations, FLT_EPSILON}); CvSVM::train; CvSVM::save.
+// THIRD PARTY -- OpenCV 2.4 modules/ml/src/svm.cpp is not in /root/reference and OpenCV is not in this image, so the
+// solver below restates its published algorithm and its parity with OpenCV itself is UNPINNED (no golden vector of a
+// training run exists in the reference; the shipped model's training set is not available).  What is pinned: the file
+// writer reproduces the reference's shipped model file byte for byte from its (weights, rho), and the solver's result
+// satisfies the KKT conditions of the C-SVC dual (tests/test_training.py).
+//   CvSVM::do_train            samples sorted by class with the original order kept inside a class
+//                              (cvSortSamplesByClasses: qsort on (class, index)); class 0 = label -1 gets y = +1,
+//                              class 1 = label +1 gets y = -1; alpha *= y after the solve; support vectors = samples
+//                              with |alpha| > 0 in that order
+//   CvSVMSolver::solve_c_svc   alpha = 0, b = -1, C_i = C
+//   CvSVMSolver::solve_generic gradient init, loop { select_working_set; two kernel rows; clipped pair update;
+//                              G[k] += Q_i[k]*d_i + Q_j[k]*d_j }, at most max_iter updates
+//   select_working_set         maximal violating pair, strict '>' so the lowest index wins ties; stop when
+//                              Gmax1 + Gmax2 < eps
+//   CvSVMKernel::calc_linear   float products summed four at a time in float, accumulated in double, stored as float
+//                              (Qfloat), clamped to FLT_MAX*1e-3; get_row_svc multiplies by y_i*y_j
+//   calc_rho                   mean of y*G over the free alphas, else the midpoint of the bounds
+//   CvSVM::optimize_linear_svm v[k] += sv[k]*alpha in double over the support vectors, stored as float; rho unchanged
+typedef struct orc_train_info_
+{
+  int32_t iterations, n_sv, n_class0, n_class1;
+  double objective;
+} orc_train_info_;
+
+int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, double C, int32_t max_iter,
+  double eps, float* weights_out, double* rho_out, int32_t* info_out /* iterations, n_sv, n_class0, n_class1 */,
+  double* alpha_out /* optional, n entries in the caller's sample order, signed */, int num_threads)
+{
+  if (n <= 0 || var_count <= 0)
+    return -1;
+  std::vector<int64_t> order;
+  order.reserve((size_t) n);
+  for (int64_t i = 0; i < n; i++)
+    if (labels[i] <= 0)
+      order.push_back(i);
+  const int64_t n0 = (int64_t) order.size();
+  for (int64_t i = 0; i < n; i++)
+    if (labels[i] > 0)
+      order.push_back(i);
+  if (n0 == 0 || n0 == n)
+    return -3; /* a two-class problem needs both classes */
+  std::vector<signed char> y((size_t) n);
+  for (int64_t k = 0; k < n; k++)
+    y[(size_t) k] = k < n0 ? 1 : -1;
+  std::vector<double> alpha((size_t) n, 0.0), G((size_t) n, -1.0);
+  std::vector<signed char> status((size_t) n, -1);
+  auto upd = [&](int64_t i) { status[(size_t) i] = alpha[(size_t) i] >= C ? 1 : (alpha[(size_t) i] <= 0 ? -1 : 0); };
+  const float max_val = (float) (FLT_MAX * 1e-3);
+  // kernel rows, cached (a cache changes nothing in the values)
+  std::vector<std::vector<float>> cache((size_t) n);
+  size_t cached_rows = 0;
+  const size_t max_rows = std::max<size_t>(4, (size_t) (((size_t) 1 << 30) / ((size_t) n * 4)));
+  auto get_row = [&](int64_t i) -> const float* {
+    std::vector<float>& row = cache[(size_t) i];
+    if (!row.empty())
+      return row.data();
+    if (cached_rows >= max_rows)
+    {
+      for (auto& r : cache)
+        std::vector<float>().swap(r);
+      cached_rows = 0;
+    }
+    row.resize((size_t) n);
+    const float* another = features + order[(size_t) i] * var_count;
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (int64_t j = 0; j < n; j++)
+    {
+      const float* sample = features + order[(size_t) j] * var_count;
+      double s = 0;
+      int k = 0;
+      for (; k <= var_count - 4; k += 4)
+        s += sample[k] * another[k] + sample[k + 1] * another[k + 1] + sample[k + 2] * another[k + 2] +
+             sample[k + 3] * another[k + 3];
+      for (; k < var_count; k++)
+        s += sample[k] * another[k];
+      float q = (float) (s * 1.0 + 0.0);
+      if (q > max_val)
+        q = max_val;
+      row[(size_t) j] = y[(size_t) i] > 0 ? y[(size_t) j] * q : -y[(size_t) j] * q;
+    }
+    cached_rows++;
+    return row.data();
+  };
+  int iter = 0;
+  for (;;)
+  {
+    double Gmax1 = -DBL_MAX, Gmax2 = -DBL_MAX;
+    int64_t i1 = -1, i2 = -1;
+    for (int64_t i = 0; i < n; i++)
+    {
+      double t;
+      const bool ub = status[(size_t) i] > 0, lb = status[(size_t) i] < 0;
+      if (y[(size_t) i] > 0)
+      {
+        if (!ub && (t = -G[(size_t) i]) > Gmax1)
+        {
+          Gmax1 = t;
+          i1 = i;
+        }
+        if (!lb && (t = G[(size_t) i]) > Gmax2)
+        {
+          Gmax2 = t;
+          i2 = i;
+        }
+      }
+      else
+      {
+        if (!ub && (t = -G[(size_t) i]) > Gmax2)
+        {
+          Gmax2 = t;
+          i2 = i;
+        }
+        if (!lb && (t = G[(size_t) i]) > Gmax1)
+        {
+          Gmax1 = t;
+          i1 = i;
+        }
+      }
+    }
+    if (Gmax1 + Gmax2 < eps || iter++ >= max_iter)
+      break;
+    const int64_t i = i1, j = i2;
+    // two rows may evict each other from a tiny cache: copy the first
+    std::vector<float> Qi_copy(get_row(i), get_row(i) + n);
+    const float* Q_i = Qi_copy.data();
+    const float* Q_j = get_row(j);
+    const double C_i = C, C_j = C;
+    double alpha_i = alpha[(size_t) i], alpha_j = alpha[(size_t) j];
+    const double old_i = alpha_i, old_j = alpha_j;
+    if (y[(size_t) i] != y[(size_t) j])
+    {
+      const double denom = Q_i[i] + Q_j[j] + 2 * Q_i[j];
+      const double delta = (-G[(size_t) i] - G[(size_t) j]) / std::max(std::fabs(denom), (double) FLT_EPSILON);
+      const double diff = alpha_i - alpha_j;
+      alpha_i += delta;
+      alpha_j += delta;
+      if (diff > 0 && alpha_j < 0)
+      {
+        alpha_j = 0;
+        alpha_i = diff;
+      }
+      else if (diff <= 0 && alpha_i < 0)
+      {
+        alpha_i = 0;
+        alpha_j = -diff;
+      }
+      if (diff > C_i - C_j && alpha_i > C_i)
+      {
+        alpha_i = C_i;
+        alpha_j = C_i - diff;
+      }
+      else if (diff <= C_i - C_j && alpha_j > C_j)
+      {
+        alpha_j = C_j;
+        alpha_i = C_j + diff;
+      }
+    }
+    else
+    {
+      const double denom = Q_i[i] + Q_j[j] - 2 * Q_i[j];
+      const double delta = (G[(size_t) i] - G[(size_t) j]) / std::max(std::fabs(denom), (double) FLT_EPSILON);
+      const double sum = alpha_i + alpha_j;
+      alpha_i -= delta;
+      alpha_j += delta;
+      if (sum > C_i && alpha_i > C_i)
+      {
+        alpha_i = C_i;
+        alpha_j = sum - C_i;
+      }
+      else if (sum <= C_i && alpha_j < 0)
+      {
+        alpha_j = 0;
+        alpha_i = sum;
+      }
+      if (sum > C_j && alpha_j > C_j)
+      {
+        alpha_j = C_j;
+        alpha_i = sum - C_j;
+      }
+      else if (sum <= C_j && alpha_i < 0)
+      {
+        alpha_i = 0;
+        alpha_j = sum;
+      }
+    }
+    alpha[(size_t) i] = alpha_i;
+    alpha[(size_t) j] = alpha_j;
+    upd(i);
+    upd(j);
+    const double d_i = alpha_i - old_i, d_j = alpha_j - old_j;
+    for (int64_t k = 0; k < n; k++)
+      G[(size_t) k] += Q_i[k] * d_i + Q_j[k] * d_j;
+  }
+  // calc_rho
+  int nr_free = 0;
+  double ub = DBL_MAX, lb = -DBL_MAX, sum_free = 0;
+  for (int64_t i = 0; i < n; i++)
+  {
+    const double yG = y[(size_t) i] * G[(size_t) i];
+    if (status[(size_t) i] < 0)
+    {
+      if (y[(size_t) i] > 0)
+        ub = std::min(ub, yG);
+      else
+        lb = std::max(lb, yG);
+    }
+    else if (status[(size_t) i] > 0)
+    {
+      if (y[(size_t) i] < 0)
+        ub = std::min(ub, yG);
+      else
+        lb = std::max(lb, yG);
+    }
+    else
+    {
+      ++nr_free;
+      sum_free += yG;
+    }
+  }
+  const double rho = nr_free > 0 ? sum_free / nr_free : (ub + lb) * 0.5;
+  std::vector<double> v((size_t) var_count, 0.0);
+  int n_sv = 0;
+  for (int64_t k = 0; k < n; k++)
+  {
+    const double a = alpha[(size_t) k] * y[(size_t) k];
+    if (alpha_out)
+      alpha_out[order[(size_t) k]] = a;
+    if (std::fabs(a) > 0)
+    {
+      n_sv++;
+      const float* src = features + order[(size_t) k] * var_count;
+      for (int q = 0; q < var_count; q++)
+        v[(size_t) q] += src[q] * a;
+    }
+  }
+  for (int q = 0; q < var_count; q++)
+    weights_out[q] = (float) v[(size_t) q];
+  *rho_out = rho;
+  if (info_out)
+  {
+    info_out[0] = iter > max_iter ? max_iter : iter;
+    info_out[1] = n_sv;
+    info_out[2] = (int32_t) n0;
+    info_out[3] = (int32_t) (n - n0);
+  }
+  return 0;
+}
+
+/* CvSVM::save for the compacted linear model, as cv::FileStorage's YAML emitter lays it out (floats "%.8e" / "%d.",
+ * doubles "%.16e", flow sequences wrapped when the next item would pass column 71).  Pinned: regenerates the
+ * reference's shipped svm_032015_linear_20_20_same byte for byte. */
+int orc_save_svm(const char* path, const float* weights, int32_t n_w, double rho)
+{
+  FILE* f = std::fopen(path, "wb");
+  if (!f)
+    return -1;
+  auto real = [](double v, bool dbl, char* buf) {
+    const long iv = std::lrint(v);
+    if ((double) iv == v)
+      std::snprintf(buf, 64, "%ld.", iv);
+    else
+      std::snprintf(buf, 64, dbl ? "%.16e" : "%.8e", v);
+  };
+  std::fprintf(f, "%%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n   kernel: { type:LINEAR }\n   C: 1.\n"
+                  "   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n   var_all: %d\n"
+                  "   var_count: %d\n   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n"
+                  "      dt: i\n      data: [ -1, 1 ]\n   sv_total: 1\n   support_vectors:\n",
+    n_w, n_w);
+  std::string line = "      - [";
+  char buf[64];
+  for (int k = 0; k < n_w; k++)
+  {
+    real((double) weights[k], false, buf);
+    if (k)
+      line += ",";
+    const size_t off = line.size() + std::strlen(buf);
+    if (off > 71 && off - 10 > 10)
+    {
+      std::fprintf(f, "%s\n", line.c_str());
+      line = std::string(10, ' ') + buf;
+    }
+    else
+      line += std::string(" ") + buf;
+  }
+  std::fprintf(f, "%s ]\n", line.c_str());
+  real(rho, true, buf);
+  std::fprintf(f, "   decision_functions:\n      -\n         sv_count: 1\n         rho: %s\n         alpha: [ 1. ]\n"
+                  "         index: [ 0 ]\n", buf);
+  std::fclose(f);
+  return 0;
 }
 
 } // extern "C"

@@ -142,6 +142,21 @@ int64_t orc_find_handles(const orc_hypothesis* hands, int64_t n_hands, int32_t m
 int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
   const double workspace[6], double cell_size, float* xyz_out, int32_t* cam_out, int64_t cap);
 
+/* f4 (training side): orc_find_hands(calculates_antipodal = 1) that also returns, per hypothesis, the images of
+ * createInstance(h, cam_pos, cam = 0) and (cam = 1) (learning.cpp:389-397): cam_images_out is cap x 2 x 8000 bytes. */
+int orc_find_hands_training(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, orc_hypothesis* out, int64_t cap, int64_t* n_out, uint8_t* images_out,
+  uint8_t* cam_images_out);
+
+/* f4: CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm as Learning::convertData runs it (learning.cpp:296-313).
+ * features n x var_count row-major, labels > 0 = positive.  OpenCV's solver restated; parity with OpenCV UNPINNED
+ * (see the .cpp).  info_out = {iterations, n_sv, n_class0, n_class1}.  Returns 0, -3 if a class is missing. */
+int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, double C, int32_t max_iter,
+  double eps, float* weights_out, double* rho_out, int32_t* info_out, double* alpha_out, int num_threads);
+
+/* f4: CvSVM::save of the compacted linear model (pinned: regenerates the shipped model file byte for byte). */
+int orc_save_svm(const char* path, const float* weights, int32_t n_w, double rho);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,56 @@ def find_handles(hands: np.ndarray, min_inliers: int = 3, min_length: float = 0.
     out = out[:n].copy()
     total = int(out["n_inliers"].sum())
     return out, idx[:total].copy()
+
+
+# ---- f4: the training side (learning.cpp:3-163, 249-318) -----------------------------------------------------
+def find_hands_training(p: OrcParams, xyz, cam, samples):
+    """find_hands(calculates_antipodal=True) plus, per hypothesis, the images of the three training instances
+    createInstance(h, cam_pos, cam = -1 / 0 / 1): 'images' is (H, 3, 8000)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    cam = np.ascontiguousarray(cam, np.int32)
+    samples = np.ascontiguousarray(samples, np.int32)
+    S = samples.shape[0]
+    cap = 8 * S
+    out = np.zeros(cap, HYP_DTYPE)
+    images = np.zeros((cap, 8000), np.uint8)
+    cam_images = np.zeros((cap, 2, 8000), np.uint8)
+    n_out = C.c_int64(0)
+    rc = lib().orc_find_hands_training(C.byref(p), _fp(xyz, C.c_float), C.c_int64(3), _fp(cam, C.c_int32),
+                                       C.c_int64(xyz.shape[0]), _fp(samples, C.c_int32), C.c_int64(S),
+                                       out.ctypes.data_as(C.c_void_p), C.c_int64(cap), C.byref(n_out),
+                                       _fp(images, C.c_uint8), _fp(cam_images, C.c_uint8))
+    assert rc == 0, rc
+    n = n_out.value
+    return {"hyps": out[:n].copy(), "images": np.concatenate([images[:n, None, :], cam_images[:n]], axis=1)}
+
+
+def hog_many(images: np.ndarray) -> np.ndarray:
+    images = np.ascontiguousarray(images, np.uint8).reshape(-1, 8000)
+    return np.stack([hog(im) for im in images]) if images.shape[0] else np.zeros((0, 3528), np.float32)
+
+
+def train_svm(features: np.ndarray, labels: np.ndarray, C_: float = 1.0, max_iter: int = 1000,
+              eps: float = 1.1920928955078125e-07, num_threads: int = 0):
+    """CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm restated (parity with OpenCV itself unpinned).
+    Returns dict(w, rho, iterations, n_sv, alpha)."""
+    features = np.ascontiguousarray(features, np.float32)
+    n, d = features.shape
+    lab = np.ascontiguousarray(np.where(np.asarray(labels) > 0, 1, -1), np.int8)
+    w = np.zeros(d, np.float32)
+    rho = C.c_double(0)
+    info = np.zeros(4, np.int32)
+    alpha = np.zeros(n, np.float64)
+    rc = lib().orc_train_svm(_fp(features, C.c_float), lab.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(d),
+                             C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _fp(w, C.c_float), C.byref(rho),
+                             _fp(info, C.c_int32), _fp(alpha, C.c_double),
+                             C.c_int(num_threads if num_threads > 0 else (os.cpu_count() or 1)))
+    if rc != 0:
+        raise RuntimeError(f"orc_train_svm failed ({rc})")
+    return {"w": w, "rho": rho.value, "iterations": int(info[0]), "n_sv": int(info[1]), "alpha": alpha}
+
+
+def save_svm(path: str, w: np.ndarray, rho: float) -> None:
+    w = np.ascontiguousarray(w, np.float32)
+    rc = lib().orc_save_svm(path.encode(), _fp(w, C.c_float), C.c_int32(w.size), C.c_double(rho))
+    assert rc == 0, rc

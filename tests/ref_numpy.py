@@ -142,7 +142,7 @@ def evaluate_hand(points, normals, cam_ids, frame, cams, geom, init_bite, sample
             out.append(dict(orientation=o, approach=approach, binormal=binormal, surface=surface + sample,
                             bottom=bottom + sample, width=width, n_in_box=int(box.sum()), finger_index=e,
                             depth_index=steps, half=(numl > 6 or numr > 6), full=(numl > 6 and numr > 6),
-                            points_in_box=pib))
+                            points_in_box=pib, cam_in_box=np.asarray(cam_ids)[box]))
     return out
 
 
@@ -229,3 +229,114 @@ def find_handles(hands, min_inliers=3, min_length=0.005):
         for j in idx:
             width[j] = -1
     return res
+
+
+# ---- f4: CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm, OpenCV 2.4 svm.cpp, transcribed for small problems -------
+def _kernel_row(X, i):
+    """calc_non_rbf_base: float products, groups of four summed in float, accumulated in double in index order."""
+    p = X * X[i][None, :]  # float32
+    n, d = X.shape
+    g = p[:, : d - d % 4].reshape(n, -1, 4)
+    gs = ((g[:, :, 0] + g[:, :, 1]) + g[:, :, 2]) + g[:, :, 3]  # float32
+    s = np.cumsum(gs.astype(np.float64), axis=1)[:, -1] if gs.shape[1] else np.zeros(n)
+    for k in range(d - d % 4, d):
+        s = s + p[:, k].astype(np.float64)
+    q = (s * 1.0 + 0.0).astype(np.float32)
+    return np.minimum(q, np.float32(np.finfo(np.float32).max * 1e-3))
+
+
+def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.float32).eps)):
+    X0 = np.ascontiguousarray(features, np.float32)
+    lab = np.asarray(labels)
+    order = np.concatenate([np.nonzero(lab <= 0)[0], np.nonzero(lab > 0)[0]])  # class 0 (label -1) first
+    n0 = int((lab <= 0).sum())
+    X = X0[order]
+    n = X.shape[0]
+    y = np.where(np.arange(n) < n0, 1, -1).astype(np.int8)
+    alpha = np.zeros(n)
+    G = -np.ones(n)
+    status = -np.ones(n, np.int8)
+    feps = float(np.finfo(np.float32).eps)
+    rows = {}
+
+    def row(i):
+        if i not in rows:
+            q = _kernel_row(X, i)
+            rows[i] = (y.astype(np.float32) * q) if y[i] > 0 else (-y.astype(np.float32) * q)
+        return rows[i]
+
+    it = 0
+    while True:
+        g1, g2, i1, i2 = -np.finfo(np.float64).max, -np.finfo(np.float64).max, -1, -1
+        for k in range(n):
+            ub, lb = status[k] > 0, status[k] < 0
+            if y[k] > 0:
+                if not ub and -G[k] > g1:
+                    g1, i1 = -G[k], k
+                if not lb and G[k] > g2:
+                    g2, i2 = G[k], k
+            else:
+                if not ub and -G[k] > g2:
+                    g2, i2 = -G[k], k
+                if not lb and G[k] > g1:
+                    g1, i1 = G[k], k
+        if g1 + g2 < eps:
+            break
+        it += 1
+        if it - 1 >= max_iter:
+            break
+        i, j = i1, i2
+        Qi, Qj = row(i), row(j)
+        ai, aj = alpha[i], alpha[j]
+        oi, oj = ai, aj
+        if y[i] != y[j]:
+            denom = float(np.float32(np.float32(Qi[i] + Qj[j]) + np.float32(2) * Qi[j]))
+            delta = (-G[i] - G[j]) / max(abs(denom), feps)
+            diff = ai - aj
+            ai += delta
+            aj += delta
+            if diff > 0 and aj < 0:
+                aj, ai = 0.0, diff
+            elif diff <= 0 and ai < 0:
+                ai, aj = 0.0, -diff
+            if diff > C - C and ai > C:
+                ai, aj = C, C - diff
+            elif diff <= C - C and aj > C:
+                aj, ai = C, C + diff
+        else:
+            denom = float(np.float32(np.float32(Qi[i] + Qj[j]) - np.float32(2) * Qi[j]))
+            delta = (G[i] - G[j]) / max(abs(denom), feps)
+            sm = ai + aj
+            ai -= delta
+            aj += delta
+            if sm > C and ai > C:
+                ai, aj = C, sm - C
+            elif sm <= C and aj < 0:
+                aj, ai = 0.0, sm
+            if sm > C and aj > C:
+                aj, ai = C, sm - C
+            elif sm <= C and ai < 0:
+                ai, aj = 0.0, sm
+        alpha[i], alpha[j] = ai, aj
+        for k in (i, j):
+            status[k] = 1 if alpha[k] >= C else (-1 if alpha[k] <= 0 else 0)
+        G = G + (Qi.astype(np.float64) * (ai - oi) + Qj.astype(np.float64) * (aj - oj))
+    yG = y * G
+    free = status == 0
+    if free.any():
+        rho = float(np.cumsum(yG[free])[-1]) / int(free.sum())
+    else:
+        ubm = (status < 0) & (y > 0) | (status > 0) & (y < 0)
+        lbm = ~ubm
+        ub = yG[ubm].min() if ubm.any() else np.finfo(np.float64).max
+        lb = yG[lbm].max() if lbm.any() else -np.finfo(np.float64).max
+        rho = (ub + lb) * 0.5
+    a = alpha * y
+    v = np.zeros(X.shape[1])
+    for k in range(n):
+        if abs(a[k]) > 0:
+            v = v + X[k].astype(np.float64) * a[k]
+    alpha_out = np.zeros(n)
+    alpha_out[order] = a
+    return dict(w=v.astype(np.float32), rho=rho, iterations=min(it, max_iter), n_sv=int((np.abs(a) > 0).sum()),
+                alpha=alpha_out)
