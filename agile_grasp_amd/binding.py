@@ -84,6 +84,7 @@ EXPORTS = [
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
+    "agh_load_svm_model",
 ]
 
 
@@ -98,10 +99,18 @@ def unpack_images(words: np.ndarray) -> np.ndarray:
     return (np.unpackbits(w.view(np.uint8), axis=1, bitorder="little") * np.uint8(255)).reshape(-1, 8000)
 
 
-def save_svm_file(path: str, w: np.ndarray, rho: float) -> None:
-    """CvSVM::save of the compacted linear model (needs no device)."""
-    w = np.ascontiguousarray(w, np.float32)
-    rc = load_library().agh_save_svm_file(path.encode(), _p(w, C.c_float), C.c_int32(w.size), C.c_double(rho))
+SVM_LINEAR = 0
+SVM_POLY2 = 1
+
+
+def save_svm_file(path: str, w: np.ndarray, rho: float, kernel: int = SVM_LINEAR, alpha: np.ndarray | None = None) -> None:
+    """CvSVM::save (needs no device): the compacted linear vector (w: 3528 floats) or, with `alpha`, the support
+    vectors (w: n_sv x 3528) of a model with the given kernel."""
+    sv = np.ascontiguousarray(w, np.float32).reshape(-1, 3528)
+    al = np.ones(1, np.float64) if alpha is None else np.ascontiguousarray(alpha, np.float64)
+    assert al.shape[0] == sv.shape[0]
+    rc = load_library().agh_save_svm_file(path.encode(), C.c_int32(kernel), _p(sv, C.c_float), C.c_int32(sv.shape[0]),
+                                          C.c_int32(3528), _p(al, C.c_double), C.c_double(rho))
     if rc != 0:
         raise AghError(rc, f"cannot write {path}")
 
@@ -291,18 +300,31 @@ class Context:
         return desc
 
     def train_svm(self, packed: np.ndarray, labels: np.ndarray, C_: float = 1.0, max_iter: int = 1000,
-                  eps: float = 1.1920928955078125e-07) -> dict:
+                  eps: float = 1.1920928955078125e-07, kernel: int = SVM_LINEAR) -> dict:
+        """convertData's CvSVM::train.  LINEAR: 'w' is the compacted vector; POLY2: 'sv' (n_sv x 3528) and 'alpha'."""
         packed = np.ascontiguousarray(packed, "<u4").reshape(-1, 250)
         lab = np.ascontiguousarray(np.where(np.asarray(labels) > 0, 1, -1), np.int8)
-        assert lab.shape[0] == packed.shape[0]
-        w = np.zeros(3528, np.float32)
+        n = packed.shape[0]
+        assert lab.shape[0] == n
+        cap = 1 if kernel == SVM_LINEAR else n
+        sv = np.zeros((cap, 3528), np.float32)
+        alpha = np.zeros(cap, np.float64)
+        n_sv = C.c_int32(0)
         rho = C.c_double(0)
         info = np.zeros(4, np.int32)
-        self._check(self.lib.agh_train_svm(self._h, _p(packed, C.c_uint32), _p(lab, C.c_int8), C.c_int64(packed.shape[0]),
-                                           C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _p(w, C.c_float),
-                                           C.byref(rho), _p(info, C.c_int32)))
-        return {"w": w, "rho": rho.value, "iterations": int(info[0]), "n_sv": int(info[1]), "n_neg": int(info[2]),
+        self._check(self.lib.agh_train_svm(self._h, _p(packed, C.c_uint32), _p(lab, C.c_int8), C.c_int64(n), C.c_int32(kernel),
+                                           C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _p(sv, C.c_float),
+                                           C.c_int64(cap), _p(alpha, C.c_double), C.byref(n_sv), C.byref(rho),
+                                           _p(info, C.c_int32)))
+        return {"w": sv[0].copy(), "sv": sv[: n_sv.value].copy(), "alpha": alpha[: n_sv.value].copy(), "rho": rho.value,
+                "kernel": kernel, "iterations": int(info[0]), "n_sv": int(info[1]), "n_neg": int(info[2]),
                 "n_pos": int(info[3])}
+
+    def load_svm_model(self, kernel: int, sv: np.ndarray, alpha: np.ndarray, rho: float):
+        sv = np.ascontiguousarray(sv, np.float32).reshape(-1, 3528)
+        alpha = np.ascontiguousarray(alpha, np.float64)
+        self._check(self.lib.agh_load_svm_model(self._h, C.c_int32(kernel), _p(sv, C.c_float), C.c_int32(sv.shape[0]),
+                                                C.c_int32(3528), _p(alpha, C.c_double), C.c_double(rho)))
 
     def load_svm(self, w: np.ndarray, rho: float):
         w = np.ascontiguousarray(w, np.float32)

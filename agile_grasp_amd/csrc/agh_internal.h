@@ -209,6 +209,16 @@ struct Ctx
   float* d_svm_w = nullptr;
   double svm_rho = 0.0;
   bool has_svm = false;
+  // a model that is not the compacted linear vector (several support vectors and/or the POLY degree-2 kernel)
+  bool svm_general = false;
+  int svm_kernel = 0;               // AGH_SVM_*
+  int svm_n_sv = 1;
+  float* d_svm_svT = nullptr;       // support vectors, tiles of 64 (train.hip: xt_index)
+  double* d_svm_alpha = nullptr;
+  float* d_cls_desc = nullptr;      // descriptors of the hypotheses being classified (general models)
+  int64_t cls_desc_cap = 0;         // in hypotheses
+  float* d_cls_kbuf = nullptr;      // kernel values, hypotheses x support vectors
+  int64_t cls_kbuf_cap = 0;         // in floats
   HogTablesDev* d_hog = nullptr;
   HandGeom* d_geom = nullptr;
   float* d_desc_out = nullptr;  // optional descriptor dump
@@ -240,6 +250,8 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
 int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
 int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st);
+int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_keep, hipStream_t st);
+int svm_load_general(Ctx* c, int kernel_type, const float* sv, int n_sv, const double* alpha, double rho);
 void hog_tables_host(HogTablesDev* t);
 int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);
 

@@ -380,6 +380,34 @@ int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st)
   if (n_hyp_cap <= 0)
     return AGH_OK;
   timing_mark(c, "start", st);
+  if (c->svm_general)
+  {
+    // several support vectors and/or the quadratic kernel: descriptors first, then CvSVM::predict's kernel row per
+    // hypothesis and the alpha-weighted sum (train.hip)
+    float* desc = c->d_desc_out;
+    if (!desc)
+    {
+      if (n_hyp_cap > c->cls_desc_cap)
+      {
+        if (c->d_cls_desc)
+          (void) hipFree(c->d_cls_desc);
+        c->d_cls_desc = nullptr;
+        c->cls_desc_cap = 0;
+        if (hipMalloc((void**) &c->d_cls_desc, (size_t) n_hyp_cap * 3528 * sizeof(float)) != hipSuccess)
+        {
+          c->err = "agh_classify: out of device memory for the descriptors";
+          return AGH_ERR_HIP;
+        }
+        c->cls_desc_cap = n_hyp_cap;
+      }
+      desc = c->d_cls_desc;
+    }
+    hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n_hyp_cap), dim3(256), 0, st, c->d_images, c->d_slot_index, c->d_nout_last,
+      c->d_hog, (const float*) nullptr, 0.0, (agh_hypothesis*) nullptr, (uint8_t*) nullptr, (double*) nullptr, desc, 0);
+    const int rc = svm_predict_general(c, desc, n_hyp_cap, d_keep, st);
+    timing_mark(c, "hog_svm", st);
+    return rc;
+  }
   hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n_hyp_cap), dim3(256), 0, st, c->d_images, c->d_slot_index, c->d_nout_last,
     c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out,
     std::getenv("AGH_DEBUG_STOP_HOG") ? std::atoi(std::getenv("AGH_DEBUG_STOP_HOG")) : 0);
@@ -498,12 +526,16 @@ int agh_load_svm(agh_ctx* ctx, const float* weights, int32_t n_weights, double r
   HIPCHK2(c, hipSetDevice(c->device));
   HIPCHK2(c, hipMemcpy(c->d_svm_w, weights, sizeof(float) * 3528, hipMemcpyHostToDevice));
   c->svm_rho = rho;
+  c->svm_general = false;
+  c->svm_kernel = AGH_SVM_LINEAR;
+  c->svm_n_sv = 1;
   c->has_svm = true;
   return AGH_OK;
 }
 
-// Reads the OpenCV "!!opencv-ml-svm" YAML written by CvSVM::save for a linear C_SVC with one (compacted)
-// support vector -- the format of the model shipped with the reference (svm_032015_linear_20_20_same).
+// Reads the OpenCV "!!opencv-ml-svm" YAML written by CvSVM::save for the two model shapes Learning::convertData
+// produces: a linear C_SVC compacted to one support vector -- the format of the model shipped with the reference
+// (svm_032015_linear_20_20_same) -- or a POLY degree-2 C_SVC with its support vectors (learning.cpp:296-312).
 int agh_load_svm_file(agh_ctx* ctx, const char* path)
 {
   if (!ctx || !path)
@@ -521,42 +553,94 @@ int agh_load_svm_file(agh_ctx* ctx, const char* path)
   while ((r = std::fread(buf, 1, sizeof(buf), f)) > 0)
     txt.append(buf, r);
   std::fclose(f);
-  const size_t sv = txt.find("support_vectors:"), df = txt.find("decision_functions:");
-  const size_t lin = txt.find("LINEAR");
-  if (sv == std::string::npos || df == std::string::npos || lin == std::string::npos || txt.find("sv_total: 1") == std::string::npos)
+  const size_t kp = txt.find("kernel:"), sv = txt.find("support_vectors:"), df = txt.find("decision_functions:");
+  if (kp == std::string::npos || sv == std::string::npos || df == std::string::npos || txt.find("C_SVC") == std::string::npos)
   {
-    c->err = "not a linear one-support-vector OpenCV SVM file";
+    c->err = "not an OpenCV C_SVC model file";
     return AGH_ERR_IO;
   }
-  const size_t lb = txt.find('[', sv), rb = txt.find(']', lb);
-  if (lb == std::string::npos || rb == std::string::npos || rb > df)
+  const std::string kline = txt.substr(kp, txt.find('\n', kp) - kp);
+  int kernel_type;
+  if (kline.find("LINEAR") != std::string::npos)
+    kernel_type = AGH_SVM_LINEAR;
+  else if (kline.find("POLY") != std::string::npos)
   {
-    c->err = "malformed support_vectors section";
-    return AGH_ERR_IO;
-  }
-  std::vector<float> w;
-  const char* s = txt.c_str() + lb + 1;
-  const char* end = txt.c_str() + rb;
-  while (s < end)
-  {
-    char* e2 = nullptr;
-    const double v = std::strtod(s, &e2);  // OpenCV parses reals as double, then stores float
-    if (e2 == s)
+    auto field = [&](const char* name) {
+      const size_t p = kline.find(name);
+      return p == std::string::npos ? NAN : std::strtod(kline.c_str() + p + std::strlen(name), nullptr);
+    };
+    if (field("degree:") != 2.0 || field("gamma:") != 1.0 || field("coef0:") != 0.0)
     {
-      s++;
-      continue;
+      c->err = "POLY models are supported with degree 2, gamma 1, coef0 0 (what Learning::convertData trains)";
+      return AGH_ERR_IO;
     }
-    w.push_back((float) v);
-    s = e2;
+    kernel_type = AGH_SVM_POLY2;
   }
-  const size_t rp = txt.find("rho:", df);
-  if (rp == std::string::npos || w.size() != 3528)
+  else
   {
-    c->err = "expected 3528 weights and a rho";
+    c->err = "only LINEAR and POLY kernels are supported";
+    return AGH_ERR_IO;
+  }
+  auto parse_reals = [&](size_t lb, size_t rb, auto&& sink) {  // OpenCV parses reals as double, then stores them
+    const char* s = txt.c_str() + lb + 1;
+    const char* end = txt.c_str() + rb;
+    while (s < end)
+    {
+      char* e2 = nullptr;
+      const double v = std::strtod(s, &e2);
+      if (e2 == s)
+      {
+        s++;
+        continue;
+      }
+      sink(v);
+      s = e2;
+    }
+  };
+  std::vector<float> w;
+  int n_sv = 0;
+  for (size_t pos = sv;;)
+  {
+    const size_t lb = txt.find('[', pos);
+    if (lb == std::string::npos || lb > df)
+      break;
+    const size_t rb = txt.find(']', lb);
+    if (rb == std::string::npos || rb > df)
+    {
+      c->err = "malformed support_vectors section";
+      return AGH_ERR_IO;
+    }
+    const size_t before = w.size();
+    parse_reals(lb, rb, [&](double v) { w.push_back((float) v); });
+    if (w.size() - before != 3528)
+    {
+      c->err = "expected support vectors of 3528 weights";
+      return AGH_ERR_IO;
+    }
+    n_sv++;
+    pos = rb + 1;
+  }
+  const size_t rp = txt.find("rho:", df), ap = txt.find("alpha:", df);
+  if (rp == std::string::npos || ap == std::string::npos || n_sv == 0)
+  {
+    c->err = "expected support vectors, a rho and alphas";
     return AGH_ERR_IO;
   }
   const double rho = std::strtod(txt.c_str() + rp + 4, nullptr);
-  return agh_load_svm(ctx, w.data(), 3528, rho);
+  std::vector<double> alpha;
+  const size_t alb = txt.find('[', ap), arb = txt.find(']', ap);
+  if (alb == std::string::npos || arb == std::string::npos)
+  {
+    c->err = "malformed alpha section";
+    return AGH_ERR_IO;
+  }
+  parse_reals(alb, arb, [&](double v) { alpha.push_back(v); });
+  if ((int) alpha.size() != n_sv)
+  {
+    c->err = "alpha count differs from the support vector count";
+    return AGH_ERR_IO;
+  }
+  return agh_load_svm_model(ctx, kernel_type, w.data(), n_sv, 3528, alpha.data(), rho);
 }
 
 int agh_classify_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream)

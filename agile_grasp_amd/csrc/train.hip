@@ -18,7 +18,7 @@
 // (oracle/agile_oracle.cpp orc_train_svm; parity with OpenCV itself is unpinned -- see DESIGN.md).
 //
 // HBM traffic per step: the transposed features once (n x 3528 x 4 B) + O(n) vectors; the kernel is bound by the
-// dependent double-precision accumulation chain (882 links per row), not by bandwidth, unless n is large.
+// dependent double-precision accumulation chains (882 links per row and instance), not by bandwidth.
 #include "agh_internal.h"
 
 #include <cfloat>
@@ -43,7 +43,11 @@ struct SvmState
   double gap;  // Gmax1 + Gmax2 of the last selection
 };
 
-// X (n x kDesc, row-major) -> XT (kDesc x n)
+// X (n x kDesc, row-major) -> XT, tiles of 64 instances: XT[(t / 64) * kDesc * 64 + k * 64 + t % 64].  A wavefront's
+// 64 instances of feature k are one 256-byte line and consecutive features follow each other: every wave reads one
+// sequential 903 KB stream per solver step.
+__device__ __forceinline__ int64_t xt_index(int t, int k) { return ((int64_t) (t >> 6) * kDesc + k) * 64 + (t & 63); }
+
 __global__ __launch_bounds__(256) void k_svm_transpose(const float* __restrict__ X, float* __restrict__ XT, int n)
 {
   __shared__ float tile[32][33];
@@ -59,20 +63,24 @@ __global__ __launch_bounds__(256) void k_svm_transpose(const float* __restrict__
   {
     const int k = k0 + r, t = t0 + tx;
     if (k < kDesc && t < n)
-      XT[(int64_t) k * n + t] = tile[tx][r];
+      XT[xt_index(t, k)] = tile[tx][r];
   }
 }
 
 // CvSVMKernel::calc_non_rbf_base for one pair of vectors: `a` strided (transposed matrix), `b` contiguous.
-__device__ __forceinline__ float qfloat(double s)
+// poly: CvSVMKernel::calc_poly with convertData's degree = 2 and CvSVMParams' gamma = 1, coef0 = 0: cvPow(R, R, 2) is
+// multiply(src, src) in float.
+__device__ __forceinline__ float qfloat(double s, int poly)
 {
   float q = (float) (s * 1.0 + 0.0);
+  if (poly)
+    q = q * q;
   const float max_val = (float) (FLT_MAX * 1e-3);
   return q > max_val ? max_val : q;  // CvSVMKernel::calc
 }
 
 __global__ __launch_bounds__(256) void k_svm_init(const float* __restrict__ XT, int n, float* __restrict__ Kdiag,
-  double* __restrict__ alpha, double* __restrict__ G, int8_t* __restrict__ status, SvmState* __restrict__ st)
+  double* __restrict__ alpha, double* __restrict__ G, int8_t* __restrict__ status, SvmState* __restrict__ st, int poly)
 {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t == 0)
@@ -88,11 +96,11 @@ __global__ __launch_bounds__(256) void k_svm_init(const float* __restrict__ XT, 
   double s = 0;
   for (int g = 0; g < kGroups; g++)
   {
-    const float a0 = XT[(int64_t) (4 * g + 0) * n + t], a1 = XT[(int64_t) (4 * g + 1) * n + t];
-    const float a2 = XT[(int64_t) (4 * g + 2) * n + t], a3 = XT[(int64_t) (4 * g + 3) * n + t];
+    const float a0 = XT[xt_index(t, 4 * g + 0)], a1 = XT[xt_index(t, 4 * g + 1)];
+    const float a2 = XT[xt_index(t, 4 * g + 2)], a3 = XT[xt_index(t, 4 * g + 3)];
     s += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
   }
-  Kdiag[t] = qfloat(s);
+  Kdiag[t] = qfloat(s, poly);
   alpha[t] = 0.0;  // solve_c_svc: alpha = 0, b = -1  =>  G = b, every alpha at its lower bound
   G[t] = -1.0;
   status[t] = -1;
@@ -123,7 +131,7 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
 // CvSVMSolver::select_working_set + the two-variable update of solve_generic.  y[k] = +1 for class 0 (label -1).
 __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X, int n, const int8_t* __restrict__ y,
   double* __restrict__ alpha, int8_t* __restrict__ status, const double* __restrict__ G, const float* __restrict__ Kdiag,
-  SvmState* __restrict__ st, double C, double eps, int max_iter)
+  SvmState* __restrict__ st, double C, double eps, int max_iter, int poly)
 {
   __shared__ ArgMax red1[16], red2[16];
   __shared__ int sel[2];
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X
     for (int u = 0; u < 14; u++)
       s += v[u];
   }
-  const float kij = qfloat(s);
+  const float kij = qfloat(s, poly);
   const int yi = y[i], yj = y[j];
   const float Qii = Kdiag[i], Qjj = Kdiag[j];               // get_row_svc: y_i * y_i = 1
   const float Qij = yi > 0 ? yj * kij : -yj * kij;          // row_i[j]
@@ -286,42 +294,139 @@ __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X
 }
 
 // Rows Q_i, Q_j of the step's pair (one entry per thread) and the gradient update.
-__global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X, const float* __restrict__ XT, int n,
-  const int8_t* __restrict__ y, double* __restrict__ G, const SvmState* __restrict__ st)
+// x_i and x_j sit interleaved in LDS ({x_i[k], x_j[k]} pairs: one packed multiply serves both rows); the instance's
+// features come from its tile of the transposed matrix through buffer loads (scalar base, constant offsets), two
+// batches of UNROLL groups in ping-pong so that loads are in flight under the two dependent double-precision chains.
+// Measured (6231 instances): 184 us per solver step with plain per-lane addressing and two groups in flight, 80 us in
+// this form; what remains is the issue time of one wavefront's 882-link chains (a wave per SIMD: the instance count is
+// all the parallelism the exact summation order leaves).
+// The two chains of one lane: dot products (calc_non_rbf_base order) of the lane's vector -- column `lane` of the tile,
+// kDesc lines of 256 bytes -- with the two vectors interleaved in LDS.
+template <int UNROLL>
+__device__ __forceinline__ void dual_dot(const float* tile /* wave-uniform */, unsigned lane_off, const float2* xij,
+  double& si, double& sj)
 {
-  __shared__ __attribute__((aligned(16))) float xi[kDesc];
-  __shared__ __attribute__((aligned(16))) float xj[kDesc];
+  static_assert(kGroups % (2 * UNROLL) == 0, "two batches per trip");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float a[UNROLL][4], b[UNROLL][4];
+  auto load = [&](float (&dst)[UNROLL][4], int g0) {
+    const __amdgpu_buffer_rsrc_t rows =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile + (int64_t) g0 * 256), 0, -1, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        dst[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (4 * u + q) * 256, 0));
+  };
+  auto chain = [&](const float (&src)[UNROLL][4], int g0) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+    {
+      const v4f b01 = reinterpret_cast<const v4f*>(xij)[2 * (g0 + u)];      // x_i[k], x_j[k], x_i[k+1], x_j[k+1]
+      const v4f b23 = reinterpret_cast<const v4f*>(xij)[2 * (g0 + u) + 1];
+      v2f p = b01.xy * src[u][0];  // lane .x: row i, lane .y: row j -- packed float math, same order per lane
+      p = p + b01.zw * src[u][1];
+      p = p + b23.xy * src[u][2];
+      p = p + b23.zw * src[u][3];
+      si += p.x;
+      sj += p.y;
+    }
+  };
+  // two register batches in ping-pong: the loads of one are in flight while the other feeds the chains
+  load(a, 0);
+  for (int g0 = 0; g0 < kGroups; g0 += 2 * UNROLL)
+  {
+    load(b, g0 + UNROLL);
+    chain(a, g0);
+    load(a, g0 + 2 * UNROLL < kGroups ? g0 + 2 * UNROLL : 0);  // (the last trip reloads the first batch: no branch)
+    chain(b, g0 + UNROLL);
+  }
+}
+
+// The tile of the wave that holds vector index `first` (wave-uniform: made visible to the compiler, or every buffer load
+// is wrapped in a waterfall loop); lanes past n read the tile's padding and are dropped by the caller.
+__device__ __forceinline__ const float* wave_tile(const float* XT, unsigned first, int n)
+{
+  const int tile_id = __builtin_amdgcn_readfirstlane(min((int) (first >> 6), (n - 1) >> 6));
+  return XT + (int64_t) tile_id * kDesc * 64;
+}
+
+__global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X, const float* __restrict__ XT, int n,
+  const int8_t* __restrict__ y, double* __restrict__ G, const SvmState* __restrict__ st, int poly)
+{
+  __shared__ __attribute__((aligned(16))) float2 xij[kDesc];
   if (st->stop)
     return;
   const int i = st->i, j = st->j;
   const double d_i = st->d_i, d_j = st->d_j;
-  for (int k = threadIdx.x; k < kGroups; k += 256)
-  {
-    reinterpret_cast<float4*>(xi)[k] = reinterpret_cast<const float4*>(X + (int64_t) i * kDesc)[k];
-    reinterpret_cast<float4*>(xj)[k] = reinterpret_cast<const float4*>(X + (int64_t) j * kDesc)[k];
-  }
+  for (int k = threadIdx.x; k < kDesc; k += 256)
+    xij[k] = make_float2(X[(int64_t) i * kDesc + k], X[(int64_t) j * kDesc + k]);
   __syncthreads();
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int tc = t < n ? t : n - 1;
-  const float* col = XT + tc;
   double si = 0, sj = 0;
-#pragma unroll 2
-  for (int g = 0; g < kGroups; g++)
-  {
-    const float a0 = col[(int64_t) (4 * g + 0) * n], a1 = col[(int64_t) (4 * g + 1) * n];
-    const float a2 = col[(int64_t) (4 * g + 2) * n], a3 = col[(int64_t) (4 * g + 3) * n];
-    const float4 bi = reinterpret_cast<const float4*>(xi)[g];
-    const float4 bj = reinterpret_cast<const float4*>(xj)[g];
-    si += a0 * bi.x + a1 * bi.y + a2 * bi.z + a3 * bi.w;
-    sj += a0 * bj.x + a1 * bj.y + a2 * bj.z + a3 * bj.w;
-  }
+  dual_dot<3>(wave_tile(XT, blockIdx.x * 256u + (threadIdx.x & ~63u), n), (threadIdx.x & 63u) * 4u, xij, si, sj);
   if (t >= n)
     return;
-  const float ki = qfloat(si), kj = qfloat(sj);
+  const float ki = qfloat(si, poly), kj = qfloat(sj, poly);
   const int yt = y[t];
   const float Qi = y[i] > 0 ? yt * ki : -yt * ki;  // get_row_svc
   const float Qj = y[j] > 0 ? yt * kj : -yt * kj;
   G[t] = G[t] + (Qi * d_i + Qj * d_j);
+}
+
+// ---- prediction with a general model (CvSVM::predict, C_SVC, two classes) --------------------------------------
+// buffer[h][v] = K(sv_v, desc_h) for two hypotheses per work-group (the pair shares the packed multiplies), then
+// sum_h = -rho + sum_v alpha[v] * buffer[h][v] in double, index order.
+__global__ __launch_bounds__(256) void k_svm_kvals(const float* __restrict__ desc, const int64_t* __restrict__ n_hyp,
+  const float* __restrict__ SVT, int n_sv, int poly, float* __restrict__ kbuf)
+{
+  __shared__ __attribute__((aligned(16))) float2 xij[kDesc];
+  const int64_t H = *n_hyp;
+  const int64_t h0 = (int64_t) blockIdx.y * 2;
+  if (h0 >= H)
+    return;
+  const int64_t h1 = h0 + 1 < H ? h0 + 1 : h0;
+  for (int k = threadIdx.x; k < kDesc; k += 256)
+    xij[k] = make_float2(desc[h0 * kDesc + k], desc[h1 * kDesc + k]);
+  __syncthreads();
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  double s0 = 0, s1 = 0;
+  dual_dot<3>(wave_tile(SVT, blockIdx.x * 256u + (threadIdx.x & ~63u), n_sv), (threadIdx.x & 63u) * 4u, xij, s0, s1);
+  if (v >= n_sv)
+    return;
+  kbuf[h0 * n_sv + v] = qfloat(s0, poly);
+  if (h1 != h0)
+    kbuf[h1 * n_sv + v] = qfloat(s1, poly);
+}
+
+__global__ __launch_bounds__(64) void k_svm_decide(const float* __restrict__ kbuf, const int64_t* __restrict__ n_hyp, int n_sv,
+  const double* __restrict__ alpha, double rho, agh_hypothesis* __restrict__ out, uint8_t* __restrict__ keep,
+  double* __restrict__ sums)
+{
+  const int64_t h = (int64_t) blockIdx.x * 64 + threadIdx.x;
+  if (h >= *n_hyp)
+    return;
+  double sum = -rho;
+  const float* row = kbuf + h * n_sv;
+  for (int v = 0; v < n_sv; v++)
+    sum += alpha[v] * row[v];
+  const uint8_t k = (sum > 0) ? 0 : 1;  // class_labels[sum > 0 ? 0 : 1] = {-1, +1}; the reference keeps prediction == 1
+  if (keep)
+    keep[h] = k;
+  if (sums)
+    sums[h] = sum;
+  if (out)
+    out[h].svm_keep = k;
+}
+
+__global__ __launch_bounds__(256) void k_svm_gather(const float* __restrict__ X, const int32_t* __restrict__ rows, int n_rows,
+  float* __restrict__ out)
+{
+  const int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t) n_rows * kDesc)
+    return;
+  out[e] = X[(int64_t) rows[e / kDesc] * kDesc + e % kDesc];
 }
 
 // CvSVM::optimize_linear_svm: v[k] = sum over the support vectors, in order, of sv[k] * alpha (double), stored as float.
@@ -342,10 +447,14 @@ __global__ __launch_bounds__(256) void k_svm_compress(const float* __restrict__ 
 }
 
 // images (n_images x kImageWords, packed) + order (instance k of the solver = image order[k]; class 0 first) -> model.
+// Outputs: LINEAR -- sv_out = the compacted vector, alpha_out[0] = 1, *n_sv_out = 1 (info_out[1] keeps the solver's
+// support-vector count); POLY -- the support vectors' descriptors in model order, their signed alphas, their count.
 int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t* h_order, const int8_t* h_y, int64_t n,
-  double C, int max_iter, double eps, float* weights_out, double* rho_out, int32_t* info_out, float* desc_out_host,
-  hipStream_t st)
+  int poly, double C, int max_iter, double eps, float* sv_out, int64_t sv_cap, double* alpha_out, int32_t* n_sv_out,
+  double* rho_out, int32_t* info_out, hipStream_t st)
 {
+  int32_t* d_rows = nullptr;
+  float* d_svrows = nullptr;
   uint32_t* d_img = nullptr;
   int32_t* d_ord = nullptr;
   int8_t *d_y = nullptr, *d_status = nullptr;
@@ -369,7 +478,7 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
   TRY(hipMalloc((void**) &d_y, (size_t) n));
   TRY(hipMalloc((void**) &d_status, (size_t) n));
   TRY(hipMalloc((void**) &d_X, (size_t) n * kDesc * 4));
-  TRY(hipMalloc((void**) &d_XT, (size_t) n * kDesc * 4));
+  TRY(hipMalloc((void**) &d_XT, (size_t) ((n + 63) / 64) * 64 * kDesc * 4));
   TRY(hipMalloc((void**) &d_diag, (size_t) n * 4));
   TRY(hipMalloc((void**) &d_w, (size_t) kDesc * 4));
   TRY(hipMalloc((void**) &d_alpha, (size_t) n * 8));
@@ -390,16 +499,15 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
     const int ni = (int) n;
     hipLaunchKernelGGL(k_svm_transpose, dim3((kDesc + 31) / 32, (unsigned) ((n + 31) / 32)), dim3(256), 0, st, d_X, d_XT, ni);
     hipLaunchKernelGGL(k_svm_init, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_XT, ni, d_diag, d_alpha, d_G,
-      d_status, d_st);
+      d_status, d_st, poly);
     const int batch = 50;  // steps between looks at the stop flag (a finished solve turns the rest into empty launches)
     for (int done = 0; rc == AGH_OK && done <= max_iter; done += batch)
     {
       for (int b = 0; b < batch; b++)
       {
         hipLaunchKernelGGL(k_svm_select, dim3(1), dim3(1024), 0, st, d_X, ni, d_y, d_alpha, d_status, d_G, d_diag, d_st, C,
-          eps, max_iter);
-        hipLaunchKernelGGL(k_svm_update, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_X, d_XT, ni, d_y, d_G,
-          d_st);
+          eps, max_iter, poly);
+        hipLaunchKernelGGL(k_svm_update, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_X, d_XT, ni, d_y, d_G, d_st, poly);
       }
       TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
       TRY(hipStreamSynchronize(st));
@@ -450,25 +558,121 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
       n_sv += std::fabs(a_signed[(size_t) k]) > 0 ? 1 : 0;
     }
     *rho_out = nr_free > 0 ? sum_free / nr_free : (ub + lb) * 0.5;
-    TRY(hipMemcpyAsync(d_as, a_signed.data(), (size_t) n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_svm_compress, dim3((kDesc + 255) / 256), dim3(256), 0, st, d_X, (int) n, d_as, d_w);
-    TRY(hipMemcpyAsync(weights_out, d_w, (size_t) kDesc * 4, hipMemcpyDeviceToHost, st));
-    if (desc_out_host)
-      TRY(hipMemcpyAsync(desc_out_host, d_X, (size_t) n * kDesc * 4, hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
-    TRY(hipGetLastError());
     if (info_out)
     {
       info_out[0] = hs.iter;
       info_out[1] = n_sv;
     }
+    if (!poly)
+    {
+      TRY(hipMemcpyAsync(d_as, a_signed.data(), (size_t) n * 8, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_svm_compress, dim3((kDesc + 255) / 256), dim3(256), 0, st, d_X, (int) n, d_as, d_w);
+      TRY(hipMemcpyAsync(sv_out, d_w, (size_t) kDesc * 4, hipMemcpyDeviceToHost, st));
+      alpha_out[0] = 1.0;
+      *n_sv_out = 1;
+    }
+    else
+    {
+      // do_train: the support vectors are the samples with |alpha| > 0, in the class-sorted order; index = 0 .. n_sv-1
+      *n_sv_out = n_sv;
+      if (n_sv > sv_cap)
+      {
+        c->err = "agh_train_svm: " + std::to_string(n_sv) + " support vectors, room for " + std::to_string(sv_cap);
+        rc = AGH_ERR_CAPACITY;
+      }
+      else if (n_sv > 0)
+      {
+        std::vector<int32_t> rows;
+        for (int64_t k = 0; k < n; k++)
+          if (std::fabs(a_signed[(size_t) k]) > 0)
+          {
+            alpha_out[rows.size()] = a_signed[(size_t) k];
+            rows.push_back((int32_t) k);
+          }
+        TRY(hipMalloc((void**) &d_rows, rows.size() * 4));
+        TRY(hipMalloc((void**) &d_svrows, rows.size() * kDesc * 4));
+        TRY(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        if (rc == AGH_OK)
+          hipLaunchKernelGGL(k_svm_gather, dim3((unsigned) ((rows.size() * kDesc + 255) / 256)), dim3(256), 0, st, d_X, d_rows,
+            (int) rows.size(), d_svrows);
+        TRY(hipMemcpyAsync(sv_out, d_svrows, rows.size() * kDesc * 4, hipMemcpyDeviceToHost, st));
+      }
+    }
+    TRY(hipStreamSynchronize(st));
+    TRY(hipGetLastError());
   }
 #undef TRY
   for (void* p : { (void*) d_img, (void*) d_ord, (void*) d_y, (void*) d_status, (void*) d_X, (void*) d_XT, (void*) d_diag,
-         (void*) d_w, (void*) d_alpha, (void*) d_G, (void*) d_as, (void*) d_st })
+         (void*) d_w, (void*) d_alpha, (void*) d_G, (void*) d_as, (void*) d_st, (void*) d_rows, (void*) d_svrows })
     if (p)
       (void) hipFree(p);
   return rc;
+}
+
+// CvSVM::predict with a model that is not the compacted linear vector (Learning::classify, learning.cpp:220-225).
+int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_keep, hipStream_t st)
+{
+  if (cap <= 0)
+    return AGH_OK;
+  const int n_sv = c->svm_n_sv;
+  if ((int64_t) cap * n_sv > c->cls_kbuf_cap)
+  {
+    if (c->d_cls_kbuf)
+      (void) hipFree(c->d_cls_kbuf);
+    c->d_cls_kbuf = nullptr;
+    c->cls_kbuf_cap = 0;
+    if (hipMalloc((void**) &c->d_cls_kbuf, (size_t) cap * n_sv * 4) != hipSuccess)
+    {
+      c->err = "agh_classify: out of device memory for the kernel-value buffer";
+      return AGH_ERR_HIP;
+    }
+    c->cls_kbuf_cap = (int64_t) cap * n_sv;
+  }
+  hipLaunchKernelGGL(k_svm_kvals, dim3((unsigned) ((n_sv + 255) / 256), (unsigned) ((cap + 1) / 2)), dim3(256), 0, st, d_desc,
+    (const int64_t*) c->d_nout_last, (const float*) c->d_svm_svT, n_sv, c->svm_kernel == AGH_SVM_POLY2 ? 1 : 0, c->d_cls_kbuf);
+  hipLaunchKernelGGL(k_svm_decide, dim3((unsigned) ((cap + 63) / 64)), dim3(64), 0, st, (const float*) c->d_cls_kbuf,
+    (const int64_t*) c->d_nout_last, n_sv, (const double*) c->d_svm_alpha, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+int svm_load_general(Ctx* c, int kernel_type, const float* sv, int n_sv, const double* alpha, double rho)
+{
+  float* d_sv = nullptr;
+  for (void** p : { (void**) &c->d_svm_svT, (void**) &c->d_svm_alpha })
+    if (*p)
+    {
+      (void) hipFree(*p);
+      *p = nullptr;
+    }
+  c->has_svm = false;
+  const size_t padded = (size_t) ((n_sv + 63) / 64) * 64;
+  if (hipMalloc((void**) &d_sv, (size_t) n_sv * kDesc * 4) != hipSuccess ||
+      hipMalloc((void**) &c->d_svm_svT, padded * kDesc * 4) != hipSuccess ||
+      hipMalloc((void**) &c->d_svm_alpha, (size_t) n_sv * 8) != hipSuccess ||
+      hipMemcpyAsync(d_sv, sv, (size_t) n_sv * kDesc * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(c->d_svm_alpha, alpha, (size_t) n_sv * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemsetAsync(c->d_svm_svT, 0, padded * kDesc * 4, c->stream) != hipSuccess)
+  {
+    if (d_sv)
+      (void) hipFree(d_sv);
+    c->err = "agh_load_svm_model: device allocation or copy failed";
+    return AGH_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_svm_transpose, dim3((kDesc + 31) / 32, (unsigned) ((n_sv + 31) / 32)), dim3(256), 0, c->stream, d_sv,
+    c->d_svm_svT, n_sv);
+  const bool ok = hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+  (void) hipFree(d_sv);
+  if (!ok)
+  {
+    c->err = "agh_load_svm_model: transpose failed";
+    return AGH_ERR_HIP;
+  }
+  c->svm_kernel = kernel_type;
+  c->svm_n_sv = n_sv;
+  c->svm_rho = rho;
+  c->svm_general = true;
+  c->has_svm = true;
+  return AGH_OK;
 }
 
 }  // namespace agh
@@ -569,13 +773,16 @@ int agh_hog_images(agh_ctx* ctx, const uint32_t* images, int64_t n, float* desc)
   return rc;
 }
 
-int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, double C, int32_t max_iter,
-  double eps, float* weights_out, double* rho_out, int32_t* info_out)
+int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, int32_t kernel_type, double C,
+  int32_t max_iter, double eps, float* sv_out, int64_t sv_cap, double* alpha_out, int32_t* n_sv_out, double* rho_out,
+  int32_t* info_out)
 {
-  if (!ctx || !images || !labels || !weights_out || !rho_out || n <= 0 || n >= (1ll << 24) || !(C > 0) || max_iter < 0)
+  if (!ctx || !images || !labels || !sv_out || !alpha_out || !n_sv_out || !rho_out || n <= 0 || n >= (1ll << 24) ||
+      !(C > 0) || max_iter < 0 || sv_cap < 1 || (kernel_type != AGH_SVM_LINEAR && kernel_type != AGH_SVM_POLY2))
   {
     if (ctx)
-      ctx->c.err = "agh_train_svm: need images, labels, 0 < n < 2^24, C > 0, max_iter >= 0 and the two outputs";
+      ctx->c.err = "agh_train_svm: need images, labels, 0 < n < 2^24, a supported kernel, C > 0, max_iter >= 0, "
+                   "sv_cap >= 1 and the outputs";
     return AGH_ERR_INVALID_ARGUMENT;
   }
   Ctx* c = &ctx->c;
@@ -600,9 +807,9 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
   if (hipSetDevice(c->device) != hipSuccess)
     return AGH_ERR_HIP;
   int32_t info[2] = { 0, 0 };
-  const int rc = svm_train(c, images, n, order.data(), y.data(), n, C, max_iter, eps, weights_out, rho_out, info, nullptr,
-    c->stream);
-  if (rc == AGH_OK && info_out)
+  const int rc = svm_train(c, images, n, order.data(), y.data(), n, kernel_type == AGH_SVM_POLY2 ? 1 : 0, C, max_iter, eps,
+    sv_out, sv_cap, alpha_out, n_sv_out, rho_out, info, c->stream);
+  if ((rc == AGH_OK || rc == AGH_ERR_CAPACITY) && info_out)
   {
     info_out[0] = info[0];
     info_out[1] = info[1];
@@ -612,12 +819,36 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
   return rc;
 }
 
-// CvSVM::save of the compacted linear model, laid out as cv::FileStorage's YAML emitter does (reals "%.8e" / "%.16e",
-// integers-valued reals "%d.", flow sequences wrapped before column 72): the reference's shipped model file is
-// reproduced byte for byte from its weights and rho (tests/test_training.py).
-int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights, double rho)
+int agh_load_svm_model(agh_ctx* ctx, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho)
 {
-  if (!path || !weights || n_weights <= 0)
+  if (!ctx || !sv || !alpha || n_sv < 1 || (kernel_type != AGH_SVM_LINEAR && kernel_type != AGH_SVM_POLY2))
+  {
+    if (ctx)
+      ctx->c.err = "agh_load_svm_model: need support vectors, alphas and a supported kernel (LINEAR, POLY degree 2)";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  Ctx* c = &ctx->c;
+  if (n_weights != kDesc)
+  {
+    c->err = "agh_load_svm_model: the HOG descriptor has 3528 entries (2 windows x 49 blocks x 36)";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  if (kernel_type == AGH_SVM_LINEAR && n_sv == 1 && alpha[0] == 1.0)  // the compacted form: fused into the HOG kernel
+    return agh_load_svm(ctx, sv, n_weights, rho);
+  if (hipSetDevice(c->device) != hipSuccess)
+    return AGH_ERR_HIP;
+  return svm_load_general(c, kernel_type, sv, n_sv, alpha, rho);
+}
+
+// CvSVM::save (learning.cpp:312) laid out as cv::FileStorage's YAML emitter does (reals "%.8e" / "%.16e", integer-valued
+// reals "%d.", flow sequences wrapped before column 72): the reference's shipped model file is reproduced byte for byte
+// from its weights and rho (tests/test_training.py).  Two shapes: the compacted LINEAR vector, or the n_sv support vectors
+// of a POLY degree-2 model with their alphas (convertData's uses_linear_kernel = false).
+int agh_save_svm_file(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho)
+{
+  if (!path || !sv || !alpha || n_sv < 1 || n_weights <= 0 || (kernel_type != AGH_SVM_LINEAR && kernel_type != AGH_SVM_POLY2))
     return AGH_ERR_INVALID_ARGUMENT;
   FILE* f = std::fopen(path, "wb");
   if (!f)
@@ -629,18 +860,12 @@ int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights,
     else
       std::snprintf(buf, 64, fmt, v);
   };
-  std::string txt = "%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n   kernel: { type:LINEAR }\n   C: 1.\n"
-                    "   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n";
-  txt += "   var_all: " + std::to_string(n_weights) + "\n   var_count: " + std::to_string(n_weights) + "\n";
-  txt += "   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n      dt: i\n"
-         "      data: [ -1, 1 ]\n   sv_total: 1\n   support_vectors:\n";
-  const size_t indent = 10, margin = 71;
-  std::string line = "      - [";
+  std::string txt;
+  const size_t margin = 71;
   char buf[64];
-  for (int k = 0; k < n_weights; k++)
-  {
-    real((double) weights[k], "%.8e", buf);
-    if (k)
+  auto begin_seq = [](const std::string& head) { return head + "["; };
+  auto add_item = [&](std::string& line, bool first, size_t indent) {  // icvYMLWrite: wrap when the item would pass the margin
+    if (!first)
       line += ',';
     const size_t off = line.size() + std::strlen(buf);
     if (off > margin && off - indent > 10)
@@ -653,11 +878,39 @@ int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights,
       line += ' ';
       line += buf;
     }
+  };
+  txt += "%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n";
+  txt += kernel_type == AGH_SVM_LINEAR ? "   kernel: { type:LINEAR }\n" : "   kernel: { type:POLY, degree:2., gamma:1., coef0:0. }\n";
+  txt += "   C: 1.\n   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n";
+  txt += "   var_all: " + std::to_string(n_weights) + "\n   var_count: " + std::to_string(n_weights) + "\n";
+  txt += "   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n      dt: i\n"
+         "      data: [ -1, 1 ]\n   sv_total: " + std::to_string(n_sv) + "\n   support_vectors:\n";
+  for (int v = 0; v < n_sv; v++)
+  {
+    std::string line = begin_seq("      - ");
+    for (int k = 0; k < n_weights; k++)
+    {
+      real((double) sv[(size_t) v * n_weights + k], "%.8e", buf);
+      add_item(line, k == 0, 10);
+    }
+    txt += line + " ]\n";
+  }
+  real(rho, "%.16e", buf);
+  txt += "   decision_functions:\n      -\n         sv_count: " + std::to_string(n_sv) + "\n         rho: " + buf + "\n";
+  std::string line = begin_seq("         alpha: ");
+  for (int k = 0; k < n_sv; k++)
+  {
+    real(alpha[k], "%.16e", buf);
+    add_item(line, k == 0, 13);
   }
   txt += line + " ]\n";
-  real(rho, "%.16e", buf);
-  txt += std::string("   decision_functions:\n      -\n         sv_count: 1\n         rho: ") + buf +
-         "\n         alpha: [ 1. ]\n         index: [ 0 ]\n";
+  line = begin_seq("         index: ");
+  for (int k = 0; k < n_sv; k++)
+  {
+    std::snprintf(buf, sizeof(buf), "%d", k);
+    add_item(line, k == 0, 13);
+  }
+  txt += line + " ]\n";
   const bool ok = std::fwrite(txt.data(), 1, txt.size(), f) == txt.size();
   return (std::fclose(f) == 0 && ok) ? AGH_OK : AGH_ERR_IO;
 }

@@ -166,7 +166,8 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
 int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
 
-/* Linear SVM (one weight vector of 3528 floats + rho), from memory or from an OpenCV YAML file. */
+/* Linear SVM (one weight vector of 3528 floats + rho) from memory, or any supported model (see agh_load_svm_model)
+ * from an OpenCV YAML file. */
 int agh_load_svm(agh_ctx* ctx, const float* weights, int32_t n_weights, double rho);
 int agh_load_svm_file(agh_ctx* ctx, const char* path);
 /* Learning::classify on the hypotheses of the last agh_find_hands* call: keep[i] = 1 iff kept.  Also sets
@@ -188,15 +189,27 @@ int agh_get_training_images(agh_ctx* ctx, uint32_t* images, int64_t cap_hyp);
 /* cv::HOGDescriptor(winSize 64x64).compute(image, winStride 32x32) as convertData calls it (learning.cpp:253-281):
  * n packed images -> n x 3528 floats. */
 int agh_hog_images(agh_ctx* ctx, const uint32_t* images, int64_t n, float* desc);
-/* convertData's CvSVM::train (C_SVC, LINEAR) on the images' descriptors, then CvSVM::optimize_linear_svm: one weight
- * vector + rho, usable with agh_load_svm.  labels[k] > 0 marks a positive (label 1), anything else label -1.  The
- * reference's CvSVMParams defaults are C = 1, max_iter = 1000, eps = FLT_EPSILON.  info_out (optional, 4 ints):
- * solver steps taken, support vectors, instances of label -1, instances of label +1.
+/* convertData's CvSVM::train (C_SVC) on the images' descriptors.  kernel_type AGH_SVM_LINEAR is convertData's
+ * uses_linear_kernel = true (the shipped model's shape): CvSVM::optimize_linear_svm compacts the result to one vector,
+ * returned as sv_out[0..3527] with alpha_out[0] = 1 and *n_sv_out = 1.  AGH_SVM_POLY2 is uses_linear_kernel = false,
+ * the default Learning::train* pass (learning.h:180-182): kernel (x.y)^2; sv_out receives the *n_sv_out support vectors
+ * (3528 floats each, room for sv_cap of them: AGH_ERR_CAPACITY with *n_sv_out set if there are more), alpha_out their
+ * signed coefficients.  labels[k] > 0 marks a positive (label 1), anything else label -1.  The reference's CvSVMParams
+ * defaults are C = 1, max_iter = 1000, eps = FLT_EPSILON.  info_out (optional, 4 ints): solver steps taken, support
+ * vectors of the solve, instances of label -1, instances of label +1.
  * OpenCV's solver is third-party code restated from its published algorithm: see DESIGN.md for what is pinned. */
-int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, double C, int32_t max_iter,
-  double eps, float* weights_out, double* rho_out, int32_t* info_out);
-/* CvSVM::save (learning.cpp:312) of that model in OpenCV's YAML layout (what agh_load_svm_file and CvSVM::load read). */
-int agh_save_svm_file(const char* path, const float* weights, int32_t n_weights, double rho);
+#define AGH_SVM_LINEAR 0
+#define AGH_SVM_POLY2 1
+int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, int64_t n, int32_t kernel_type, double C,
+  int32_t max_iter, double eps, float* sv_out, int64_t sv_cap, double* alpha_out, int32_t* n_sv_out, double* rho_out,
+  int32_t* info_out);
+/* CvSVM::save (learning.cpp:312) of such a model in OpenCV's YAML layout (what agh_load_svm_file and CvSVM::load read). */
+int agh_save_svm_file(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho);
+/* Load a model for agh_classify from memory: the compacted linear vector (same as agh_load_svm) or support vectors +
+ * alphas with either kernel (CvSVM::predict: sum = -rho + sum_k alpha[k] K(sv_k, x), kept iff sum <= 0). */
+int agh_load_svm_model(agh_ctx* ctx, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho);
 
 /* Introspection for parity tests / plotting (host buffers). */
 int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap);

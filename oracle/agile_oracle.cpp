@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1910,10 +1911,14 @@ typedef struct orc_train_info_
   double objective;
 } orc_train_info_;
 
-int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, double C, int32_t max_iter,
-  double eps, float* weights_out, double* rho_out, int32_t* info_out /* iterations, n_sv, n_class0, n_class1 */,
-  double* alpha_out /* optional, n entries in the caller's sample order, signed */, int num_threads)
+int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, int32_t kernel, double C,
+  int32_t max_iter, double eps, float* weights_out, double* rho_out,
+  int32_t* info_out /* iterations, n_sv, n_class0, n_class1 */,
+  double* alpha_out /* optional, n entries in the caller's sample order, signed */,
+  int32_t* sv_order_out /* optional, n_sv entries: the support vectors' sample indices in model order */, int num_threads)
 {
+  if (kernel != 0 && kernel != 1)
+    return -1;
   if (n <= 0 || var_count <= 0)
     return -1;
   std::vector<int64_t> order;
@@ -1961,7 +1966,9 @@ int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_
              sample[k + 3] * another[k + 3];
       for (; k < var_count; k++)
         s += sample[k] * another[k];
-      float q = (float) (s * 1.0 + 0.0);
+      float q = (float) (s * 1.0 + 0.0); /* gamma = 1, coef0 = 0 (CvSVMParams defaults) */
+      if (kernel == 1)
+        q = q * q; /* calc_poly: cvPow(R, R, degree = 2) = multiply(src, src) in float */
       if (q > max_val)
         q = max_val;
       row[(size_t) j] = y[(size_t) i] > 0 ? y[(size_t) j] * q : -y[(size_t) j] * q;
@@ -2115,13 +2122,15 @@ int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_
       alpha_out[order[(size_t) k]] = a;
     if (std::fabs(a) > 0)
     {
+      if (sv_order_out)
+        sv_order_out[n_sv] = (int32_t) order[(size_t) k];
       n_sv++;
       const float* src = features + order[(size_t) k] * var_count;
       for (int q = 0; q < var_count; q++)
         v[(size_t) q] += src[q] * a;
     }
   }
-  for (int q = 0; q < var_count; q++)
+  for (int q = 0; q < var_count && weights_out; q++) /* optimize_linear_svm (LINEAR models only) */
     weights_out[q] = (float) v[(size_t) q];
   *rho_out = rho;
   if (info_out)
@@ -2175,6 +2184,193 @@ int orc_save_svm(const char* path, const float* weights, int32_t n_w, double rho
   std::fprintf(f, "   decision_functions:\n      -\n         sv_count: 1\n         rho: %s\n         alpha: [ 1. ]\n"
                   "         index: [ 0 ]\n", buf);
   std::fclose(f);
+  return 0;
+}
+
+
+/* CvSVM::save for any of the two model shapes Learning::convertData produces (learning.cpp:296-312): LINEAR (compacted
+ * to one support vector by optimize_linear_svm) and POLY degree 2 (uses_linear_kernel = false, the header's default):
+ * write_params' kernel map, sv_total support vectors, one decision function with alpha ("%.16e") and index. */
+int orc_save_svm_model(const char* path, int32_t kernel, const float* sv, int32_t n_sv, int32_t n_w, const double* alpha,
+  double rho)
+{
+  FILE* f = std::fopen(path, "wb");
+  if (!f)
+    return -1;
+  auto real = [](double v, bool dbl, char* buf) {
+    const long iv = std::lrint(v);
+    if ((double) iv == v)
+      std::snprintf(buf, 64, "%ld.", iv);
+    else
+      std::snprintf(buf, 64, dbl ? "%.16e" : "%.8e", v);
+  };
+  std::string out;
+  auto flow_seq = [&](const std::string& head, size_t indent, int count, const std::function<void(int, char*)>& item) {
+    std::string line = head + "[";
+    char buf[64];
+    for (int k = 0; k < count; k++)
+    {
+      item(k, buf);
+      if (k)
+        line += ",";
+      const size_t off = line.size() + std::strlen(buf);
+      if (off > 71 && off - indent > 10)
+      {
+        out += line + "\n";
+        line = std::string(indent, ' ') + buf;
+      }
+      else
+        line += std::string(" ") + buf;
+    }
+    out += line + " ]\n";
+  };
+  out += "%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n";
+  out += kernel == 0 ? "   kernel: { type:LINEAR }\n" : "   kernel: { type:POLY, degree:2., gamma:1., coef0:0. }\n";
+  out += "   C: 1.\n   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n";
+  out += "   var_all: " + std::to_string(n_w) + "\n   var_count: " + std::to_string(n_w) + "\n";
+  out += "   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n      dt: i\n"
+         "      data: [ -1, 1 ]\n";
+  out += "   sv_total: " + std::to_string(n_sv) + "\n   support_vectors:\n";
+  for (int v = 0; v < n_sv; v++)
+    flow_seq("      - ", 10, n_w, [&](int k, char* buf) { real((double) sv[(size_t) v * n_w + k], false, buf); });
+  char rb[64];
+  real(rho, true, rb);
+  out += "   decision_functions:\n      -\n         sv_count: " + std::to_string(n_sv) + "\n         rho: " + rb + "\n";
+  flow_seq("         alpha: ", 13, n_sv, [&](int k, char* buf) { real(alpha[k], true, buf); });
+  flow_seq("         index: ", 13, n_sv, [&](int k, char* buf) { std::snprintf(buf, 64, "%d", k); });
+  const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+  return (std::fclose(f) == 0 && ok) ? 0 : -1;
+}
+
+/* CvSVM::load for those files: returns n_sv (the arrays hold min(n_sv, sv_cap) vectors), <0 on a parse error or an
+ * unsupported model (anything but C_SVC with LINEAR, or POLY degree 2 / gamma 1 / coef0 0). */
+int orc_load_svm_model(const char* path, int32_t* kernel_out, float* sv_out, int32_t sv_cap, int32_t n_w,
+  double* alpha_out, double* rho_out)
+{
+  FILE* f = std::fopen(path, "rb");
+  if (!f)
+    return -1;
+  std::string txt;
+  char buf[1 << 16];
+  size_t r;
+  while ((r = std::fread(buf, 1, sizeof(buf), f)) > 0)
+    txt.append(buf, r);
+  std::fclose(f);
+  const size_t kp = txt.find("kernel:"), svp = txt.find("support_vectors:"), dfp = txt.find("decision_functions:");
+  if (kp == std::string::npos || svp == std::string::npos || dfp == std::string::npos || txt.find("C_SVC") == std::string::npos)
+    return -2;
+  const std::string kline = txt.substr(kp, txt.find('\n', kp) - kp);
+  int kernel;
+  if (kline.find("LINEAR") != std::string::npos)
+    kernel = 0;
+  else if (kline.find("POLY") != std::string::npos)
+  {
+    auto field = [&](const char* name) {
+      const size_t p = kline.find(name);
+      return p == std::string::npos ? NAN : std::strtod(kline.c_str() + p + std::strlen(name), nullptr);
+    };
+    if (field("degree:") != 2.0 || field("gamma:") != 1.0 || field("coef0:") != 0.0)
+      return -3;
+    kernel = 1;
+  }
+  else
+    return -3;
+  *kernel_out = kernel;
+  int32_t n_sv = 0;
+  size_t pos = svp;
+  for (;;)
+  {
+    const size_t lb = txt.find('[', pos);
+    if (lb == std::string::npos || lb > dfp)
+      break;
+    const size_t rb = txt.find(']', lb);
+    if (rb == std::string::npos || rb > dfp)
+      return -2;
+    const char* s = txt.c_str() + lb + 1;
+    const char* end = txt.c_str() + rb;
+    int32_t k = 0;
+    while (s < end)
+    {
+      char* e2 = nullptr;
+      const double v = std::strtod(s, &e2);
+      if (e2 == s)
+      {
+        s++;
+        continue;
+      }
+      if (n_sv < sv_cap && k < n_w)
+        sv_out[(size_t) n_sv * n_w + k] = (float) v;
+      k++;
+      s = e2;
+    }
+    if (k != n_w)
+      return -2;
+    n_sv++;
+    pos = rb + 1;
+  }
+  const size_t rp = txt.find("rho:", dfp), ap = txt.find("alpha:", dfp);
+  if (rp == std::string::npos || ap == std::string::npos || n_sv == 0)
+    return -2;
+  *rho_out = std::strtod(txt.c_str() + rp + 4, nullptr);
+  const size_t lb = txt.find('[', ap), rb = txt.find(']', ap);
+  if (lb == std::string::npos || rb == std::string::npos)
+    return -2;
+  const char* s = txt.c_str() + lb + 1;
+  const char* end = txt.c_str() + rb;
+  int32_t k = 0;
+  while (s < end)
+  {
+    char* e2 = nullptr;
+    const double v = std::strtod(s, &e2);
+    if (e2 == s)
+    {
+      s++;
+      continue;
+    }
+    if (k < sv_cap)
+      alpha_out[k] = v;
+    k++;
+    s = e2;
+  }
+  return k == n_sv ? n_sv : -2;
+}
+
+/* CvSVM::predict (C_SVC, two classes) for those models: buffer[k] = K(sv_k, x) as a float (calc_linear / calc_poly with
+ * the clamp of CvSVMKernel::calc), sum = -rho + sum_k alpha[k] * buffer[index[k]] in double, class 0 (label -1) iff
+ * sum > 0; Learning::classify keeps prediction == 1 (learning.cpp:225-227). */
+int orc_classify_model(const uint8_t* images, int64_t n_hyp, int32_t kernel, const float* sv, int32_t n_sv, int32_t n_w,
+  const double* alpha, double rho, uint8_t* keep_out, double* sum_out, int num_threads)
+{
+  if (n_w != 3528)
+    return -1;
+  hog_tables();
+  const float max_val = (float) (FLT_MAX * 1e-3);
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+  for (int64_t i = 0; i < n_hyp; i++)
+  {
+    float desc[3528];
+    hog_compute(images + i * 8000, desc);
+    double sum = -rho;
+    for (int32_t v = 0; v < n_sv; v++)
+    {
+      const float* sample = sv + (size_t) v * n_w;
+      double s = 0;
+      int k = 0;
+      for (; k <= n_w - 4; k += 4)
+        s += sample[k] * desc[k] + sample[k + 1] * desc[k + 1] + sample[k + 2] * desc[k + 2] + sample[k + 3] * desc[k + 3];
+      for (; k < n_w; k++)
+        s += sample[k] * desc[k];
+      float q = (float) (s * 1.0 + 0.0);
+      if (kernel == 1)
+        q = q * q;
+      if (q > max_val)
+        q = max_val;
+      sum += alpha[v] * q;
+    }
+    keep_out[i] = (uint8_t) ((sum > 0) ? 0 : 1);
+    if (sum_out)
+      sum_out[i] = sum;
+  }
   return 0;
 }
 

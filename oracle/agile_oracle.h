@@ -151,8 +151,18 @@ int orc_find_hands_training(const orc_params* p, const float* xyz, int64_t strid
 /* f4: CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm as Learning::convertData runs it (learning.cpp:296-313).
  * features n x var_count row-major, labels > 0 = positive.  OpenCV's solver restated; parity with OpenCV UNPINNED
  * (see the .cpp).  info_out = {iterations, n_sv, n_class0, n_class1}.  Returns 0, -3 if a class is missing. */
-int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, double C, int32_t max_iter,
-  double eps, float* weights_out, double* rho_out, int32_t* info_out, double* alpha_out, int num_threads);
+int orc_train_svm(const float* features, const int8_t* labels, int64_t n, int32_t var_count, int32_t kernel /* 0 LINEAR,
+  1 POLY degree 2 (convertData's uses_linear_kernel = false) */, double C, int32_t max_iter, double eps,
+  float* weights_out /* LINEAR: the compacted vector; may be NULL */, double* rho_out, int32_t* info_out,
+  double* alpha_out, int32_t* sv_order_out, int num_threads);
+
+/* f4: CvSVM::save / load / predict for both model shapes (one compacted vector, or n_sv support vectors + alphas). */
+int orc_save_svm_model(const char* path, int32_t kernel, const float* sv, int32_t n_sv, int32_t n_w, const double* alpha,
+  double rho);
+int orc_load_svm_model(const char* path, int32_t* kernel_out, float* sv_out, int32_t sv_cap, int32_t n_w,
+  double* alpha_out, double* rho_out);
+int orc_classify_model(const uint8_t* images, int64_t n_hyp, int32_t kernel, const float* sv, int32_t n_sv, int32_t n_w,
+  const double* alpha, double rho, uint8_t* keep_out, double* sum_out, int num_threads);
 
 /* f4: CvSVM::save of the compacted linear model (pinned: regenerates the shipped model file byte for byte). */
 int orc_save_svm(const char* path, const float* weights, int32_t n_w, double rho);

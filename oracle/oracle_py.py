@@ -293,9 +293,10 @@ def hog_many(images: np.ndarray) -> np.ndarray:
 
 
 def train_svm(features: np.ndarray, labels: np.ndarray, C_: float = 1.0, max_iter: int = 1000,
-              eps: float = 1.1920928955078125e-07, num_threads: int = 0):
-    """CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm restated (parity with OpenCV itself unpinned).
-    Returns dict(w, rho, iterations, n_sv, alpha)."""
+              eps: float = 1.1920928955078125e-07, num_threads: int = 0, kernel: int = 0):
+    """CvSVM::train(C_SVC, LINEAR or POLY degree 2) restated (parity with OpenCV itself unpinned).
+    Returns dict(w [LINEAR: the compacted vector], rho, iterations, n_sv, alpha, sv_order, model) where model =
+    (kernel, sv, alpha, rho) is what CvSVM::save would hold."""
     features = np.ascontiguousarray(features, np.float32)
     n, d = features.shape
     lab = np.ascontiguousarray(np.where(np.asarray(labels) > 0, 1, -1), np.int8)
@@ -303,13 +304,61 @@ def train_svm(features: np.ndarray, labels: np.ndarray, C_: float = 1.0, max_ite
     rho = C.c_double(0)
     info = np.zeros(4, np.int32)
     alpha = np.zeros(n, np.float64)
+    sv_order = np.zeros(n, np.int32)
     rc = lib().orc_train_svm(_fp(features, C.c_float), lab.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(d),
-                             C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _fp(w, C.c_float), C.byref(rho),
-                             _fp(info, C.c_int32), _fp(alpha, C.c_double),
-                             C.c_int(num_threads if num_threads > 0 else (os.cpu_count() or 1)))
+                             C.c_int32(kernel), C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _fp(w, C.c_float),
+                             C.byref(rho), _fp(info, C.c_int32), _fp(alpha, C.c_double), _fp(sv_order, C.c_int32),
+                             C.c_int(num_threads if num_threads > 0 else min(os.cpu_count() or 1, 32)))
     if rc != 0:
         raise RuntimeError(f"orc_train_svm failed ({rc})")
-    return {"w": w, "rho": rho.value, "iterations": int(info[0]), "n_sv": int(info[1]), "alpha": alpha}
+    sv_order = sv_order[: int(info[1])]
+    if kernel == 0:
+        model = (0, w[None, :].copy(), np.ones(1), rho.value)
+    else:
+        model = (1, features[sv_order].copy(), alpha[sv_order].copy(), rho.value)
+    return {"w": w, "rho": rho.value, "iterations": int(info[0]), "n_sv": int(info[1]), "alpha": alpha,
+            "sv_order": sv_order, "model": model}
+
+
+def save_svm_model(path: str, model) -> None:
+    kernel, sv, alpha, rho = model
+    sv = np.ascontiguousarray(sv, np.float32)
+    alpha = np.ascontiguousarray(alpha, np.float64)
+    rc = lib().orc_save_svm_model(path.encode(), C.c_int32(kernel), _fp(sv, C.c_float), C.c_int32(sv.shape[0]),
+                                  C.c_int32(sv.shape[1]), _fp(alpha, C.c_double), C.c_double(rho))
+    assert rc == 0, rc
+
+
+def load_svm_model(path: str, sv_cap: int = 1 << 16):
+    kernel = C.c_int32(0)
+    rho = C.c_double(0)
+    probe = np.zeros((1, 3528), np.float32)
+    a1 = np.zeros(1, np.float64)
+    n = lib().orc_load_svm_model(path.encode(), C.byref(kernel), _fp(probe, C.c_float), C.c_int32(1), C.c_int32(3528),
+                                 _fp(a1, C.c_double), C.byref(rho))
+    if n < 0:
+        raise RuntimeError(f"SVM parse failed ({n})")
+    sv = np.zeros((n, 3528), np.float32)
+    alpha = np.zeros(n, np.float64)
+    n2 = lib().orc_load_svm_model(path.encode(), C.byref(kernel), _fp(sv, C.c_float), C.c_int32(n), C.c_int32(3528),
+                                  _fp(alpha, C.c_double), C.byref(rho))
+    assert n2 == n
+    return kernel.value, sv, alpha, rho.value
+
+
+def classify_model(images: np.ndarray, model, num_threads: int = 0):
+    kernel, sv, alpha, rho = model
+    images = np.ascontiguousarray(images, np.uint8).reshape(-1, 8000)
+    sv = np.ascontiguousarray(sv, np.float32)
+    alpha = np.ascontiguousarray(alpha, np.float64)
+    keep = np.zeros(images.shape[0], np.uint8)
+    sums = np.zeros(images.shape[0], np.float64)
+    rc = lib().orc_classify_model(_fp(images, C.c_uint8), C.c_int64(images.shape[0]), C.c_int32(kernel), _fp(sv, C.c_float),
+                                  C.c_int32(sv.shape[0]), C.c_int32(3528), _fp(alpha, C.c_double), C.c_double(rho),
+                                  _fp(keep, C.c_uint8), _fp(sums, C.c_double),
+                                  C.c_int(num_threads if num_threads > 0 else (os.cpu_count() or 1)))
+    assert rc == 0
+    return keep, sums
 
 
 def save_svm(path: str, w: np.ndarray, rho: float) -> None:

@@ -232,7 +232,7 @@ def find_handles(hands, min_inliers=3, min_length=0.005):
 
 
 # ---- f4: CvSVM::train(C_SVC, LINEAR) + optimize_linear_svm, OpenCV 2.4 svm.cpp, transcribed for small problems -------
-def _kernel_row(X, i):
+def _kernel_row(X, i, poly=False):
     """calc_non_rbf_base: float products, groups of four summed in float, accumulated in double in index order."""
     p = X * X[i][None, :]  # float32
     n, d = X.shape
@@ -242,10 +242,12 @@ def _kernel_row(X, i):
     for k in range(d - d % 4, d):
         s = s + p[:, k].astype(np.float64)
     q = (s * 1.0 + 0.0).astype(np.float32)
+    if poly:
+        q = q * q  # calc_poly: cvPow(R, R, 2) = multiply(src, src), float
     return np.minimum(q, np.float32(np.finfo(np.float32).max * 1e-3))
 
 
-def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.float32).eps)):
+def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.float32).eps), poly=False):
     X0 = np.ascontiguousarray(features, np.float32)
     lab = np.asarray(labels)
     order = np.concatenate([np.nonzero(lab <= 0)[0], np.nonzero(lab > 0)[0]])  # class 0 (label -1) first
@@ -261,7 +263,7 @@ def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.floa
 
     def row(i):
         if i not in rows:
-            q = _kernel_row(X, i)
+            q = _kernel_row(X, i, poly)
             rows[i] = (y.astype(np.float32) * q) if y[i] > 0 else (-y.astype(np.float32) * q)
         return rows[i]
 
@@ -339,4 +341,4 @@ def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.floa
     alpha_out = np.zeros(n)
     alpha_out[order] = a
     return dict(w=v.astype(np.float32), rho=rho, iterations=min(it, max_iter), n_sv=int((np.abs(a) > 0).sum()),
-                alpha=alpha_out)
+                alpha=alpha_out, sv_order=order[np.abs(a) > 0])

@@ -68,14 +68,39 @@ def test_oracle_camera_images_match_numpy_transcription(tiny_scene):
     assert checked > 10
 
 
-@pytest.mark.parametrize("n,seed,max_iter", [(40, 1, 1000), (90, 2, 60), (64, 3, 1000)])
-def test_oracle_solver_matches_numpy_transcription(n, seed, max_iter):
+@pytest.mark.parametrize("n,seed,max_iter,kernel", [(40, 1, 1000, 0), (90, 2, 60, 0), (64, 3, 1000, 0), (64, 4, 1000, 1),
+                                                     (90, 5, 45, 1)])
+def test_oracle_solver_matches_numpy_transcription(n, seed, max_iter, kernel):
     X, y = _toy_problem(n, seed)
-    a = O.train_svm(X, y, max_iter=max_iter)
-    b = R.train_svm(X, y, max_iter=max_iter)
+    a = O.train_svm(X, y, max_iter=max_iter, kernel=kernel)
+    b = R.train_svm(X, y, max_iter=max_iter, poly=bool(kernel))
     assert a["iterations"] == b["iterations"] and a["n_sv"] == b["n_sv"]
-    assert np.array_equal(a["alpha"], b["alpha"])
-    assert a["rho"] == b["rho"] and np.array_equal(a["w"], b["w"])
+    assert np.array_equal(a["alpha"], b["alpha"]) and np.array_equal(a["sv_order"], b["sv_order"])
+    assert a["rho"] == b["rho"]
+    if kernel == 0:
+        assert np.array_equal(a["w"], b["w"])
+
+
+def test_model_files_round_trip_both_shapes(tmp_path):
+    from agile_grasp_amd import binding, build
+
+    build.build()
+    X, y = _toy_problem(120, 8)
+    for kernel in (0, 1):
+        r = O.train_svm(X, y, kernel=kernel)
+        k, sv, alpha, rho = r["model"]
+        assert sv.shape[0] == (1 if kernel == 0 else r["n_sv"])
+        po, pp = str(tmp_path / f"o{kernel}.yaml"), str(tmp_path / f"p{kernel}.yaml")
+        O.save_svm_model(po, r["model"])
+        binding.save_svm_file(pp, sv, rho, kernel=kernel, alpha=alpha)
+        assert open(po, "rb").read() == open(pp, "rb").read()  # the two writers agree byte for byte
+        k2, sv2, alpha2, rho2 = O.load_svm_model(pp)
+        assert k2 == kernel and np.array_equal(sv2, sv) and np.array_equal(alpha2, alpha) and rho2 == rho
+    # the quadratic model separates what it was trained on (sum > 0 <=> label -1)
+    r = O.train_svm(X, y, kernel=1, max_iter=100000, eps=1e-3)
+    _, sv, alpha, rho = r["model"]
+    dec = ((X.astype(np.float64) @ sv.astype(np.float64).T) ** 2) @ alpha - rho
+    assert (np.where(dec > 0, -1, 1) == y).mean() > 0.95
 
 
 def test_oracle_solver_satisfies_kkt_when_run_to_convergence():
@@ -139,6 +164,47 @@ def test_training_images_and_descriptors_bit_exact(scene_name):
     assert_hyps_equal(again, ref["hyps"])
     with pytest.raises(binding.AghError):
         ctx.training_images()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_iter", [1000, 41])
+def test_quadratic_model_trained_saved_loaded_classified_bit_exact(small_scene, tmp_path, max_iter):
+    """Learning::train* as the reference calls convertData: uses_linear_kernel = false (learning.h:180-182)."""
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    ctx = binding.Context(sc.cam_origins)
+    hyps, packed, images = _training_set(sc, ctx)
+    use = (hyps["half_antipodal"] == 0) | (hyps["full_antipodal"] == 1)
+    labels = np.repeat(hyps["full_antipodal"][use].astype(np.int8), 3)
+    got = ctx.train_svm(packed[use].reshape(-1, 250), labels, max_iter=max_iter, kernel=binding.SVM_POLY2)
+    feats = O.hog_many(images[use].reshape(-1, 8000))
+    ref = O.train_svm(feats, labels, max_iter=max_iter, kernel=1)
+    _, rsv, ralpha, rrho = ref["model"]
+    assert got["iterations"] == ref["iterations"] and got["n_sv"] == ref["n_sv"] == len(got["alpha"])
+    assert got["rho"] == rrho and np.array_equal(got["alpha"], ralpha) and np.array_equal(got["sv"], rsv)
+    path = str(tmp_path / "poly.yaml")
+    binding.save_svm_file(path, got["sv"], got["rho"], kernel=binding.SVM_POLY2, alpha=got["alpha"])
+    model = O.load_svm_model(path)
+    assert model[0] == 1 and np.array_equal(model[1], rsv) and np.array_equal(model[2], ralpha) and model[3] == rrho
+    ctx.load_svm_file(path)
+    keep = ctx.classify()
+    desc, sums = ctx.hog()
+    okeep, osums = O.classify_model(images[:, 0], model)
+    assert np.array_equal(desc, feats.reshape(-1, 3, 3528)[:, 0]) if use.all() else True
+    assert np.array_equal(sums, osums) and np.array_equal(keep, okeep)
+    assert 0 < keep.sum() < keep.size
+    # an uncompacted LINEAR model (several support vectors) goes through the same general path
+    lin = O.train_svm(feats, labels, max_iter=max_iter, kernel=0)
+    order = lin["sv_order"]
+    ctx.load_svm_model(binding.SVM_LINEAR, feats[order], lin["alpha"][order], lin["rho"])
+    keep2 = ctx.classify()
+    okeep2, _ = O.classify_model(images[:, 0], (0, feats[order], lin["alpha"][order], lin["rho"]))
+    assert np.array_equal(keep2, okeep2)
+    # and loading the compacted vector switches back to the fused path
+    ctx.load_svm(lin["w"], lin["rho"])
+    okeep3, _ = O.classify(images[:, 0], lin["w"], lin["rho"])
+    assert np.array_equal(ctx.classify(), okeep3)
 
 
 @pytest.mark.gpu
