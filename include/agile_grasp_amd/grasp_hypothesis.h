@@ -3,7 +3,9 @@
 #ifndef AGILE_GRASP_AMD_GRASP_HYPOTHESIS_H
 #define AGILE_GRASP_AMD_GRASP_HYPOTHESIS_H
 
+#include <cstdint>
 #include <iostream>
+#include <memory>
 #include <vector>
 
 #include "../agh.h"
@@ -80,6 +82,22 @@ public:
   /** Position of this hypothesis in the device-side result list of the HandSearch call that produced it. */
   long getDeviceIndex() const { return device_index_; }
 
+  /** Training side.  The reference keeps points_for_learning_ and their split by camera in every hypothesis
+   *  (grasp_hypothesis.h:220-222) so that Learning::train can rasterise three instances later; here the hand sweep
+   *  rasterises them and the hypothesis carries the three packed 80x100 images (250 words each; cam = -1, 0, 1) when
+   *  HandSearch::setKeepsTrainingImages(true) was set.  `block` is shared by the hypotheses of one findHands call. */
+  void setTrainingImages(const std::shared_ptr<const std::vector<std::uint32_t> >& block, std::size_t first_word)
+  {
+    training_block_ = block;
+    training_first_ = first_word;
+  }
+  bool hasTrainingImages() const { return (bool) training_block_; }
+  /** cam = -1: all points of the hand box (createInstance's default); 0 / 1: that camera's points (learning.cpp:385-397). */
+  const std::uint32_t* getTrainingImage(int cam) const
+  {
+    return training_block_ ? training_block_->data() + training_first_ + (std::size_t) (cam + 1) * 250 : nullptr;
+  }
+
 private:
   Vector3d axis_, approach_, binormal_, grasp_bottom_, grasp_surface_;
   int cam_source_;
@@ -87,6 +105,8 @@ private:
   bool full_antipodal_, half_antipodal_;
   long device_index_;
   int n_points_for_learning_;
+  std::shared_ptr<const std::vector<std::uint32_t> > training_block_;
+  std::size_t training_first_ = 0;
 };
 
 }  // namespace agile_grasp_amd

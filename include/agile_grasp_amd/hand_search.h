@@ -70,6 +70,9 @@ public:
     dirty_ = true;
   }
   agh_ctx* context() { return ctx_; }
+  /** Training runs (src/nodes/train.cpp): every findHands(calculates_antipodal = true) also attaches the three
+   *  instance images to its hypotheses (GraspHypothesis::getTrainingImage), the input of Learning::train*. */
+  void setKeepsTrainingImages(bool b) { keeps_training_images_ = b; }
 
   std::vector<GraspHypothesis> findHands(const PointCloud::Ptr cloud, const VectorXi& pts_cam_source,
     const std::vector<int>& indices, const PointCloud::Ptr cloud_plot, bool calculates_antipodal, bool uses_clustering)
@@ -159,6 +162,9 @@ public:
     if (calculates_antipodal)
       std::cout << "Calculating normals for all points\n";  // hand_search.cpp:19
     std::cout << "Estimating local axes ...\nFinding hand poses ...\n";  // hand_search.cpp:52,58
+    const bool training = keeps_training_images_ && calculates_antipodal;
+    if (agh_set_training_images(ctx_, training ? 1 : 0) != AGH_OK)
+      return fail("agh_set_training_images");
     std::vector<agh_hypothesis> out(8 * idx.size() + 1);
     std::int64_t n_out = 0;
     const int rc = agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
@@ -168,6 +174,14 @@ public:
     hand_list.reserve((std::size_t) n_out);
     for (std::int64_t i = 0; i < n_out; i++)
       hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i));
+    if (training && n_out > 0)
+    {
+      std::shared_ptr<std::vector<std::uint32_t> > block(new std::vector<std::uint32_t>((std::size_t) n_out * 750));
+      if (agh_get_training_images(ctx_, block->data(), n_out) != (int) n_out)
+        return fail("agh_get_training_images");
+      for (std::int64_t i = 0; i < n_out; i++)
+        hand_list[(std::size_t) i].setTrainingImages(block, (std::size_t) i * 750);
+    }
     std::cout << " Found " << hand_list.size() << " robot hand poses\n";  // hand_search.cpp:203
     return hand_list;
   }
@@ -236,6 +250,7 @@ private:
   std::uint64_t sample_seed_;
   int device_;
   bool dirty_;
+  bool keeps_training_images_ = false;
 };
 
 }  // namespace agile_grasp_amd

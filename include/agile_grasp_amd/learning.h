@@ -1,5 +1,14 @@
-// learning.h -- the prediction side of Learning (include/agile_grasp/learning.h:122-123, learning.cpp:165-247):
-// classify(hands_list, svm_filename, cam_pos) keeps the hypotheses the linear SVM labels antipodal.
+// learning.h -- Learning (include/agile_grasp/learning.h:57-205).
+//
+// Prediction (learning.h:122-123, learning.cpp:165-247): classify(hands_list, svm_filename, cam_pos) keeps the
+// hypotheses the SVM labels antipodal.
+//
+// Training (learning.h:87-113, 180-182; learning.cpp:3-163, 249-318): train / trainBalanced select the instances exactly
+// as the reference does (three per hand: all points, camera 0's, camera 1's; std::rand() for the max_positive draws and
+// the negatives of trainBalanced) and convertData turns them into HOG descriptors, runs CvSVM::train's solver and writes
+// CvSVM::save's file -- all three on the GPU through agh_train_svm.  Like the reference, train* call convertData with
+// its default uses_linear_kernel = false, i.e. the quadratic kernel; pass true for the shipped model's linear shape.
+// The hands must come from a HandSearch with setKeepsTrainingImages(true) and calculates_antipodal = true.
 //
 // The HOG descriptor and the SVM score are computed on the GPU from the occupancy images the hand search left there,
 // so `hands_list` must come from the most recent HandSearch::findHands of the HandSearch passed to the constructor
@@ -8,8 +17,10 @@
 #ifndef AGILE_GRASP_AMD_LEARNING_H
 #define AGILE_GRASP_AMD_LEARNING_H
 
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -72,7 +83,181 @@ public:
     return antipodal_hands;
   }
 
+  /** learning.h:130-136: what convertToImage needs of a hand -- here the rasterised image itself. */
+  struct Instance
+  {
+    const std::uint32_t* image;  // 250 packed words (80 x 100 pixels)
+    bool label;
+  };
+
+  /** learning.cpp:375-400.  cam_pos is implied by the search (the image was rasterised with its camera origins). */
+  Instance createInstance(const GraspHypothesis& h, const Matrix3Xd& cam_pos, int cam = -1) const
+  {
+    (void) cam_pos;
+    Instance ins;
+    ins.image = h.getTrainingImage(cam);
+    ins.label = h.isFullAntipodal();
+    return ins;
+  }
+
+  /** learning.cpp:3-74 */
+  void trainBalanced(const std::vector<GraspHypothesis>& hands_list, const std::vector<int>& sizes,
+    const std::string& file_name, const Matrix3Xd& cam_pos, int max_positive = 1000000000, bool is_plotting = false)
+  {
+    std::vector<int> positives, negatives, indices_selected, positives_sub;
+    std::size_t k = 0;
+    for (int i = 0; i < (int) hands_list.size(); i++)
+    {
+      if (hands_list[(std::size_t) i].isFullAntipodal())
+        positives_sub.push_back(i);
+      else if (!hands_list[(std::size_t) i].isHalfAntipodal())
+        negatives.push_back(i);
+      if (k < sizes.size() && i == sizes[k])
+      {
+        selectPositives(positives_sub, max_positive, positives);
+        positives_sub.resize(0);
+        k++;
+      }
+    }
+    indices_selected.insert(indices_selected.end(), positives.begin(), positives.end());
+    std::set<int> indices;
+    while (!negatives.empty() && indices.size() < positives.size() && indices.size() < negatives.size())
+      indices.insert(indices.end(), std::rand() % (int) negatives.size());
+    for (std::set<int>::iterator it = indices.begin(); it != indices.end(); it++)
+      indices_selected.push_back(negatives[(std::size_t) *it]);
+    std::cout << "size(positives): " << positives.size() << std::endl;
+    std::cout << "indices_selected.size: " << indices_selected.size() << std::endl;
+    std::vector<Instance> instances;
+    for (std::size_t i = 0; i < indices_selected.size(); i++)
+      pushInstances(hands_list[(std::size_t) indices_selected[i]], cam_pos, instances);
+    std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    convertData(instances, file_name, is_plotting);
+  }
+
+  /** learning.cpp:76-141 */
+  void train(const std::vector<GraspHypothesis>& hands_list, const std::vector<int>& sizes, const std::string& file_name,
+    const Matrix3Xd& cam_pos, int max_positive = 1000000000, bool is_plotting = false)
+  {
+    std::vector<int> positives, chosen;
+    std::vector<Instance> instances;
+    std::size_t k = 0;
+    for (int i = 0; i < (int) hands_list.size(); i++)
+    {
+      const GraspHypothesis& h = hands_list[(std::size_t) i];
+      if (h.isFullAntipodal())
+        positives.push_back(i);
+      else if (!h.isHalfAntipodal())
+        pushInstances(h, cam_pos, instances);
+      if (k < sizes.size() && i == sizes[k])
+      {
+        chosen.clear();
+        selectPositives(positives, max_positive, chosen);
+        for (std::size_t j = 0; j < chosen.size(); j++)
+          pushInstances(hands_list[(std::size_t) chosen[j]], cam_pos, instances);
+        positives.resize(0);
+        k++;
+      }
+    }
+    std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    convertData(instances, file_name, is_plotting);
+  }
+
+  /** learning.cpp:143-163 */
+  void train(const std::vector<GraspHypothesis>& hands_list, const std::string& file_name, const Matrix3Xd& cam_pos,
+    bool is_plotting = false)
+  {
+    std::vector<Instance> instances;
+    for (std::size_t i = 0; i < hands_list.size(); i++)
+      if (!hands_list[i].isHalfAntipodal() || hands_list[i].isFullAntipodal())  // skip the merely half-antipodal
+        pushInstances(hands_list[i], cam_pos, instances);
+    std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    convertData(instances, file_name, is_plotting);
+  }
+
+  /** learning.cpp:249-318: images -> HOG -> CvSVM::train -> CvSVM::save.  Returns false (after printing why) where the
+   *  reference would throw inside OpenCV or write nothing useful. */
+  bool convertData(const std::vector<Instance>& instances, const std::string& file_name, bool is_plotting = false,
+    bool uses_linear_kernel = false)
+  {
+    (void) is_plotting;
+    agh_ctx* ctx = search_.context();
+    if (!ctx)
+    {
+      std::cout << " Error: no hand search has run on this device context\n";
+      return false;
+    }
+    const std::size_t n = instances.size();
+    std::vector<std::uint32_t> images(n * 250);
+    std::vector<signed char> labels(n);
+    int num_positives = 0;
+    for (std::size_t i = 0; i < n; i++)
+    {
+      if (!instances[i].image)
+      {
+        std::cout << " Error: hypothesis without training images (HandSearch::setKeepsTrainingImages, "
+                     "calculates_antipodal)\n";
+        return false;
+      }
+      for (int w = 0; w < 250; w++)
+        images[i * 250 + (std::size_t) w] = instances[i].image[w];
+      labels[i] = instances[i].label ? 1 : -1;  // learning.cpp:282-288
+      num_positives += instances[i].label ? 1 : 0;
+    }
+    const int kernel = uses_linear_kernel ? AGH_SVM_LINEAR : AGH_SVM_POLY2;  // learning.cpp:303-309
+    const std::size_t sv_cap = uses_linear_kernel ? 1 : (n > 0 ? n : 1);
+    std::vector<float> sv(sv_cap * 3528);
+    std::vector<double> alpha(sv_cap);
+    std::int32_t n_sv = 0, info[4] = { 0, 0, 0, 0 };
+    double rho = 0;
+    // CvSVMParams defaults (learning.cpp:297): C = 1, term_crit = 1000 iterations / FLT_EPSILON
+    if (agh_train_svm(ctx, images.data(), labels.data(), (std::int64_t) n, kernel, 1.0, 1000, 1.1920928955078125e-07,
+          sv.data(), (std::int64_t) sv_cap, alpha.data(), &n_sv, &rho, info) != AGH_OK)
+    {
+      std::cout << " Error: " << agh_last_error(ctx) << "\n";
+      return false;
+    }
+    if (agh_save_svm_file(file_name.c_str(), kernel, sv.data(), n_sv, 3528, alpha.data(), rho) != AGH_OK)
+    {
+      std::cout << " Error: cannot write " << file_name << "\n";
+      return false;
+    }
+    std::cout << "# training examples: " << n << " (# positives: " << num_positives << ", # negatives: "
+              << n - (std::size_t) num_positives << ")\n";
+    std::cout << "Saved trained SVM as " << file_name << "\n";
+    return true;
+  }
+
 private:
+  // the instance for the hand as it is plus the two simulated single-camera views (learning.cpp:64-69, 92-97, 154-158)
+  void pushInstances(const GraspHypothesis& h, const Matrix3Xd& cam_pos, std::vector<Instance>& instances) const
+  {
+    instances.push_back(createInstance(h, cam_pos));
+    instances.push_back(createInstance(h, cam_pos, 0));
+    instances.push_back(createInstance(h, cam_pos, 1));
+  }
+
+  // learning.cpp:21-41 / 100-133: all of `from` if it has at most max_positive entries, else max_positive distinct
+  // std::rand() draws in ascending order
+  static void selectPositives(const std::vector<int>& from, int max_positive, std::vector<int>& to)
+  {
+    if ((long) from.size() <= (long) max_positive)
+    {
+      to.insert(to.end(), from.begin(), from.end());
+      return;
+    }
+    std::set<int> indices;
+    while ((long) indices.size() < (long) max_positive)
+      indices.insert(indices.end(), std::rand() % (int) from.size());
+    std::cout << from.size() << " positive examples found\n";
+    std::cout << " randomly selected indices:";
+    for (std::set<int>::iterator it = indices.begin(); it != indices.end(); it++)
+    {
+      std::cout << " " << *it;
+      to.push_back(from[(std::size_t) *it]);
+    }
+    std::cout << std::endl;
+  }
+
   HandSearch& search_;
   int num_threads_;
 };

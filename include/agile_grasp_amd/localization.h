@@ -87,6 +87,20 @@ public:
     device_ = device;
     search_.reset();
   }
+  /** Training runs (src/nodes/train.cpp): localizeHands(..., calculates_antipodal = true, ...) then returns hypotheses
+   *  that carry their three instance images, the input of Learning::train / trainBalanced. */
+  void setKeepsTrainingImages(bool b)
+  {
+    keeps_training_images_ = b;
+    if (search_)
+      search_->setKeepsTrainingImages(b);
+  }
+  /** The search the hypotheses came from: what this adapter's Learning is constructed on (train.cpp:122). */
+  HandSearch& getHandSearch()
+  {
+    ensureSearch();
+    return *search_;
+  }
 
   /** localization.cpp:3-140 */
   std::vector<GraspHypothesis> localizeHands(const PointCloud::Ptr& cloud_in, int size_left,
@@ -240,6 +254,7 @@ private:
     search_->setCamTfRight(cam_tf_right_);
     search_->setDeterministicNormalEstimation(deterministic_);
     search_->setDevice(device_);
+    search_->setKeepsTrainingImages(keeps_training_images_);
   }
 
   int num_threads_, num_samples_;
@@ -250,6 +265,7 @@ private:
   double finger_width_, hand_outer_diameter_, hand_depth_, init_bite_, hand_height_, nn_radius_taubin_, nn_radius_hands_;
   bool deterministic_;
   int device_;
+  bool keeps_training_images_ = false;
   std::unique_ptr<HandSearch> search_;
   PointCloud::Ptr last_cloud_;
   VectorXi last_cam_;

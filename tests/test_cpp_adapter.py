@@ -363,3 +363,104 @@ def test_example_runs_on_pcd_files(tmp_path):
     n_hands, n_anti, n_handles = (int(t) for t in summary[0].replace(",", "").split()[0:6:2])
     assert n_hands >= n_anti >= 0 and n_handles >= 0
     assert len([l for l in out.stdout.splitlines() if l.startswith("grasp ")]) == n_handles
+
+
+# ---- the training run (src/nodes/train.cpp) through the adapter's Learning::train* ----
+def _build_train(tmp_path):
+    from agile_grasp_amd import build
+
+    build.build()
+    exe = str(tmp_path / "train_test")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "train_test.cpp"), "-o", exe, "-L" + libdir,
+                           "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_train_adapter_compiles(tmp_path):
+    _build_train(tmp_path)
+
+
+def _select_like_reference(hyp_lists, mode, max_positive):
+    """learning.cpp:3-163 in Python: returns the hypothesis indices (into the concatenation) in instance order."""
+    from oracle import oracle_py as O
+
+    hyps = np.concatenate(hyp_lists)
+    sizes = list(np.cumsum([len(h) for h in hyp_lists]))
+    full, half = hyps["full_antipodal"] != 0, hyps["half_antipodal"] != 0
+    rnd = iter(O.glibc_rand(1, 100000))  # std::rand() after the test program's srand(1)
+
+    def pick(pos):
+        if len(pos) <= max_positive:
+            return list(pos)
+        chosen = set()
+        while len(chosen) < max_positive:
+            chosen.add(int(next(rnd)) % len(pos))
+        return [pos[i] for i in sorted(chosen)]
+
+    if mode in ("all", "linear"):
+        return [i for i in range(len(hyps)) if (not half[i]) or full[i]]
+    sel, pos, neg, positives, k = [], [], [], [], 0
+    for i in range(len(hyps)):
+        if full[i]:
+            pos.append(i)
+        elif not half[i]:
+            (sel if mode == "sizes" else neg).append(i)
+        if k < len(sizes) and i == sizes[k]:
+            if mode == "sizes":
+                sel.extend(pick(pos))
+            else:
+                positives.extend(pick(pos))
+            pos = []
+            k += 1
+    if mode == "sizes":
+        return sel
+    chosen = set()
+    while neg and len(chosen) < len(positives) and len(chosen) < len(neg):
+        chosen.add(int(next(rnd)) % len(neg))
+    return positives + [neg[i] for i in sorted(chosen)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,max_positive", [("all", 0), ("sizes", 5), ("balanced", 7), ("linear", 0)])
+def test_train_adapter_writes_the_model_the_c_abi_trains(tmp_path, mode, max_positive):
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as O
+
+    exe = _build_train(tmp_path)
+    scenes = [synthetic.config("small"), synthetic.make_scene(30_000, 150, seed=21, two_view=True, n_objects=6),
+              synthetic.config("tiny")]
+    clouds = []
+    for k, sc in enumerate(scenes):
+        clouds.append(str(tmp_path / f"cloud{k}.bin"))
+        _dump(sc, clouds[-1])
+    model = str(tmp_path / "model.yaml")
+    out = subprocess.run([exe, model, mode, str(max_positive)] + clouds, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ctx = binding.Context(scenes[0].cam_origins)
+    ctx.set_training_images(True)
+    hyp_lists, img_lists = [], []
+    for sc in scenes:
+        ctx.set_cloud(sc.xyz, sc.cam)
+        hyp_lists.append(ctx.find_hands(sc.samples, calculates_antipodal=True))
+        img_lists.append(ctx.training_images())
+    hyps, imgs = np.concatenate(hyp_lists), np.concatenate(img_lists)
+    sel = _select_like_reference(hyp_lists, mode, max_positive)
+    labels = np.repeat(hyps["full_antipodal"][sel].astype(np.int8), 3)
+    assert f"# training examples: {3 * len(sel)} (# positives: {int(labels.sum())}" in out.stdout
+    kernel = binding.SVM_LINEAR if mode == "linear" else binding.SVM_POLY2  # convertData's default is the quadratic kernel
+    got = ctx.train_svm(imgs[sel].reshape(-1, 250), labels, kernel=kernel)
+    expect = str(tmp_path / "expect.yaml")
+    if kernel == binding.SVM_LINEAR:
+        binding.save_svm_file(expect, got["w"], got["rho"])
+    else:
+        binding.save_svm_file(expect, got["sv"], got["rho"], kernel=kernel, alpha=got["alpha"])
+    assert open(model, "rb").read() == open(expect, "rb").read()
+    # ... and Learning::classify with the new model file on the last cloud's hands
+    ctx.load_svm_file(model)
+    keep = ctx.classify()
+    res = [l for l in out.stdout.splitlines() if l.startswith("TRAINED")][0].split()
+    assert int(res[1]) == len(hyps) and int(res[2]) == int(keep.sum())
+    okeep, _ = O.classify_model(binding.unpack_images(img_lists[-1][:, 0]), O.load_svm_model(model))
+    assert np.array_equal(keep, okeep)
