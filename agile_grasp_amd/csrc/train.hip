@@ -14,8 +14,8 @@
 // k_svm_select (one work-group) does the reductions, the K(i,j) dot product and the clipped two-variable update;
 // k_svm_update (one thread per instance) computes its entry of both rows from the transposed feature matrix (so a
 // wavefront reads 64 consecutive instances of one feature: coalesced) and updates its gradient entry.  Every float
-// and double operation keeps the order of the CPU code, so the model is bit-identical to the oracle's restatement
-// (oracle/agile_oracle.cpp orc_train_svm; parity with OpenCV itself is unpinned -- see DESIGN.md).
+// and double operation keeps the order of the CPU code, so the model is bit-identical to the test suite's CPU
+// restatement of the same algorithm (parity with OpenCV itself is unpinned -- see DESIGN.md).
 //
 // HBM traffic per step: the transposed features once (n x 3528 x 4 B) + O(n) vectors; the kernel is bound by the
 // dependent double-precision accumulation chains (882 links per row and instance), not by bandwidth.

@@ -30,6 +30,13 @@ timeout 300 python bench.py --config C3 > $OUT/${TAG}_bench_c3.json 2> /dev/null
 timeout 300 python bench.py --config C2 --normals rand50 --no-cpu-baseline > $OUT/${TAG}_bench_c2_rand50.json 2> /dev/null
 timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TAG}_bench_c4.json 2> /dev/null
 timeout 300 python scripts/preprocess_bench.py 2> /dev/null | grep raw_points > $OUT/${TAG}_preprocess.jsonl
+timeout 300 python scripts/handles_bench.py 2> /dev/null | grep '"hands"' > $OUT/${TAG}_handles.jsonl
+timeout 300 python scripts/pipeline_bench.py 2> /dev/null | tail -1 > $OUT/${TAG}_pipeline.json
+timeout 600 python scripts/train_bench.py 2> /dev/null | grep '"instances"' > $OUT/${TAG}_training.jsonl
+rm -rf /tmp/kt_train
+(cd /tmp && TRAIN_BENCH_CPU_N=300 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_train -o kt -- python $R/scripts/train_bench.py > /tmp/kt_train.log 2>&1)
+db=$(find /tmp/kt_train -name "*.db" | head -1)
+[ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_training_kernel_trace_stats.csv > /dev/null
 ls -la $OUT
 head -c 600 $OUT/${TAG}_bench_c2.json; echo
 head -8 $OUT/${TAG}_c2_kernel_trace_stats.csv

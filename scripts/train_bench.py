@@ -52,11 +52,34 @@ images = binding.unpack_images(packed[sub])
 t0 = time.perf_counter()
 feats = orc.hog_many(images)
 cpu_hog_s = time.perf_counter() - t0
+CPU_T = int(os.environ.get("TRAIN_BENCH_CPU_THREADS", "16"))
 t0 = time.perf_counter()
-ref = orc.train_svm(feats, labels[sub])
+ref = orc.train_svm(feats, labels[sub], num_threads=CPU_T)
 cpu_s = time.perf_counter() - t0
 gsub = ctx.train_svm(packed[sub], labels[sub])
 same = bool(gsub["rho"] == ref["rho"] and np.array_equal(gsub["w"], ref["w"]) and gsub["iterations"] == ref["iterations"])
+# the quadratic kernel (what Learning::train* asks convertData for by default): train, then classify one cloud with it
+t0 = time.perf_counter()
+poly = ctx.train_svm(packed, labels, kernel=binding.SVM_POLY2)
+poly_s = time.perf_counter() - t0
+ctx.load_svm_model(binding.SVM_POLY2, poly["sv"], poly["alpha"], poly["rho"])
+ctx.set_profile(1)
+for _ in range(3):
+    keep = ctx.classify()
+ctx.timing()
+for _ in range(10):
+    keep = ctx.classify()
+poly_cls_ms = ctx.timing().get("hog_svm", 0.0) / 10
+ctx.load_svm(got["w"], got["rho"])
+for _ in range(3):
+    ctx.classify()
+ctx.timing()
+for _ in range(10):
+    ctx.classify()
+lin_cls_ms = ctx.timing().get("hog_svm", 0.0) / 10
+rp = orc.train_svm(feats, labels[sub], kernel=1, num_threads=CPU_T)
+gp = ctx.train_svm(packed[sub], labels[sub], kernel=binding.SVM_POLY2)
+same_poly = bool(gp["rho"] == rp["rho"] and np.array_equal(gp["alpha"], rp["model"][2]) and np.array_equal(gp["sv"], rp["model"][1]))
 dec = desc.astype(np.float64) @ got["w"].astype(np.float64) - got["rho"]
 acc = float((np.where(dec > 0, -1, 1) == np.where(labels > 0, 1, -1)).mean())
 print(json.dumps({"clouds": K, "instances": n, "positives": int((labels > 0).sum()), "search_s_total": t_search,
@@ -64,6 +87,10 @@ print(json.dumps({"clouds": K, "instances": n, "positives": int((labels > 0).sum
                   "gpu_ms_per_solver_step": step_ms, "gpu_hog_s_host_to_host": hog_s,
                   "algorithmic_GB_per_step": n * 3528 * 4 / 1e9, "achieved_GBps_per_step": n * 3528 * 4 / 1e9 / (step_ms * 1e-3),
                   "training_set_accuracy": acc,
+                  "quadratic_kernel": {"gpu_train_s": poly_s, "support_vectors": int(len(poly["alpha"])),
+                                       "steps": poly["iterations"], "classify_last_cloud_ms": poly_cls_ms,
+                                       "hypotheses_classified": int(len(keep)), "bit_exact_vs_oracle_on_that_prefix": same_poly},
+                  "linear_classify_last_cloud_ms": lin_cls_ms,
                   "cpu_oracle": {"instances": int(sub.size), "hog_s_1_thread": cpu_hog_s, "train_s": cpu_s,
-                                 "threads": os.cpu_count(), "steps": ref["iterations"]},
+                                 "threads": CPU_T, "steps": ref["iterations"]},
                   "bit_exact_vs_oracle_on_that_prefix": same}))
