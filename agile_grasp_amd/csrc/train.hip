@@ -409,7 +409,18 @@ __global__ __launch_bounds__(64) void k_svm_decide(const float* __restrict__ kbu
     return;
   double sum = -rho;
   const float* row = kbuf + h * n_sv;
-  for (int v = 0; v < n_sv; v++)
+  int v = 0;
+  for (; v + 16 <= n_sv; v += 16)  // loads in flight, the chain in index order
+  {
+    float q[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      q[u] = row[v + u];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      sum += alpha[v + u] * q[u];
+  }
+  for (; v < n_sv; v++)
     sum += alpha[v] * row[v];
   const uint8_t k = (sum > 0) ? 0 : 1;  // class_labels[sum > 0 ? 0 : 1] = {-1, +1}; the reference keeps prediction == 1
   if (keep)
