@@ -464,3 +464,43 @@ def test_train_adapter_writes_the_model_the_c_abi_trains(tmp_path, mode, max_pos
     assert int(res[1]) == len(hyps) and int(res[2]) == int(keep.sum())
     okeep, _ = O.classify_model(binding.unpack_images(img_lists[-1][:, 0]), O.load_svm_model(model))
     assert np.array_equal(keep, okeep)
+
+
+# ---- examples/train_pcd.cpp: the train node without ROS ----
+def _build_train_example(tmp_path):
+    from agile_grasp_amd import build
+
+    build.build()
+    exe = str(tmp_path / "train_pcd")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "train_pcd.cpp"), "-o", exe, "-L" + libdir,
+                           "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_train_example_compiles(tmp_path):
+    exe = _build_train_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "No PCD filenames given!" in out.stdout
+
+
+@pytest.mark.gpu
+def test_train_example_trains_a_loadable_model(tmp_path):
+    from oracle import oracle_py as O
+
+    exe = _build_train_example(tmp_path)
+    d = str(tmp_path) + os.sep
+    with open(d + "workspace.txt", "w") as f:
+        for k in range(2):
+            xyz, size_left, ws, _cams = _raw_cloud(seed=11 + k)
+            _write_pcd(d + f"{k}l_reg.pcd", xyz[:size_left], True)
+            _write_pcd(d + f"{k}r_reg.pcd", xyz[size_left:], True)
+            f.write(" ".join(repr(float(v)) for v in ws) + " \n")
+    model = d + "trained.yaml"
+    out = subprocess.run([exe, "2", d, model, "0", "400"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Training the SVM ..." in out.stdout and "Saved trained SVM as " + model in out.stdout
+    kernel, sv, alpha, rho = O.load_svm_model(model)  # a CvSVM file of the quadratic-kernel shape
+    assert kernel == 1 and sv.shape[0] == alpha.shape[0] >= 2 and np.isfinite(rho)
+    assert (alpha > 0).any() and (alpha < 0).any() and np.all(np.abs(alpha) <= 1.0)
