@@ -248,3 +248,32 @@ def test_train_svm_argument_errors(tiny_scene):
         ctx.train_svm(im, np.ones(6))  # one class
     with pytest.raises(binding.AghError):
         ctx.training_images()  # nothing searched yet
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 257, 600])
+def test_solver_sizes_around_the_tile_boundaries(tiny_scene, n):
+    """Instance counts below, at and above the 64-instance tile and the 256-thread work-group, random images."""
+    from agile_grasp_amd import binding
+
+    ctx = binding.Context(tiny_scene.cam_origins)
+    rng = np.random.default_rng(n)
+    images = np.zeros((n, 80, 100), np.uint8)
+    for im in images:  # a few random strokes: descriptors with many exact zeros, like real grasp images
+        for _ in range(int(rng.integers(1, 6))):
+            r, c = int(rng.integers(0, 80)), int(rng.integers(0, 100))
+            im[r:r + int(rng.integers(1, 30)), c:c + int(rng.integers(1, 4))] = 255
+    packed = binding.pack_images(images.reshape(n, 8000))
+    labels = np.where(rng.random(n) < 0.4, 1, -1)
+    labels[0], labels[1] = 1, -1
+    feats = O.hog_many(images.reshape(n, 8000))
+    assert np.array_equal(ctx.hog_images(packed), feats)
+    for kernel in (binding.SVM_LINEAR, binding.SVM_POLY2):
+        for max_iter in (0, 1000):
+            got = ctx.train_svm(packed, labels, kernel=kernel, max_iter=max_iter)
+            ref = O.train_svm(feats, labels, kernel=kernel, max_iter=max_iter)
+            assert got["iterations"] == ref["iterations"] and got["n_sv"] == ref["n_sv"] and got["rho"] == ref["rho"]
+            if kernel == binding.SVM_LINEAR:
+                assert np.array_equal(got["w"], ref["w"])
+            else:
+                assert np.array_equal(got["sv"], ref["model"][1]) and np.array_equal(got["alpha"], ref["model"][2])
