@@ -7,9 +7,10 @@
  * (paths relative to /root/reference; "x.cpp" = src/agile_grasp/x.cpp, "x.h" = include/agile_grasp/x.h).
  *
  * PARITY UNPINNED at the third-party seams (the libraries are not in the reference tree and not in this
- * image): FLANN radius search, LAPACK dggev, Eigen::EigenSolver, OpenCV 2.4 HOGDescriptor / CvSVM.  The
- * interpretation used at each seam is stated where it is implemented; tests/golden pins the eigen seam
- * against scipy's LAPACK dggev.
+ * image): FLANN radius search, LAPACK dggev, Eigen::EigenSolver, OpenCV 2.4 HOGDescriptor / CvSVM (predict, and --
+ * training side -- train / save).  The interpretation used at each seam is stated where it is implemented;
+ * tests/golden pins the eigen seam against scipy's LAPACK dggev, and the model writer against the reference's
+ * shipped SVM file (byte for byte).
  *
  * Floating-point contract: compiled with -ffp-contract=off, no -ffast-math; every sum is written in the
  * order it is evaluated (left to right unless stated), so the HIP kernels can reproduce it bit for bit.
@@ -18,11 +19,11 @@
 
 #include <algorithm>
 #include <cfloat>
-#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <set>
