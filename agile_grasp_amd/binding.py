@@ -84,7 +84,7 @@ EXPORTS = [
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
-    "agh_load_svm_model",
+    "agh_load_svm_model", "agh_get_learning_points",
 ]
 
 
@@ -325,6 +325,18 @@ class Context:
         alpha = np.ascontiguousarray(alpha, np.float64)
         self._check(self.lib.agh_load_svm_model(self._h, C.c_int32(kernel), _p(sv, C.c_float), C.c_int32(sv.shape[0]),
                                                 C.c_int32(3528), _p(alpha, C.c_double), C.c_double(rho)))
+
+    def learning_points(self, hyp: int):
+        """(3, n_b) points_for_learning of hypothesis `hyp` and the camera id of each column."""
+        n = C.c_int64(0)
+        rc = self.lib.agh_get_learning_points(self._h, C.c_int64(hyp), None, None, C.c_int64(0), C.byref(n))
+        if rc not in (0, -4):  # AGH_ERR_CAPACITY reports the size
+            self._check(rc)
+        pts = np.zeros((max(n.value, 1), 3), np.float64)
+        cam = np.zeros(max(n.value, 1), np.int32)
+        self._check(self.lib.agh_get_learning_points(self._h, C.c_int64(hyp), _p(pts, C.c_double), _p(cam, C.c_int32),
+                                                     C.c_int64(n.value), C.byref(n)))
+        return pts[: n.value].T.copy(), cam[: n.value].copy()
 
     def load_svm(self, w: np.ndarray, rho: float):
         w = np.ascontiguousarray(w, np.float32)

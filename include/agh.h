@@ -217,6 +217,12 @@ int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, i
 int agh_get_images(agh_ctx* ctx, uint8_t* images, int64_t cap_hyp); /* cap_hyp x 8000 bytes, 80 rows x 100 cols */
 int agh_get_hog(agh_ctx* ctx, float* desc, double* sums, int64_t cap_hyp); /* cap_hyp x 3528 floats (+ SVM sums) */
 int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points);  /* cloud_normals_ (3 doubles per point) */
+/* GraspHypothesis::getPointsForLearning and the split of its columns by camera (grasp_hypothesis.h:149-170; filled at
+ * rotating_hand.cpp:125-157), recomputed on demand for hypothesis `hyp` of the last agh_find_hands* call: `points`
+ * receives the 3 x n_b matrix column by column (Eigen's Matrix3Xd layout) in the reference's column order, cam_source[k]
+ * the camera id of column k (indices_cam1 = the k with 0, indices_cam2 = the k with 1).  *n_out = n_b in any case;
+ * AGH_ERR_CAPACITY if n_b > cap.  A lazy getter (one pass over the cloud per call), not part of the hot path. */
+int agh_get_learning_points(agh_ctx* ctx, int64_t hyp, double* points, int32_t* cam_source, int64_t cap, int64_t* n_out);
 int agh_get_timing(agh_ctx* ctx, agh_timing* out);
 /* Change agh_params::profile of a live context (0, 1 or 2); pending timings are dropped. */
 int agh_set_profile(agh_ctx* ctx, int32_t level);

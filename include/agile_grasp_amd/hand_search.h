@@ -70,6 +70,38 @@ public:
     dirty_ = true;
   }
   agh_ctx* context() { return ctx_; }
+  /** GraspHypothesis::getPointsForLearning / getIndicesPointsForLearningCam1 / ...Cam2 (grasp_hypothesis.h:149-170) for
+   *  a hypothesis of the most recent findHands of this search, recomputed on the GPU on demand (the hot path keeps only
+   *  the rasterised image).  Returns false (after printing why) on error. */
+  bool getPointsForLearning(const GraspHypothesis& h, Matrix3Xd& points_for_learning, std::vector<int>& indices_cam1,
+    std::vector<int>& indices_cam2)
+  {
+    indices_cam1.clear();
+    indices_cam2.clear();
+    resize_3xn(points_for_learning, 0);
+    if (!ctx_ || h.getDeviceIndex() < 0)
+    {
+      std::cout << " Error: the hypothesis does not come from this search\n";
+      return false;
+    }
+    const std::size_t n_b = (std::size_t) h.getNumPointsForLearning();
+    std::vector<std::int32_t> cam(n_b + 1);
+    std::int64_t n = 0;
+    double* dst = resize_3xn(points_for_learning, n_b);
+    std::vector<double> dummy(3);
+    if (agh_get_learning_points(ctx_, h.getDeviceIndex(), n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
+    {
+      std::cout << " Error in agh_get_learning_points: " << agh_last_error(ctx_) << "\n";
+      resize_3xn(points_for_learning, 0);
+      return false;
+    }
+    for (std::size_t k = 0; k < n_b; k++)  // rotating_hand.cpp:143-151
+      if (cam[k] == 0)
+        indices_cam1.push_back((int) k);
+      else if (cam[k] == 1)
+        indices_cam2.push_back((int) k);
+    return true;
+  }
   /** Training runs (src/nodes/train.cpp): every findHands(calculates_antipodal = true) also attaches the three
    *  instance images to its hypotheses (GraspHypothesis::getTrainingImage), the input of Learning::train*. */
   void setKeepsTrainingImages(bool b) { keeps_training_images_ = b; }

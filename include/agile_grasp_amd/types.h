@@ -35,6 +35,11 @@ typedef Eigen::VectorXd VectorXd;
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
 inline bool cloud_is_dense(const PointCloud& c) { return c.is_dense; }
+inline double* resize_3xn(Matrix3Xd& m, std::size_t n)  // column-major storage of a 3 x n matrix
+{
+  m.resize(3, (Eigen::Index) n);
+  return m.data();
+}
 inline int loadPCDFile(const std::string& f, PointCloud& c) { return pcl::io::loadPCDFile<pcl::PointXYZRGBA>(f, c); }
 }  // namespace agile_grasp_amd
 
@@ -82,6 +87,11 @@ struct Matrix3Xd  // 3 x n, column-major like Eigen
   double operator()(int r, std::size_t c) const { return d[3 * c + r]; }
   std::size_t cols() const { return d.size() / 3; }
 };
+inline double* resize_3xn(Matrix3Xd& m, std::size_t n)
+{
+  m.d.assign(3 * n, 0.0);
+  return m.d.data();
+}
 struct PointXYZRGBA  // pcl::PointXYZRGBA: 32 bytes, xyz at offset 0
 {
   float x, y, z, pad0;

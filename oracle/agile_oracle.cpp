@@ -953,6 +953,8 @@ struct HandOut
   orc_hypothesis h;
   std::vector<uint8_t> image;
   std::vector<uint8_t> image_cam[2]; /* createInstance(h, cam_pos, cam = 0 / 1): only that camera's points */
+  std::vector<double> pts;           /* points_for_learning, 3 x n_b column-major (rotating_hand.cpp:132-139) */
+  std::vector<int32_t> pts_cam;      /* camera id per column (indices_cam1 / indices_cam2, 143-151) */
 };
 
 void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>& nb, const orc_frame& F,
@@ -974,7 +976,7 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
     fr[r][2] = F.axis[r];
   }
   /* points_ = frame^T * centered (26), normals_ likewise (33); crop |z| < hand_height (37-51) */
-  std::vector<double> X, Y, NX, NY;
+  std::vector<double> X, Y, Z, NX, NY;
   std::vector<int> CAMS;
   X.reserve(n);
   Y.reserve(n);
@@ -991,6 +993,7 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
     {
       X.push_back(tx);
       Y.push_back(ty);
+      Z.push_back(tz);
       CAMS.push_back(cl.cam[nb[j].idx]);
       if (normals)
       {
@@ -1054,6 +1057,8 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
       const double box_y = finger_hand.back_of_hand + finger_hand.depth; /* rotating_hand.cpp:127 */
       std::vector<double> bx, by;
       std::vector<double> bxc[2], byc[2]; /* indices_cam1 / indices_cam2 (rotating_hand.cpp:143-151) */
+      std::vector<double> pts3;
+      std::vector<int32_t> pts_cam;
       int numl = 0, numr = 0, nbox = 0;
       const double cos_thresh = std::cos(20 * M_PI / 180.0); /* antipodal.cpp:16 */
       for (int j = 0; j < nc; j++)
@@ -1062,7 +1067,14 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
           nbox++;
           bx.push_back(XR[j] - surface[0]); /* rotating_hand.cpp:138 (world-frame offset, replicated as-is) */
           by.push_back(YR[j] - surface[1]);
-          if (want_images > 1 && (CAMS[j] == 0 || CAMS[j] == 1))
+          if (want_images == 3) /* the whole column: rot leaves z alone, and surface is subtracted as a 3-vector */
+          {
+            pts3.push_back(bx.back());
+            pts3.push_back(by.back());
+            pts3.push_back(Z[j] - surface[2]);
+            pts_cam.push_back(CAMS[j]);
+          }
+          if (want_images == 2 && (CAMS[j] == 0 || CAMS[j] == 1))
           {
             bxc[CAMS[j]].push_back(bx.back());
             byc[CAMS[j]].push_back(by.back());
@@ -1107,7 +1119,9 @@ void hands_for_sample(const orc_params& P, const Cloud& cl, const std::vector<Ne
           s2c[r] = ho.h.surface[r] - P.cam_origin[cs_i][r];
         ho.image.resize(8000);
         make_image(bx, by, dot3(binormal, s2c) > 0, ho.image.data());
-        for (int c = 0; c < 2 && want_images > 1; c++) /* same source_to_center, the camera's subset of pts */
+        ho.pts = std::move(pts3);
+        ho.pts_cam = std::move(pts_cam);
+        for (int c = 0; c < 2 && want_images == 2; c++) /* same source_to_center, the camera's subset of pts */
         {
           ho.image_cam[c].resize(8000);
           make_image(bxc[c], byc[c], dot3(binormal, s2c) > 0, ho.image_cam[c].data());
@@ -1444,7 +1458,8 @@ void fit_frames_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid
 
 int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, const int32_t* sample_idx, int64_t S,
   const orc_frame* frames, const double* normals, orc_hypothesis* out, int64_t cap, int64_t* n_out, int32_t* nh_out,
-  uint8_t* images_out, uint8_t* cam_images_out = nullptr)
+  uint8_t* images_out, uint8_t* cam_images_out = nullptr, std::vector<double>* pts_out = nullptr,
+  std::vector<int32_t>* pts_cam_out = nullptr, std::vector<int64_t>* pts_ofs_out = nullptr)
 {
   std::vector<std::vector<HandOut>> lists(S);
 #pragma omp parallel for num_threads(P.num_threads) schedule(static)
@@ -1457,7 +1472,7 @@ int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, cons
       nh_out[i] = (int32_t) nb.size();
     /* hands_cam_source(i) = pts_cam_source(indices[i]) (hand_search.cpp:40-42; defined so for explicit indices) */
     hands_for_sample(P, cl, nb, frames[i], normals, (int) i, cl.cam[sample_idx[i]],
-      cam_images_out ? 2 : (images_out != nullptr ? 1 : 0), lists[i]);
+      pts_out ? 3 : (cam_images_out ? 2 : (images_out != nullptr ? 1 : 0)), lists[i]);
   }
   int64_t k = 0;
   for (int64_t i = 0; i < S; i++) /* concatenation, hand_search.cpp:194-200 */
@@ -1470,6 +1485,12 @@ int hands_impl(const orc_params& P, const Cloud& cl, const GridIndex& grid, cons
           std::memcpy(images_out + k * 8000, lists[i][j].image.data(), 8000);
         for (int c = 0; c < 2 && cam_images_out; c++)
           std::memcpy(cam_images_out + (k * 2 + c) * 8000, lists[i][j].image_cam[c].data(), 8000);
+        if (pts_out)
+        {
+          pts_ofs_out->push_back((int64_t) pts_cam_out->size());
+          pts_out->insert(pts_out->end(), lists[i][j].pts.begin(), lists[i][j].pts.end());
+          pts_cam_out->insert(pts_cam_out->end(), lists[i][j].pts_cam.begin(), lists[i][j].pts_cam.end());
+        }
       }
       k++;
     }
@@ -1553,6 +1574,37 @@ int orc_find_hands(const orc_params* p, const float* xyz, int64_t stride_floats,
 {
   return find_hands_full(p, xyz, stride_floats, cam, n, sample_idx, n_samples, calculates_antipodal, out, cap, n_out,
     frames_out, nh_out, images_out, nullptr);
+}
+
+/* a14: the variable part of GraspHypothesis -- points_for_learning and the camera id of each column -- for every
+ * hypothesis of a (non-antipodal) search.  ofs_out[k] .. ofs_out[k+1] are hypothesis k's columns in pts_out (3 doubles
+ * each) / cam_out.  Returns the total number of columns (may exceed pts_cap: then nothing is copied). */
+int64_t orc_find_hands_points(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, orc_hypothesis* out, int64_t cap, int64_t* n_out, double* pts_out,
+  int32_t* cam_out, int64_t pts_cap, int64_t* ofs_out)
+{
+  Cloud cl{ xyz, stride_floats, cam, n };
+  GridIndex g_t, g_h;
+  g_t.build(cl, p->nn_radius_taubin);
+  g_h.build(cl, p->nn_radius_hands);
+  GlibcRand rng(p->rand_seed);
+  std::vector<orc_frame> frames(n_samples);
+  fit_frames_impl(*p, cl, g_t, p->nn_radius_taubin, sample_idx, n_samples, frames.data(), &rng);
+  std::vector<double> pts;
+  std::vector<int32_t> pc;
+  std::vector<int64_t> ofs;
+  std::vector<uint8_t> images((size_t) cap * 8000);
+  if (hands_impl(*p, cl, g_h, sample_idx, n_samples, frames.data(), nullptr, out, cap, n_out, nullptr, images.data(), nullptr,
+        &pts, &pc, &ofs) != 0)
+    return -2;
+  ofs.push_back((int64_t) pc.size());
+  std::memcpy(ofs_out, ofs.data(), sizeof(int64_t) * ofs.size());
+  if ((int64_t) pc.size() <= pts_cap)
+  {
+    std::memcpy(pts_out, pts.data(), sizeof(double) * pts.size());
+    std::memcpy(cam_out, pc.data(), sizeof(int32_t) * pc.size());
+  }
+  return (int64_t) pc.size();
 }
 
 int orc_find_hands_training(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,

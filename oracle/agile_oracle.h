@@ -142,6 +142,12 @@ int64_t orc_find_handles(const orc_hypothesis* hands, int64_t n_hands, int32_t m
 int64_t orc_preprocess(const float* xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
   const double workspace[6], double cell_size, float* xyz_out, int32_t* cam_out, int64_t cap);
 
+/* a14: points_for_learning + the camera id of each column for every hypothesis of a (non-antipodal) search
+ * (rotating_hand.cpp:125-151); ofs_out has n_out + 1 entries.  Returns the total column count. */
+int64_t orc_find_hands_points(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,
+  const int32_t* sample_idx, int64_t n_samples, orc_hypothesis* out, int64_t cap, int64_t* n_out, double* pts_out,
+  int32_t* cam_out, int64_t pts_cap, int64_t* ofs_out);
+
 /* f4 (training side): orc_find_hands(calculates_antipodal = 1) that also returns, per hypothesis, the images of
  * createInstance(h, cam_pos, cam = 0) and (cam = 1) (learning.cpp:389-397): cam_images_out is cap x 2 x 8000 bytes. */
 int orc_find_hands_training(const orc_params* p, const float* xyz, int64_t stride_floats, const int32_t* cam, int64_t n,

@@ -265,6 +265,32 @@ def find_handles(hands: np.ndarray, min_inliers: int = 3, min_length: float = 0.
     return out, idx[:total].copy()
 
 
+def find_hands_points(p: OrcParams, xyz, cam, samples):
+    """Hypotheses plus, per hypothesis, points_for_learning (3, n_b) and the camera id of each column."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    cam = np.ascontiguousarray(cam, np.int32)
+    samples = np.ascontiguousarray(samples, np.int32)
+    S = samples.shape[0]
+    cap = 8 * S
+    out = np.zeros(cap, HYP_DTYPE)
+    ofs = np.zeros(cap + 1, np.int64)
+    n_out = C.c_int64(0)
+    f = lib().orc_find_hands_points
+    f.restype = C.c_int64
+    args = lambda pts, pc, pcap: (C.byref(p), _fp(xyz, C.c_float), C.c_int64(3), _fp(cam, C.c_int32), C.c_int64(xyz.shape[0]),
+                                  _fp(samples, C.c_int32), C.c_int64(S), out.ctypes.data_as(C.c_void_p), C.c_int64(cap),
+                                  C.byref(n_out), _fp(pts, C.c_double), _fp(pc, C.c_int32), C.c_int64(pcap),
+                                  _fp(ofs, C.c_int64))
+    total = f(*args(np.zeros(3), np.zeros(1, np.int32), 0))
+    assert total >= 0, total
+    pts = np.zeros((max(total, 1), 3), np.float64)
+    pc = np.zeros(max(total, 1), np.int32)
+    assert f(*args(pts, pc, total)) == total
+    n = n_out.value
+    return {"hyps": out[:n].copy(), "points": [pts[ofs[k]:ofs[k + 1]].T.copy() for k in range(n)],
+            "cams": [pc[ofs[k]:ofs[k + 1]].copy() for k in range(n)]}
+
+
 # ---- f4: the training side (learning.cpp:3-163, 249-318) -----------------------------------------------------
 def find_hands_training(p: OrcParams, xyz, cam, samples):
     """find_hands(calculates_antipodal=True) plus, per hypothesis, the images of the three training instances

@@ -63,5 +63,20 @@ int main(int argc, char** argv)
   }
   for (size_t i = 0; i < antipodal.size(); i++)
     std::printf("A %ld\n", antipodal[i].getDeviceIndex());
+  // the variable part of the first and the last hypothesis, fetched on demand (grasp_hypothesis.h:149-170)
+  for (size_t pick = 0; pick < 2 && !hands.empty(); pick++)
+  {
+    const GraspHypothesis& h = pick == 0 ? hands.front() : hands.back();
+    Matrix3Xd pts;
+    std::vector<int> cam1, cam2;
+    if (!hand_search.getPointsForLearning(h, pts, cam1, cam2))
+      return 3;
+    double sum[3] = { 0, 0, 0 };
+    for (size_t k = 0; k < pts.cols(); k++)
+      for (int r = 0; r < 3; r++)
+        sum[r] += pts(r, k);
+    std::printf("P %ld %zu %zu %zu %.17g %.17g %.17g\n", h.getDeviceIndex(), (size_t) pts.cols(), cam1.size(), cam2.size(),
+      sum[0], sum[1], sum[2]);
+  }
   return 0;
 }

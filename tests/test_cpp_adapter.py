@@ -79,6 +79,16 @@ def test_adapter_matches_c_abi(tmp_path, tiny_scene, svm_model, deterministic):
         assert int(row[7]) == h["cam_source"] and int(row[8]) == h["n_in_box"]
     kept_idx = [int(l.split()[1]) for l in lines if l.startswith("A ")]
     assert kept_idx == list(np.nonzero(keep)[0])
+    pl = [l.split()[1:] for l in lines if l.startswith("P ")]
+    assert [int(r[0]) for r in pl] == [0, len(hyps) - 1]
+    for r in pl:  # getPointsForLearning + the two index lists, fetched on demand
+        pts, cam = ctx.learning_points(int(r[0]))
+        assert int(r[1]) == pts.shape[1] and int(r[2]) == int((cam == 0).sum()) and int(r[3]) == int((cam == 1).sum())
+        sums = [0.0, 0.0, 0.0]
+        for k in range(pts.shape[1]):
+            for q in range(3):
+                sums[q] += float(pts[q, k])
+        assert [float(v) for v in r[4:7]] == sums
 
 
 # ---- Localization facade: host-side preprocessing restated from localization.cpp:25-45, 216-355 ----

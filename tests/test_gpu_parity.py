@@ -388,3 +388,32 @@ def test_large_sample_list_matches_small_one(tiny_scene):
         for r, q in zip(rows, ref):
             for f in FLOAT_FIELDS + ("orientation", "cam_source", "n_in_box", "finger_index", "depth_index"):
                 assert np.array_equal(r[f], q[f]), (p, f)
+
+
+def test_points_for_learning_on_demand(tiny_scene):
+    """GraspHypothesis::getPointsForLearning + the camera index lists, recomputed per hypothesis (agh_get_learning_points)."""
+    from agile_grasp_amd import binding
+    from oracle import oracle_py as O
+
+    sc = tiny_scene
+    ctx = _ctx(sc)
+    with pytest.raises(binding.AghError):
+        ctx.learning_points(0)  # nothing searched yet
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ref = O.find_hands_points(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples)
+    assert_hyps_equal(hyps, ref["hyps"])
+    for k in range(len(hyps)):
+        pts, cam = ctx.learning_points(k)
+        assert pts.shape == (3, hyps["n_in_box"][k])
+        assert np.array_equal(pts, ref["points"][k]) and np.array_equal(cam, ref["cams"][k])
+    with pytest.raises(binding.AghError):
+        ctx.learning_points(len(hyps))
+    # the image Learning::convertToImage draws from these points is the one the sweep rasterised
+    from tests import ref_numpy as R
+
+    images = ctx.images()
+    for k in (0, len(hyps) // 2, len(hyps) - 1):
+        pts, _ = ctx.learning_points(k)
+        s2c = hyps["surface"][k] - sc.cam_origins[hyps["cam_source"][k]]
+        assert np.array_equal(R.convert_to_image(pts, hyps["binormal"][k], s2c).reshape(-1), images[k])

@@ -247,3 +247,23 @@ def test_classify_oracle_on_real_hypotheses(tiny_scene, svm_model):
             acc += float(np.float32(np.float32(np.float32(q[0] + q[1]) + q[2]) + q[3]))
         assert float(np.float32(acc)) - rho == pytest.approx(s, abs=1e-12)
         assert k == (0 if s > 0 else 1)
+
+
+def test_points_for_learning_match_numpy_transcription(tiny_scene):
+    """a14: the variable part of GraspHypothesis (rotating_hand.cpp:125-151) -- all three rows and the camera split."""
+    sc = tiny_scene
+    p = O.default_params(sc.cam_origins)
+    res = O.find_hands_points(p, sc.xyz, sc.cam, sc.samples)
+    fr = O.find_hands(p, sc.xyz, sc.cam, sc.samples)["frames"]
+    hyps = res["hyps"]
+    checked = 0
+    for si in range(0, sc.samples.size, 2):
+        pts, cam_ids, frame = _transcription_inputs(sc, p, fr, si)
+        sample = fr["sample"][si]
+        cams = (sc.cam_origins - sample[None, :]).T
+        for g in R.evaluate_hand(pts, np.zeros_like(pts), cam_ids, frame, cams, (0.01, 0.09, 0.06), 0.01, sample):
+            k = np.nonzero((hyps["sample"] == si) & (hyps["orientation"] == g["orientation"]))[0][0]
+            assert np.array_equal(res["points"][k], g["points_in_box"])
+            assert np.array_equal(res["cams"][k], g["cam_in_box"])
+            checked += 1
+    assert checked > 10
