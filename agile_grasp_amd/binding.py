@@ -311,14 +311,14 @@ class Context:
         alpha = np.zeros(cap, np.float64)
         n_sv = C.c_int32(0)
         rho = C.c_double(0)
-        info = np.zeros(4, np.int32)
+        info = np.zeros(6, np.int32)
         self._check(self.lib.agh_train_svm(self._h, _p(packed, C.c_uint32), _p(lab, C.c_int8), C.c_int64(n), C.c_int32(kernel),
                                            C.c_double(C_), C.c_int32(max_iter), C.c_double(eps), _p(sv, C.c_float),
                                            C.c_int64(cap), _p(alpha, C.c_double), C.byref(n_sv), C.byref(rho),
                                            _p(info, C.c_int32)))
         return {"w": sv[0].copy(), "sv": sv[: n_sv.value].copy(), "alpha": alpha[: n_sv.value].copy(), "rho": rho.value,
                 "kernel": kernel, "iterations": int(info[0]), "n_sv": int(info[1]), "n_neg": int(info[2]),
-                "n_pos": int(info[3])}
+                "n_pos": int(info[3]), "rows_computed": int(info[4]), "rows_reused": int(info[5])}
 
     def load_svm_model(self, kernel: int, sv: np.ndarray, alpha: np.ndarray, rho: float):
         sv = np.ascontiguousarray(sv, np.float32).reshape(-1, 3528)

@@ -41,6 +41,20 @@ struct SvmState
   int iter;
   double d_i, d_j;
   double gap;  // Gmax1 + Gmax2 of the last selection
+  // kernel-row cache (what CvSVMSolver's row cache does: the values are the same floats, cached or recomputed)
+  int slot_i, slot_j;  // where rows Q_i, Q_j live
+  int need_i, need_j;  // 1: the step's update kernel computes the row and stores it; 0: it reads it
+  int next_slot;       // round-robin victim
+  int rows_computed, rows_reused;
+};
+
+struct SvmCache
+{
+  float* rows;       // n_slots x pitch
+  int* slot_of_row;  // n, -1 = not cached
+  int* row_of_slot;  // n_slots, -1 = free
+  int n_slots;
+  int64_t pitch;
 };
 
 // X (n x kDesc, row-major) -> XT, tiles of 64 instances: XT[(t / 64) * kDesc * 64 + k * 64 + t % 64].  A wavefront's
@@ -90,6 +104,10 @@ __global__ __launch_bounds__(256) void k_svm_init(const float* __restrict__ XT, 
     st->iter = 0;
     st->d_i = st->d_j = 0.0;
     st->gap = 0.0;
+    st->slot_i = st->slot_j = -1;
+    st->need_i = st->need_j = 0;
+    st->next_slot = 0;
+    st->rows_computed = st->rows_reused = 0;
   }
   if (t >= n)
     return;
@@ -131,10 +149,11 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a)
 // CvSVMSolver::select_working_set + the two-variable update of solve_generic.  y[k] = +1 for class 0 (label -1).
 __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X, int n, const int8_t* __restrict__ y,
   double* __restrict__ alpha, int8_t* __restrict__ status, const double* __restrict__ G, const float* __restrict__ Kdiag,
-  SvmState* __restrict__ st, double C, double eps, int max_iter, int poly)
+  SvmState* __restrict__ st, double C, double eps, int max_iter, int poly, SvmCache cache)
 {
   __shared__ ArgMax red1[16], red2[16];
   __shared__ int sel[2];
+  __shared__ int had[2];  // the rows' cache slots before this step (-1: not cached)
   __shared__ float grp[kGroups];
   if (st->stop)
     return;
@@ -187,6 +206,36 @@ __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X
       st->stop = 1;
     sel[0] = stop ? -1 : m1.idx;
     sel[1] = stop ? -1 : m2.idx;
+    if (!stop && m1.idx >= 0 && m2.idx >= 0)
+    {
+      // cache bookkeeping: a missing row gets the round-robin victim slot (never the partner's slot)
+      const int ri = m1.idx, rj = m2.idx;
+      int si = cache.slot_of_row[ri], sj = cache.slot_of_row[rj];
+      had[0] = si;
+      had[1] = sj;
+      auto alloc = [&](int row, int avoid) {
+        int v = st->next_slot;
+        if (v == avoid)
+          v = (v + 1) % cache.n_slots;
+        st->next_slot = (v + 1) % cache.n_slots;
+        const int old = cache.row_of_slot[v];
+        if (old >= 0)
+          cache.slot_of_row[old] = -1;
+        cache.row_of_slot[v] = row;
+        cache.slot_of_row[row] = v;
+        return v;
+      };
+      st->need_i = si < 0 ? 1 : 0;
+      st->need_j = sj < 0 ? 1 : 0;
+      if (si < 0)
+        si = alloc(ri, sj);
+      if (sj < 0)
+        sj = alloc(rj, si);
+      st->slot_i = si;
+      st->slot_j = sj;
+      st->rows_computed += st->need_i + st->need_j;
+      st->rows_reused += 2 - st->need_i - st->need_j;
+    }
   }
   __syncthreads();
   const int i = sel[0], j = sel[1];
@@ -196,10 +245,11 @@ __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X
       st->stop = 1;
     return;
   }
-  // K(i, j), calc_non_rbf_base order: 882 float group sums, then one double chain
+  const bool kij_cached = had[0] >= 0 || had[1] >= 0;  // Q_i[j] == Q_j[i] bit for bit (the float products commute)
+  // K(i, j), calc_non_rbf_base order: 882 float group sums, then one double chain -- unless one of the rows is cached
   const float* xi = X + (int64_t) i * kDesc;
   const float* xj = X + (int64_t) j * kDesc;
-  if (tid < kGroups)
+  if (!kij_cached && tid < kGroups)
   {
     const float4 a = reinterpret_cast<const float4*>(xj)[tid];  // sample = vecs[j], another = x_i
     const float4 b = reinterpret_cast<const float4*>(xi)[tid];
@@ -208,21 +258,29 @@ __global__ __launch_bounds__(1024) void k_svm_select(const float* __restrict__ X
   __syncthreads();
   if (tid != 0)
     return;
-  double s = 0;
-  for (int g0 = 0; g0 < kGroups; g0 += 14)  // 882 = 63 x 14
-  {
-    float v[14];
-#pragma unroll
-    for (int u = 0; u < 14; u++)
-      v[u] = grp[g0 + u];
-#pragma unroll
-    for (int u = 0; u < 14; u++)
-      s += v[u];
-  }
-  const float kij = qfloat(s, poly);
   const int yi = y[i], yj = y[j];
-  const float Qii = Kdiag[i], Qjj = Kdiag[j];               // get_row_svc: y_i * y_i = 1
-  const float Qij = yi > 0 ? yj * kij : -yj * kij;          // row_i[j]
+  float Qij;  // row_i[j]
+  if (had[0] >= 0)
+    Qij = cache.rows[(int64_t) had[0] * cache.pitch + j];
+  else if (had[1] >= 0)
+    Qij = cache.rows[(int64_t) had[1] * cache.pitch + i];
+  else
+  {
+    double s = 0;
+    for (int g0 = 0; g0 < kGroups; g0 += 14)  // 882 = 63 x 14
+    {
+      float v[14];
+#pragma unroll
+      for (int u = 0; u < 14; u++)
+        v[u] = grp[g0 + u];
+#pragma unroll
+      for (int u = 0; u < 14; u++)
+        s += v[u];
+    }
+    const float kij = qfloat(s, poly);
+    Qij = yi > 0 ? yj * kij : -yj * kij;
+  }
+  const float Qii = Kdiag[i], Qjj = Kdiag[j];  // get_row_svc: y_i * y_i = 1
   const double C_i = C, C_j = C;
   double alpha_i = alpha[i], alpha_j = alpha[j];
   const double old_i = alpha_i, old_j = alpha_j;
@@ -353,25 +411,42 @@ __device__ __forceinline__ const float* wave_tile(const float* XT, unsigned firs
 }
 
 __global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X, const float* __restrict__ XT, int n,
-  const int8_t* __restrict__ y, double* __restrict__ G, const SvmState* __restrict__ st, int poly)
+  const int8_t* __restrict__ y, double* __restrict__ G, const SvmState* __restrict__ st, int poly, SvmCache cache)
 {
   __shared__ __attribute__((aligned(16))) float2 xij[kDesc];
   if (st->stop)
     return;
   const int i = st->i, j = st->j;
   const double d_i = st->d_i, d_j = st->d_j;
-  for (int k = threadIdx.x; k < kDesc; k += 256)
-    xij[k] = make_float2(X[(int64_t) i * kDesc + k], X[(int64_t) j * kDesc + k]);
-  __syncthreads();
   const int t = blockIdx.x * 256 + threadIdx.x;
-  double si = 0, sj = 0;
-  dual_dot<3>(wave_tile(XT, blockIdx.x * 256u + (threadIdx.x & ~63u), n), (threadIdx.x & 63u) * 4u, xij, si, sj);
-  if (t >= n)
-    return;
-  const float ki = qfloat(si, poly), kj = qfloat(sj, poly);
-  const int yt = y[t];
-  const float Qi = y[i] > 0 ? yt * ki : -yt * ki;  // get_row_svc
-  const float Qj = y[j] > 0 ? yt * kj : -yt * kj;
+  float* row_i = cache.rows + (int64_t) st->slot_i * cache.pitch;
+  float* row_j = cache.rows + (int64_t) st->slot_j * cache.pitch;
+  float Qi, Qj;
+  if (st->need_i || st->need_j)  // (uniform) at least one row is new: both come out of one pass over the features
+  {
+    for (int k = threadIdx.x; k < kDesc; k += 256)
+      xij[k] = make_float2(X[(int64_t) i * kDesc + k], X[(int64_t) j * kDesc + k]);
+    __syncthreads();
+    double si = 0, sj = 0;
+    dual_dot<3>(wave_tile(XT, blockIdx.x * 256u + (threadIdx.x & ~63u), n), (threadIdx.x & 63u) * 4u, xij, si, sj);
+    if (t >= n)
+      return;
+    const float ki = qfloat(si, poly), kj = qfloat(sj, poly);
+    const int yt = y[t];
+    Qi = y[i] > 0 ? yt * ki : -yt * ki;  // get_row_svc
+    Qj = y[j] > 0 ? yt * kj : -yt * kj;
+    if (st->need_i)
+      row_i[t] = Qi;
+    if (st->need_j)
+      row_j[t] = Qj;
+  }
+  else
+  {
+    if (t >= n)
+      return;
+    Qi = row_i[t];
+    Qj = row_j[t];
+  }
   G[t] = G[t] + (Qi * d_i + Qj * d_j);
 }
 
@@ -466,6 +541,7 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
 {
   int32_t* d_rows = nullptr;
   float* d_svrows = nullptr;
+  SvmCache cache{ nullptr, nullptr, nullptr, 0, 0 };
   uint32_t* d_img = nullptr;
   int32_t* d_ord = nullptr;
   int8_t *d_y = nullptr, *d_status = nullptr;
@@ -496,6 +572,12 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
   TRY(hipMalloc((void**) &d_G, (size_t) n * 8));
   TRY(hipMalloc((void**) &d_as, (size_t) n * 8));
   TRY(hipMalloc((void**) &d_st, sizeof(SvmState)));
+  // kernel-row cache: every row if that fits 16 GiB, else as many as do (at least the step's two)
+  cache.pitch = (n + 63) / 64 * 64;
+  cache.n_slots = (int) std::max<int64_t>(2, std::min<int64_t>(n, ((int64_t) 16 << 30) / (cache.pitch * 4)));
+  TRY(hipMalloc((void**) &cache.rows, (size_t) cache.n_slots * cache.pitch * 4));
+  TRY(hipMalloc((void**) &cache.slot_of_row, (size_t) n * 4));
+  TRY(hipMalloc((void**) &cache.row_of_slot, (size_t) cache.n_slots * 4));
   std::vector<double> alpha((size_t) n), G((size_t) n), a_signed((size_t) n);
   std::vector<int8_t> status((size_t) n);
   SvmState hs;
@@ -505,6 +587,8 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
     TRY(hipMemcpyAsync(d_img, h_images, (size_t) n_images * kImageWords * 4, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_ord, h_order, (size_t) n * 4, hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(d_y, h_y, (size_t) n, hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(cache.slot_of_row, 0xff, (size_t) n * 4, st));
+    TRY(hipMemsetAsync(cache.row_of_slot, 0xff, (size_t) cache.n_slots * 4, st));
     if (rc == AGH_OK)
       rc = hog_images(c, d_img, d_ord, n, d_X, st);
     const int ni = (int) n;
@@ -517,8 +601,9 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
       for (int b = 0; b < batch; b++)
       {
         hipLaunchKernelGGL(k_svm_select, dim3(1), dim3(1024), 0, st, d_X, ni, d_y, d_alpha, d_status, d_G, d_diag, d_st, C,
-          eps, max_iter, poly);
-        hipLaunchKernelGGL(k_svm_update, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_X, d_XT, ni, d_y, d_G, d_st, poly);
+          eps, max_iter, poly, cache);
+        hipLaunchKernelGGL(k_svm_update, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, d_X, d_XT, ni, d_y, d_G, d_st, poly,
+          cache);
       }
       TRY(hipMemcpyAsync(&hs, d_st, sizeof(hs), hipMemcpyDeviceToHost, st));
       TRY(hipStreamSynchronize(st));
@@ -573,6 +658,8 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
     {
       info_out[0] = hs.iter;
       info_out[1] = n_sv;
+      info_out[2] = hs.rows_computed;
+      info_out[3] = hs.rows_reused;
     }
     if (!poly)
     {
@@ -614,7 +701,8 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
   }
 #undef TRY
   for (void* p : { (void*) d_img, (void*) d_ord, (void*) d_y, (void*) d_status, (void*) d_X, (void*) d_XT, (void*) d_diag,
-         (void*) d_w, (void*) d_alpha, (void*) d_G, (void*) d_as, (void*) d_st, (void*) d_rows, (void*) d_svrows })
+         (void*) d_w, (void*) d_alpha, (void*) d_G, (void*) d_as, (void*) d_st, (void*) d_rows, (void*) d_svrows, (void*) cache.rows, (void*) cache.slot_of_row,
+         (void*) cache.row_of_slot })
     if (p)
       (void) hipFree(p);
   return rc;
@@ -817,7 +905,7 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
     y[(size_t) k] = k < n0 ? 1 : -1;
   if (hipSetDevice(c->device) != hipSuccess)
     return AGH_ERR_HIP;
-  int32_t info[2] = { 0, 0 };
+  int32_t info[4] = { 0, 0, 0, 0 };
   const int rc = svm_train(c, images, n, order.data(), y.data(), n, kernel_type == AGH_SVM_POLY2 ? 1 : 0, C, max_iter, eps,
     sv_out, sv_cap, alpha_out, n_sv_out, rho_out, info, c->stream);
   if ((rc == AGH_OK || rc == AGH_ERR_CAPACITY) && info_out)
@@ -826,6 +914,8 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
     info_out[1] = info[1];
     info_out[2] = (int32_t) n0;
     info_out[3] = (int32_t) (n - n0);
+    info_out[4] = info[2];
+    info_out[5] = info[3];
   }
   return rc;
 }

@@ -195,8 +195,9 @@ int agh_hog_images(agh_ctx* ctx, const uint32_t* images, int64_t n, float* desc)
  * the default Learning::train* pass (learning.h:180-182): kernel (x.y)^2; sv_out receives the *n_sv_out support vectors
  * (3528 floats each, room for sv_cap of them: AGH_ERR_CAPACITY with *n_sv_out set if there are more), alpha_out their
  * signed coefficients.  labels[k] > 0 marks a positive (label 1), anything else label -1.  The reference's CvSVMParams
- * defaults are C = 1, max_iter = 1000, eps = FLT_EPSILON.  info_out (optional, 4 ints): solver steps taken, support
- * vectors of the solve, instances of label -1, instances of label +1.
+ * defaults are C = 1, max_iter = 1000, eps = FLT_EPSILON.  info_out (optional, 6 ints): solver steps taken, support
+ * vectors of the solve, instances of label -1, instances of label +1, kernel rows computed, kernel rows served by the
+ * row cache.
  * OpenCV's solver is third-party code restated from its published algorithm: see DESIGN.md for what is pinned. */
 #define AGH_SVM_LINEAR 0
 #define AGH_SVM_POLY2 1

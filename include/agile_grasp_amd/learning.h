@@ -207,7 +207,7 @@ public:
     const std::size_t sv_cap = uses_linear_kernel ? 1 : (n > 0 ? n : 1);
     std::vector<float> sv(sv_cap * 3528);
     std::vector<double> alpha(sv_cap);
-    std::int32_t n_sv = 0, info[4] = { 0, 0, 0, 0 };
+    std::int32_t n_sv = 0, info[6] = { 0, 0, 0, 0, 0, 0 };
     double rho = 0;
     // CvSVMParams defaults (learning.cpp:297): C = 1, term_crit = 1000 iterations / FLT_EPSILON
     if (agh_train_svm(ctx, images.data(), labels.data(), (std::int64_t) n, kernel, 1.0, 1000, 1.1920928955078125e-07,
