@@ -24,6 +24,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -575,6 +576,8 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
   // kernel-row cache: every row if that fits 16 GiB, else as many as do (at least the step's two)
   cache.pitch = (n + 63) / 64 * 64;
   cache.n_slots = (int) std::max<int64_t>(2, std::min<int64_t>(n, ((int64_t) 16 << 30) / (cache.pitch * 4)));
+  if (const char* e = std::getenv("AGH_SVM_CACHE_ROWS"))  // testing aid: force evictions with a small cache
+    cache.n_slots = (int) std::max<int64_t>(2, std::min<int64_t>(cache.n_slots, std::atoll(e)));
   TRY(hipMalloc((void**) &cache.rows, (size_t) cache.n_slots * cache.pitch * 4));
   TRY(hipMalloc((void**) &cache.slot_of_row, (size_t) n * 4));
   TRY(hipMalloc((void**) &cache.row_of_slot, (size_t) cache.n_slots * 4));

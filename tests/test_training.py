@@ -277,3 +277,26 @@ def test_solver_sizes_around_the_tile_boundaries(tiny_scene, n):
                 assert np.array_equal(got["w"], ref["w"])
             else:
                 assert np.array_equal(got["sv"], ref["model"][1]) and np.array_equal(got["alpha"], ref["model"][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cache_rows", [2, 3, 17])
+def test_row_cache_evictions_do_not_change_the_model(small_scene, cache_rows, monkeypatch):
+    """A cache that holds only a few kernel rows evicts on nearly every step; the values are the same floats."""
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    ctx = binding.Context(sc.cam_origins)
+    hyps, packed, images = _training_set(sc, ctx)
+    labels = np.repeat(hyps["full_antipodal"].astype(np.int8), 3)
+    inst = packed.reshape(-1, 250)
+    full = ctx.train_svm(inst, labels, max_iter=300)
+    monkeypatch.setenv("AGH_SVM_CACHE_ROWS", str(cache_rows))
+    small = ctx.train_svm(inst, labels, max_iter=300)
+    assert small["rows_computed"] > full["rows_computed"]
+    assert small["iterations"] == full["iterations"] and small["rho"] == full["rho"] and small["n_sv"] == full["n_sv"]
+    assert np.array_equal(small["w"], full["w"])
+    poly_full = ctx.train_svm(inst, labels, max_iter=120, kernel=binding.SVM_POLY2)
+    monkeypatch.delenv("AGH_SVM_CACHE_ROWS")
+    poly_ref = ctx.train_svm(inst, labels, max_iter=120, kernel=binding.SVM_POLY2)
+    assert poly_full["rho"] == poly_ref["rho"] and np.array_equal(poly_full["alpha"], poly_ref["alpha"])
