@@ -455,11 +455,11 @@ __global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X,
 // buffer[h][v] = K(sv_v, desc_h) for two hypotheses per work-group (the pair shares the packed multiplies), then
 // sum_h = -rho + sum_v alpha[v] * buffer[h][v] in double, index order.
 __global__ __launch_bounds__(256) void k_svm_kvals(const float* __restrict__ desc, const int64_t* __restrict__ n_hyp,
-  const float* __restrict__ SVT, int n_sv, int poly, float* __restrict__ kbuf)
+  const float* __restrict__ SVT, int n_sv, int poly, float* __restrict__ kbuf, int64_t h_base)
 {
   __shared__ __attribute__((aligned(16))) float2 xij[kDesc];
   const int64_t H = *n_hyp;
-  const int64_t h0 = (int64_t) blockIdx.y * 2;
+  const int64_t h0 = h_base + (int64_t) blockIdx.y * 2;
   if (h0 >= H)
     return;
   const int64_t h1 = h0 + 1 < H ? h0 + 1 : h0;
@@ -730,8 +730,13 @@ int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_kee
     }
     c->cls_kbuf_cap = (int64_t) cap * n_sv;
   }
-  hipLaunchKernelGGL(k_svm_kvals, dim3((unsigned) ((n_sv + 255) / 256), (unsigned) ((cap + 1) / 2)), dim3(256), 0, st, d_desc,
-    (const int64_t*) c->d_nout_last, (const float*) c->d_svm_svT, n_sv, c->svm_kernel == AGH_SVM_POLY2 ? 1 : 0, c->d_cls_kbuf);
+  for (int64_t h_base = 0; h_base < cap; h_base += 2 * 65535)  // (gridDim.y <= 65535: two hypotheses per work-group)
+  {
+    const int64_t pairs = std::min<int64_t>(65535, (cap - h_base + 1) / 2);
+    hipLaunchKernelGGL(k_svm_kvals, dim3((unsigned) ((n_sv + 255) / 256), (unsigned) pairs), dim3(256), 0, st, d_desc,
+      (const int64_t*) c->d_nout_last, (const float*) c->d_svm_svT, n_sv, c->svm_kernel == AGH_SVM_POLY2 ? 1 : 0, c->d_cls_kbuf,
+      h_base);
+  }
   hipLaunchKernelGGL(k_svm_decide, dim3((unsigned) ((cap + 63) / 64)), dim3(64), 0, st, (const float*) c->d_cls_kbuf,
     (const int64_t*) c->d_nout_last, n_sv, (const double*) c->d_svm_alpha, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
@@ -879,11 +884,11 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
   int32_t max_iter, double eps, float* sv_out, int64_t sv_cap, double* alpha_out, int32_t* n_sv_out, double* rho_out,
   int32_t* info_out)
 {
-  if (!ctx || !images || !labels || !sv_out || !alpha_out || !n_sv_out || !rho_out || n <= 0 || n >= (1ll << 24) ||
+  if (!ctx || !images || !labels || !sv_out || !alpha_out || !n_sv_out || !rho_out || n <= 0 || n > 2000000 ||
       !(C > 0) || max_iter < 0 || sv_cap < 1 || (kernel_type != AGH_SVM_LINEAR && kernel_type != AGH_SVM_POLY2))
   {
     if (ctx)
-      ctx->c.err = "agh_train_svm: need images, labels, 0 < n < 2^24, a supported kernel, C > 0, max_iter >= 0, "
+      ctx->c.err = "agh_train_svm: need images, labels, 0 < n <= 2000000, a supported kernel, C > 0, max_iter >= 0, "
                    "sv_cap >= 1 and the outputs";
     return AGH_ERR_INVALID_ARGUMENT;
   }
