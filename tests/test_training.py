@@ -300,3 +300,41 @@ def test_row_cache_evictions_do_not_change_the_model(small_scene, cache_rows, mo
     monkeypatch.delenv("AGH_SVM_CACHE_ROWS")
     poly_ref = ctx.train_svm(inst, labels, max_iter=120, kernel=binding.SVM_POLY2)
     assert poly_full["rho"] == poly_ref["rho"] and np.array_equal(poly_full["alpha"], poly_ref["alpha"])
+
+
+@pytest.mark.gpu
+def test_model_loader_shapes_and_refusals(tiny_scene, tmp_path, svm_model):
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctx = binding.Context(sc.cam_origins)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    images = ctx.images()
+    w, rho = svm_model
+    # a one-support-vector quadratic model, and a linear model with alpha != 1 (not the compacted form)
+    for kernel, alpha in ((binding.SVM_POLY2, [1.0]), (binding.SVM_LINEAR, [0.5]), (binding.SVM_POLY2, [-2.5])):
+        path = str(tmp_path / f"m{kernel}_{alpha[0]}.yaml")
+        binding.save_svm_file(path, w, rho, kernel=kernel, alpha=np.array(alpha))
+        ctx.load_svm_file(path)
+        keep = ctx.classify()
+        _, sums = ctx.hog()
+        okeep, osums = O.classify_model(images, O.load_svm_model(path))
+        assert np.array_equal(keep, okeep) and np.array_equal(sums, osums)
+    # refused: kernels / parameters convertData never writes
+    good = open(str(tmp_path / f"m{binding.SVM_POLY2}_1.0.yaml")).read()
+    for bad in (good.replace("type:POLY, degree:2.", "type:POLY, degree:3."), good.replace("type:POLY", "type:RBF"),
+                good.replace("gamma:1.", "gamma:5.0000000000000000e-01"), good.replace("C_SVC", "NU_SVC"),
+                good.replace("alpha: [ 1. ]", "alpha: [ 1., 2. ]")):
+        path = str(tmp_path / "bad.yaml")
+        open(path, "w").write(bad)
+        with pytest.raises(binding.AghError):
+            ctx.load_svm_file(path)
+        with pytest.raises(RuntimeError):
+            O.load_svm_model(path)
+    with pytest.raises(binding.AghError):
+        ctx.load_svm_file(str(tmp_path / "missing.yaml"))
+    # the previous model stays usable after a refused load
+    ctx.load_svm(w, rho)
+    okeep, _ = O.classify(images, w, rho)
+    assert np.array_equal(ctx.classify(), okeep) and len(hyps) == len(okeep)
