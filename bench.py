@@ -30,21 +30,30 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def cpu_baseline(sc, n_sub: int, normals_mode: int, classify: bool, svm):
-    """The oracle (a CPU port of the reference's OpenMP path) timed on this box's host cores on a bounded sample."""
+    """The oracle (a CPU port of the reference's OpenMP path: static schedule over the samples, hand_search.cpp:77-79,
+    135-137) timed on this box's host cores on the same cloud.  The call includes what the reference's call includes (the
+    search-structure build); the port does not scale to every core of a large host (fork/join and allocator contention
+    over a few thousand samples), so a few thread counts are tried and the best one is reported with its count."""
     from oracle import oracle_py as O
 
     cores = os.cpu_count() or 1
-    p = O.default_params(sc.cam_origins, normals_mode=normals_mode, num_threads=cores)
     sub = sc.samples[:n_sub]
-    O.find_hands(p, sc.xyz, sc.cam, sub[:8])  # warm-up (page-in, OpenMP pool)
-    t0 = time.perf_counter()
-    r = O.find_hands(p, sc.xyz, sc.cam, sub, want_images=classify)
-    if classify:
-        O.classify(r["images"], svm[0], svm[1], num_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": len(r["hyps"]) / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sub} of the {sc.samples.size} samples of the same cloud, "
-                      f"{'rand50' if normals_mode else 'deterministic'} normals, OpenMP x{cores}, {dt:.2f} s",
+    best = None
+    for threads in sorted({min(cores, t) for t in (16, 32, 64, cores)}):
+        p = O.default_params(sc.cam_origins, normals_mode=normals_mode, num_threads=threads)
+        O.find_hands(p, sc.xyz, sc.cam, sub[:8])  # warm-up (page-in, OpenMP pool)
+        t0 = time.perf_counter()
+        r = O.find_hands(p, sc.xyz, sc.cam, sub, want_images=classify)
+        if classify:
+            O.classify(r["images"], svm[0], svm[1], num_threads=threads)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, threads, len(r["hyps"]))
+    dt, threads, n_hyp = best
+    return {"value": n_hyp / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
+            "sample": f"{'all' if n_sub == sc.samples.size else 'first ' + str(n_sub) + ' of the'} {sc.samples.size} samples of the "
+                      f"same cloud, {'rand50' if normals_mode else 'deterministic'} normals, best of OpenMP x16/32/64/{cores}: "
+                      f"x{threads}, {dt:.2f} s",
             "samples_per_s": n_sub / dt}
 
 
@@ -55,7 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "small"])
     ap.add_argument("--normals", default="det", choices=["det", "rand50"])
-    ap.add_argument("--cpu-samples", type=int, default=400)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 30,
+                    help="samples of the cloud the CPU baseline is timed on (default: all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
     args = ap.parse_args()
