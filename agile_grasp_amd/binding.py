@@ -57,7 +57,7 @@ HYP_DTYPE = np.dtype(
         ("valid", "u1"),
         ("finger_index", "<i4"),
         ("depth_index", "<i4"),
-        ("pad_", "<i4"),
+        ("epoch", "<i4"),
     ]
 )
 FRAME_DTYPE = np.dtype(
@@ -84,7 +84,8 @@ EXPORTS = [
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
-    "agh_load_svm_model", "agh_get_learning_points",
+    "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images",
+    "agh_save_svm_file_ex",
 ]
 
 
@@ -350,6 +351,28 @@ class Context:
         nk = C.c_int64(0)
         self._check(self.lib.agh_classify(self._h, _p(keep, C.c_uint8), C.c_int64(self.last_n), C.byref(nk)))
         return keep[:self.last_n]
+
+    def epoch(self):
+        """(stamp, hypothesis count) of the last find_hands call."""
+        e, n = C.c_int32(0), C.c_int64(0)
+        self._check(self.lib.agh_get_epoch(self._h, C.byref(e), C.byref(n)))
+        return e.value, n.value
+
+    def packed_images(self) -> np.ndarray:
+        """(H, 250) packed occupancy images of the last find_hands call."""
+        im = np.zeros((max(self.last_n, 1), 250), "<u4")
+        n = self._check(self.lib.agh_get_packed_images(self._h, _p(im, C.c_uint32), C.c_int64(self.last_n)))
+        return im[:n]
+
+    def classify_images(self, packed: np.ndarray):
+        """Learning::classify on packed images that belong to no search: (keep, decision values)."""
+        packed = np.ascontiguousarray(packed, "<u4").reshape(-1, 250)
+        n = packed.shape[0]
+        keep = np.zeros(max(n, 1), np.uint8)
+        sums = np.zeros(max(n, 1), np.float64)
+        self._check(self.lib.agh_classify_images(self._h, _p(packed, C.c_uint32), C.c_int64(n), _p(keep, C.c_uint8),
+                                                 _p(sums, C.c_double)))
+        return keep[:n], sums[:n]
 
     def hog(self):
         desc = np.zeros((max(self.last_n, 1), 3528), np.float32)

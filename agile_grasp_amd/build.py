@@ -10,7 +10,9 @@ ROOT = os.path.dirname(HERE)
 SRC = ["voxelize.hip", "grid.hip", "taubin.hip", "hand_sweep.hip", "hog_svm.hip", "handles.hip", "train.hip", "points.hip", "api.hip"]
 LIB = os.path.join(HERE, "lib", "libagile_grasp_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"]
+if os.environ.get("AGH_DEBUG_BUILD") == "1":  # phase-timing hooks (AGH_DEBUG_STOP_*, AGH_DEBUG_CLOCKS) for scripts/
+    FLAGS.append("-DAGH_DEBUG_HOOKS")
 
 
 def needs_build() -> bool:

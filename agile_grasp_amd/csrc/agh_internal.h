@@ -193,6 +193,7 @@ struct Ctx
   int32_t* d_draws = nullptr;
   int64_t draws_cap = 0;
   int64_t last_s = 0;
+  int32_t epoch = 0;         // stamp of the last agh_find_hands* call (agh_hypothesis::epoch; process-wide counter)
   int64_t last_nout = -1;
   int64_t last_cap = 0;
   agh_hypothesis* d_out_last = nullptr;  // where the last call's compacted records live
@@ -225,11 +226,16 @@ struct Ctx
   double* d_svm_sums = nullptr;
   uint8_t* d_keep = nullptr;
   int64_t keep_cap = 0;
+  uint32_t* d_cls_images = nullptr;  // agh_classify_images: uploaded packed images, keep flags, decision values
+  uint8_t* d_cls_keep = nullptr;
+  double* d_cls_sums = nullptr;
+  int64_t cls_images_cap = 0;
 
   long long* d_dbg = nullptr;  // AGH_DEBUG_CLOCKS: per-sample phase timestamps of k_hand_sweep (dumped to a file)
   int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep
   int debug_stop_moments = 0;  // AGH_DEBUG_STOP_MOMENTS
   int debug_stop_frame = 0;    // AGH_DEBUG_STOP_FRAME
+  int debug_stop_hog = 0;      // AGH_DEBUG_STOP_HOG  (all four only in builds with -DAGH_DEBUG_HOOKS)
 
   // timing
   std::vector<hipEvent_t> ev;
@@ -251,6 +257,9 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
 int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st);
 int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_keep, hipStream_t st);
+int svm_predict_images(Ctx* c, const float* d_desc, int64_t n, uint8_t* d_keep, double* d_sums, hipStream_t st);
+int svm_predict_desc(Ctx* c, const float* d_desc, int64_t cap, const int64_t* d_nhyp, agh_hypothesis* d_out, uint8_t* d_keep,
+  double* d_sums, hipStream_t st);
 int svm_load_general(Ctx* c, int kernel_type, const float* sv, int n_sv, const double* alpha, double rho);
 void hog_tables_host(HogTablesDev* t);
 int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);

@@ -9,6 +9,7 @@
 #include "agh_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,16 @@ using namespace agh;
 namespace
 {
 thread_local std::string g_create_error;
+std::atomic<int32_t> g_epoch{ 0 };  // stamps of agh_find_hands* calls, unique across the contexts of a process
+
+int32_t next_epoch()
+{
+  int32_t e;
+  do
+    e = (int32_t) ((uint32_t) g_epoch.fetch_add(1) + 1u) & 0x7fffffff;
+  while (e == 0);
+  return e;
+}
 constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
 
 #define HIPCHK(ctx, expr)                                                                             \
@@ -346,12 +357,16 @@ int agh_create(const agh_params* p, agh_ctx** out)
   Ctx* c = &ctx->c;
   c->p = *p;
   c->device = p->device;
+#ifdef AGH_DEBUG_HOOKS  // phase-timing aids of scripts/phase_timing.py; not compiled into the product build
   if (const char* e = std::getenv("AGH_DEBUG_STOP_SWEEP"))
     c->debug_stop_sweep = std::atoi(e);
   if (const char* e = std::getenv("AGH_DEBUG_STOP_MOMENTS"))
     c->debug_stop_moments = std::atoi(e);
   if (const char* e = std::getenv("AGH_DEBUG_STOP_FRAME"))
     c->debug_stop_frame = std::atoi(e);
+  if (const char* e = std::getenv("AGH_DEBUG_STOP_HOG"))
+    c->debug_stop_hog = std::atoi(e);
+#endif
   std::string gerr;
   build_geometry(*p, &c->geom, &gerr);
   if (!gerr.empty())
@@ -406,7 +421,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_vmask, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_images_cam, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_images_cam, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -774,6 +789,7 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
   timing_begin(c, st);
   c->zero_flags_pending = true;  // the first kernel of the call clears the error flags (no memset launch)
   c->last_s = S;
+  c->epoch = next_epoch();
   c->last_nout = -1;
   c->last_cap = cap;
   c->d_out_last = d_out;
@@ -820,8 +836,10 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     return AGH_OK;
   }
-  if (std::getenv("AGH_DEBUG_CLOCKS") && !c->d_dbg)
-    (void) hipMalloc((void**) &c->d_dbg, sizeof(long long) * 8 * c->s_cap);
+#ifdef AGH_DEBUG_HOOKS
+  if (std::getenv("AGH_DEBUG_CLOCKS") && !c->d_dbg && hipMalloc((void**) &c->d_dbg, sizeof(long long) * 8 * c->s_cap) != hipSuccess)
+    c->d_dbg = nullptr;
+#endif
   rc = hand_sweep(c, d_sample_idx, S, calculates_antipodal != 0, st);
   if (rc != AGH_OK)
   {
@@ -945,7 +963,8 @@ int agh_synchronize(agh_ctx* ctx)
   Ctx* c = &ctx->c;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  if (c->d_dbg && c->last_s > 0)  // development aid (AGH_DEBUG_CLOCKS): dump the phase timestamps
+#ifdef AGH_DEBUG_HOOKS
+  if (c->d_dbg && c->last_s > 0 && std::getenv("AGH_DEBUG_CLOCKS"))  // development aid: dump the phase timestamps
   {
     std::vector<long long> h((size_t) c->last_s * 8);
     if (hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -955,7 +974,19 @@ int agh_synchronize(agh_ctx* ctx)
         std::fclose(f);
       }
   }
+#endif
   return check_flags(c, c->stream);
+}
+
+int agh_get_epoch(agh_ctx* ctx, int32_t* epoch, int64_t* n_hyp)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (epoch)
+    *epoch = ctx->c.epoch;
+  if (n_hyp)
+    *n_hyp = ctx->c.last_nout;
+  return AGH_OK;
 }
 
 int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap)

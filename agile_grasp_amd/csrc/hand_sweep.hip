@@ -20,6 +20,8 @@
 // points-in-box count, the antipodal counts and the 80x100 occupancy image.
 #include "agh_internal.h"
 
+#include <cstddef>
+
 namespace agh
 {
 
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sum
 
 __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __restrict__ slots, int n,
   const int* __restrict__ block_sums, agh_hypothesis* __restrict__ out, int64_t cap, int32_t* __restrict__ slot_of_hyp,
-  int32_t* __restrict__ flags)
+  int32_t* __restrict__ flags, int32_t epoch)
 {
   __shared__ int ws[4];
   const int i0 = blockIdx.x * 1024 + threadIdx.x * 4;
@@ -813,6 +815,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
       if (pos < cap)
       {
         out[pos] = slots[i0 + k];
+        out[pos].epoch = epoch;
         slot_of_hyp[pos] = i0 + k;
       }
       else
@@ -861,9 +864,10 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restr
 
 __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __restrict__ slots,
   const uint8_t* __restrict__ vmask, const int* __restrict__ offs, int n_slots, agh_hypothesis* __restrict__ out,
-  int64_t cap, int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags)
+  int64_t cap, int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch)
 {
   static_assert(sizeof(agh_hypothesis) == 160, "10 x 16 bytes per record");
+  static_assert(offsetof(agh_hypothesis, epoch) == 156, "the stamp is the last word of the record");
   const int slot = blockIdx.x * 25 + threadIdx.x / 10, part = threadIdx.x % 10;
   if (threadIdx.x >= 250 || slot >= n_slots)
     return;
@@ -878,7 +882,10 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
       atomicOr(&flags[0], 2);
     return;
   }
-  reinterpret_cast<uint4*>(out + pos)[part] = reinterpret_cast<const uint4*>(slots + slot)[part];
+  uint4 v = reinterpret_cast<const uint4*>(slots + slot)[part];
+  if (part == 9)
+    v.w = (unsigned) epoch;
+  reinterpret_cast<uint4*>(out + pos)[part] = v;
   if (part == 0)
     slot_of_hyp[pos] = slot;
 }
@@ -932,14 +939,14 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
       d_nout);
     hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
-      (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags);
+      (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch);
   }
   else
   {
     hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
     hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout);
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
-      c->d_slot_index, c->d_flags);
+      c->d_slot_index, c->d_flags, c->epoch);
   }
   timing_mark(c, "compact", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;

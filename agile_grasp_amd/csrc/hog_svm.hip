@@ -409,8 +409,7 @@ int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st)
     return rc;
   }
   hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n_hyp_cap), dim3(256), 0, st, c->d_images, c->d_slot_index, c->d_nout_last,
-    c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out,
-    std::getenv("AGH_DEBUG_STOP_HOG") ? std::atoi(std::getenv("AGH_DEBUG_STOP_HOG")) : 0);
+    c->d_hog, c->d_svm_w, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums, c->d_desc_out, c->debug_stop_hog);
   timing_mark(c, "hog_svm", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
@@ -705,6 +704,101 @@ int agh_classify(agh_ctx* ctx, uint8_t* keep, int64_t cap, int64_t* n_kept)
     k += keep[i] ? 1 : 0;
   if (n_kept)
     *n_kept = k;
+  return AGH_OK;
+}
+
+int agh_get_packed_images(agh_ctx* ctx, uint32_t* images, int64_t cap_hyp)
+{
+  if (!ctx || (cap_hyp > 0 && !images) || cap_hyp < 0)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (c->last_nout < 0)
+  {
+    c->err = "agh_get_packed_images: needs a completed agh_find_hands call";
+    return AGH_ERR_STATE;
+  }
+  const int64_t n = std::min<int64_t>(cap_hyp, c->last_nout);
+  if (n == 0)
+    return 0;
+  HIPCHK2(c, hipSetDevice(c->device));
+  HIPCHK2(c, hipDeviceSynchronize());
+  // the images sit in the per-sample slots; hypothesis h is slot d_slot_index[h] (the compaction's record)
+  std::vector<int32_t> slot((size_t) n);
+  std::vector<uint32_t> words((size_t) c->last_s * 8 * kImageWords);
+  HIPCHK2(c, hipMemcpy(slot.data(), c->d_slot_index, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK2(c, hipMemcpy(words.data(), c->d_images, words.size() * 4, hipMemcpyDeviceToHost));
+  for (int64_t h = 0; h < n; h++)
+    std::memcpy(images + h * kImageWords, &words[(size_t) slot[(size_t) h] * kImageWords], kImageWords * 4);
+  return (int) n;
+}
+
+int agh_classify_images(agh_ctx* ctx, const uint32_t* images, int64_t n, uint8_t* keep, double* sums)
+{
+  if (!ctx || n < 0 || (n > 0 && (!images || !keep)))
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->has_svm)
+  {
+    c->err = "agh_classify_images: no SVM loaded";
+    return AGH_ERR_NO_SVM;
+  }
+  if (n == 0)
+    return AGH_OK;
+  if (n > (1 << 24))
+  {
+    c->err = "agh_classify_images: more than 2^24 images in one call";
+    return AGH_ERR_CAPACITY;
+  }
+  HIPCHK2(c, hipSetDevice(c->device));
+  if (n > c->cls_images_cap)
+  {
+    for (void* p : { (void*) c->d_cls_images, (void*) c->d_cls_keep, (void*) c->d_cls_sums })
+      if (p)
+        (void) hipFree(p);
+    c->d_cls_images = nullptr;
+    c->d_cls_keep = nullptr;
+    c->d_cls_sums = nullptr;
+    c->cls_images_cap = 0;
+    const int64_t cap = std::max<int64_t>(n, 1024);
+    HIPCHK2(c, hipMalloc((void**) &c->d_cls_images, (size_t) cap * kImageWords * 4));
+    HIPCHK2(c, hipMalloc((void**) &c->d_cls_keep, (size_t) cap));
+    HIPCHK2(c, hipMalloc((void**) &c->d_cls_sums, (size_t) cap * sizeof(double)));
+    c->cls_images_cap = cap;
+  }
+  hipStream_t st = c->stream;
+  HIPCHK2(c, hipMemcpyAsync(c->d_cls_images, images, (size_t) n * kImageWords * 4, hipMemcpyHostToDevice, st));
+  int rc = AGH_OK;
+  if (c->svm_general)
+  {
+    if (n > c->cls_desc_cap)
+    {
+      if (c->d_cls_desc)
+        (void) hipFree(c->d_cls_desc);
+      c->d_cls_desc = nullptr;
+      c->cls_desc_cap = 0;
+      HIPCHK2(c, hipMalloc((void**) &c->d_cls_desc, (size_t) n * 3528 * sizeof(float)));
+      c->cls_desc_cap = n;
+    }
+    rc = hog_images(c, c->d_cls_images, nullptr, n, c->d_cls_desc, st);
+    if (rc == AGH_OK)
+      rc = svm_predict_images(c, c->d_cls_desc, n, c->d_cls_keep, c->d_cls_sums, st);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_hog_svm, dim3((unsigned) n), dim3(256), 0, st, (const uint32_t*) c->d_cls_images,
+      (const int32_t*) nullptr, (const int64_t*) nullptr, c->d_hog, (const float*) c->d_svm_w, c->svm_rho,
+      (agh_hypothesis*) nullptr, c->d_cls_keep, c->d_cls_sums, (float*) nullptr, 0);
+    rc = hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+  }
+  if (rc != AGH_OK)
+  {
+    c->err = "agh_classify_images: launch failed";
+    return rc;
+  }
+  HIPCHK2(c, hipMemcpyAsync(keep, c->d_cls_keep, (size_t) n, hipMemcpyDeviceToHost, st));
+  if (sums)
+    HIPCHK2(c, hipMemcpyAsync(sums, c->d_cls_sums, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK2(c, hipStreamSynchronize(st));
   return AGH_OK;
 }
 

@@ -455,10 +455,10 @@ __global__ __launch_bounds__(256) void k_svm_update(const float* __restrict__ X,
 // buffer[h][v] = K(sv_v, desc_h) for two hypotheses per work-group (the pair shares the packed multiplies), then
 // sum_h = -rho + sum_v alpha[v] * buffer[h][v] in double, index order.
 __global__ __launch_bounds__(256) void k_svm_kvals(const float* __restrict__ desc, const int64_t* __restrict__ n_hyp,
-  const float* __restrict__ SVT, int n_sv, int poly, float* __restrict__ kbuf, int64_t h_base)
+  const float* __restrict__ SVT, int n_sv, int poly, float* __restrict__ kbuf, int64_t h_base, int64_t cap)
 {
   __shared__ __attribute__((aligned(16))) float2 xij[kDesc];
-  const int64_t H = *n_hyp;
+  const int64_t H = n_hyp ? (*n_hyp < cap ? *n_hyp : cap) : cap;  // never past the buffers, whatever the device count says
   const int64_t h0 = h_base + (int64_t) blockIdx.y * 2;
   if (h0 >= H)
     return;
@@ -478,10 +478,10 @@ __global__ __launch_bounds__(256) void k_svm_kvals(const float* __restrict__ des
 
 __global__ __launch_bounds__(64) void k_svm_decide(const float* __restrict__ kbuf, const int64_t* __restrict__ n_hyp, int n_sv,
   const double* __restrict__ alpha, double rho, agh_hypothesis* __restrict__ out, uint8_t* __restrict__ keep,
-  double* __restrict__ sums)
+  double* __restrict__ sums, int64_t cap)
 {
   const int64_t h = (int64_t) blockIdx.x * 64 + threadIdx.x;
-  if (h >= *n_hyp)
+  if (h >= cap || (n_hyp && h >= *n_hyp))
     return;
   double sum = -rho;
   const float* row = kbuf + h * n_sv;
@@ -714,6 +714,18 @@ int svm_train(Ctx* c, const uint32_t* h_images, int64_t n_images, const int32_t*
 // CvSVM::predict with a model that is not the compacted linear vector (Learning::classify, learning.cpp:220-225).
 int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_keep, hipStream_t st)
 {
+  return svm_predict_desc(c, d_desc, cap, c->d_nout_last, c->d_out_last, d_keep, c->d_svm_sums, st);
+}
+
+// The same for `cap` descriptors that belong to no search (agh_classify_images): exact count, no records to mark.
+int svm_predict_images(Ctx* c, const float* d_desc, int64_t n, uint8_t* d_keep, double* d_sums, hipStream_t st)
+{
+  return svm_predict_desc(c, d_desc, n, nullptr, nullptr, d_keep, d_sums, st);
+}
+
+int svm_predict_desc(Ctx* c, const float* d_desc, int64_t cap, const int64_t* d_nhyp, agh_hypothesis* d_out, uint8_t* d_keep,
+  double* d_sums, hipStream_t st)
+{
   if (cap <= 0)
     return AGH_OK;
   const int n_sv = c->svm_n_sv;
@@ -734,17 +746,17 @@ int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_kee
   {
     const int64_t pairs = std::min<int64_t>(65535, (cap - h_base + 1) / 2);
     hipLaunchKernelGGL(k_svm_kvals, dim3((unsigned) ((n_sv + 255) / 256), (unsigned) pairs), dim3(256), 0, st, d_desc,
-      (const int64_t*) c->d_nout_last, (const float*) c->d_svm_svT, n_sv, c->svm_kernel == AGH_SVM_POLY2 ? 1 : 0, c->d_cls_kbuf,
-      h_base);
+      d_nhyp, (const float*) c->d_svm_svT, n_sv, c->svm_kernel == AGH_SVM_POLY2 ? 1 : 0, c->d_cls_kbuf, h_base, cap);
   }
   hipLaunchKernelGGL(k_svm_decide, dim3((unsigned) ((cap + 63) / 64)), dim3(64), 0, st, (const float*) c->d_cls_kbuf,
-    (const int64_t*) c->d_nout_last, n_sv, (const double*) c->d_svm_alpha, c->svm_rho, c->d_out_last, d_keep, c->d_svm_sums);
+    d_nhyp, n_sv, (const double*) c->d_svm_alpha, c->svm_rho, d_out, d_keep, d_sums, cap);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
 int svm_load_general(Ctx* c, int kernel_type, const float* sv, int n_sv, const double* alpha, double rho)
 {
   float* d_sv = nullptr;
+  (void) hipDeviceSynchronize();  // classify work on a caller's stream may still read the old model
   for (void** p : { (void**) &c->d_svm_svT, (void**) &c->d_svm_alpha })
     if (*p)
     {
@@ -957,6 +969,13 @@ int agh_load_svm_model(agh_ctx* ctx, int32_t kernel_type, const float* sv, int32
 int agh_save_svm_file(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
   const double* alpha, double rho)
 {
+  // CvSVMParams' defaults, what Learning::convertData trains with (learning.cpp:297)
+  return agh_save_svm_file_ex(path, kernel_type, sv, n_sv, n_weights, alpha, rho, 1.0, 1000, 1.1920928955078125e-07);
+}
+
+int agh_save_svm_file_ex(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho, double C, int32_t max_iter, double eps)
+{
   if (!path || !sv || !alpha || n_sv < 1 || n_weights <= 0 || (kernel_type != AGH_SVM_LINEAR && kernel_type != AGH_SVM_POLY2))
     return AGH_ERR_INVALID_ARGUMENT;
   FILE* f = std::fopen(path, "wb");
@@ -990,7 +1009,10 @@ int agh_save_svm_file(const char* path, int32_t kernel_type, const float* sv, in
   };
   txt += "%YAML:1.0\nmy_svm: !!opencv-ml-svm\n   svm_type: C_SVC\n";
   txt += kernel_type == AGH_SVM_LINEAR ? "   kernel: { type:LINEAR }\n" : "   kernel: { type:POLY, degree:2., gamma:1., coef0:0. }\n";
-  txt += "   C: 1.\n   term_criteria: { epsilon:1.1920928955078125e-07, iterations:1000 }\n";
+  real(C, "%.16e", buf);  // the parameters the model was trained with (CvSVM::write_params)
+  txt += std::string("   C: ") + buf + "\n";
+  real(eps, "%.16e", buf);
+  txt += std::string("   term_criteria: { epsilon:") + buf + ", iterations:" + std::to_string(max_iter) + " }\n";
   txt += "   var_all: " + std::to_string(n_weights) + "\n   var_count: " + std::to_string(n_weights) + "\n";
   txt += "   class_count: 2\n   class_labels: !!opencv-matrix\n      rows: 1\n      cols: 2\n      dt: i\n"
          "      data: [ -1, 1 ]\n   sv_total: " + std::to_string(n_sv) + "\n   support_vectors:\n";

@@ -100,7 +100,10 @@ int main(int argc, char** argv)
     for (int k = 0; k < 6; k++)
       ws((std::size_t) k) = workspace_mat[i][(std::size_t) k];
     loc.setWorkspace(ws);
-    std::vector<GraspHypothesis> hands = loc.localizeHands(files[i] + "l_reg.pcd", files[i] + "r_reg.pcd", true, true);
+    // src/nodes/train.cpp:115 passes uses_clustering = true (RANSAC table-plane removal, pcl::SACSegmentation).  That step
+    // is not part of this build -- asking for it returns an empty list with an error -- so this example expects clouds
+    // whose table plane has been removed already (or workspaces that exclude it) and passes false.
+    std::vector<GraspHypothesis> hands = loc.localizeHands(files[i] + "l_reg.pcd", files[i] + "r_reg.pcd", true, false);
     hand_list.insert(hand_list.end(), hands.begin(), hands.end());
     hand_list_sizes[i] = (int) hand_list.size();
     std::cout << i << ") # hands: " << hands.size() << std::endl;
@@ -111,8 +114,8 @@ int main(int argc, char** argv)
     return 1;
   }
   std::cout << "Training the SVM ...\n";
-  Learning learn(loc.getHandSearch());
-  Matrix3Xd cam_pos;  // the search holds the two camera origins
+  Learning learn(4);   // train.cpp:122
+  Matrix3Xd cam_pos;  // the instance images were rasterised with the two camera origins the search holds
   const int max_positives = 20;
   learn.train(hand_list, hand_list_sizes, svm_file_name, cam_pos, max_positives);
   return 0;

@@ -82,7 +82,9 @@ typedef struct agh_hypothesis
   uint8_t valid;
   int32_t finger_index; /* eroded hand index (finger_hand.cpp:190) */
   int32_t depth_index;  /* successful deepen steps (finger_hand.cpp:204-225) */
-  int32_t pad_;
+  int32_t epoch;        /* stamp of the agh_find_hands* call that produced the record (process-wide counter, never 0):
+                           the device-side state behind agh_classify / agh_get_learning_points / agh_get_packed_images
+                           belongs to ONE call, and a record with another stamp must not be matched against it */
 } agh_hypothesis;
 
 /* Per-sample local frame (Quadric's results: quadric.h getters) -- for stage-wise parity tests and plotting. */
@@ -174,6 +176,16 @@ int agh_load_svm_file(agh_ctx* ctx, const char* path);
  * svm_keep in the device-side records; keep may be NULL for the device variant. */
 int agh_classify(agh_ctx* ctx, uint8_t* keep, int64_t cap, int64_t* n_kept);
 int agh_classify_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream);
+/* Stamp (agh_hypothesis::epoch) and hypothesis count of the last completed agh_find_hands* call of this context
+ * (*n_hyp = -1 while the count of an asynchronous agh_find_hands_device call is not known to the host). */
+int agh_get_epoch(agh_ctx* ctx, int32_t* epoch, int64_t* n_hyp);
+/* The 80x100 occupancy images (Learning::convertToImage, learning.cpp:320-365) of the hypotheses of the last
+ * agh_find_hands* call, packed (250 words each, layout below): what a hypothesis must carry to be classified later, by
+ * any context, without the device state of its search.  Returns the number of images written. */
+int agh_get_packed_images(agh_ctx* ctx, uint32_t* images, int64_t cap_hyp);
+/* Learning::classify on n such images, independent of any earlier call (the reference's classify is stateless and takes
+ * any list, learning.cpp:165-247): keep[i] = 1 iff CvSVM::predict == 1; sums (optional) receives the decision values. */
+int agh_classify_images(agh_ctx* ctx, const uint32_t* images, int64_t n, uint8_t* keep, double* sums);
 
 /* ---- training side: Learning::train / trainBalanced / convertData, learning.cpp:3-163, 249-318
  * The reference keeps, in every GraspHypothesis, the points of its hand box and their split by camera
@@ -207,6 +219,10 @@ int agh_train_svm(agh_ctx* ctx, const uint32_t* images, const int8_t* labels, in
 /* CvSVM::save (learning.cpp:312) of such a model in OpenCV's YAML layout (what agh_load_svm_file and CvSVM::load read). */
 int agh_save_svm_file(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
   const double* alpha, double rho);
+/* The same with the training parameters the file's header records (C, term_criteria); agh_save_svm_file writes
+ * CvSVMParams' defaults (C = 1, 1000 iterations, FLT_EPSILON), which is what Learning::convertData trains with. */
+int agh_save_svm_file_ex(const char* path, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
+  const double* alpha, double rho, double C, int32_t max_iter, double eps);
 /* Load a model for agh_classify from memory: the compacted linear vector (same as agh_load_svm) or support vectors +
  * alphas with either kernel (CvSVM::predict: sum = -rho + sum_k alpha[k] K(sv_k, x), kept iff sum <= 0). */
 int agh_load_svm_model(agh_ctx* ctx, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,

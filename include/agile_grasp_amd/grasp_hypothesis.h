@@ -14,22 +14,46 @@
 namespace agile_grasp_amd
 {
 
+namespace detail
+{
+/** What a hypothesis knows about the search that produced it: the device context, or nullptr once that HandSearch is
+ *  gone or has been re-created.  Shared by the HandSearch and every hypothesis it returned. */
+struct SearchLink
+{
+  agh_ctx* ctx;
+  SearchLink() : ctx(nullptr) {}
+};
+}  // namespace detail
+
 class GraspHypothesis
 {
 public:
   GraspHypothesis() : cam_source_(-1), grasp_width_(0), full_antipodal_(false), half_antipodal_(false), device_index_(-1),
-    n_points_for_learning_(0)
+    epoch_(0), n_points_for_learning_(0), points_fetched_(false)
+  {
+  }
+
+  /** The reference's constructor (grasp_hypothesis.h:67-75): a self-contained hypothesis with its points.  Such a
+   *  hypothesis carries no occupancy image, so Learning::classify refuses it (the image is rasterised by the search). */
+  GraspHypothesis(const Vector3d& axis, const Vector3d& approach, const Vector3d& binormal, const Vector3d& bottom,
+    const Vector3d& surface, double width, const Matrix3Xd& points_for_learning, const std::vector<int>& indices_cam1,
+    const std::vector<int>& indices_cam2, int cam_source)
+    : axis_(axis), approach_(approach), binormal_(binormal), grasp_bottom_(bottom), grasp_surface_(surface),
+      cam_source_(cam_source), grasp_width_(width), full_antipodal_(false), half_antipodal_(false), device_index_(-1),
+      epoch_(0), n_points_for_learning_((int) points_for_learning.cols()), points_fetched_(true),
+      points_for_learning_(points_for_learning), indices_cam1_(indices_cam1), indices_cam2_(indices_cam2)
   {
   }
 
   /** Built from one record of agh_find_hands; device_index = its position in that call's result list. */
-  GraspHypothesis(const agh_hypothesis& h, long device_index)
+  GraspHypothesis(const agh_hypothesis& h, long device_index,
+    const std::shared_ptr<detail::SearchLink>& link = std::shared_ptr<detail::SearchLink>())
     : axis_(make_vec3(h.axis[0], h.axis[1], h.axis[2])), approach_(make_vec3(h.approach[0], h.approach[1], h.approach[2])),
       binormal_(make_vec3(h.binormal[0], h.binormal[1], h.binormal[2])),
       grasp_bottom_(make_vec3(h.bottom[0], h.bottom[1], h.bottom[2])),
       grasp_surface_(make_vec3(h.surface[0], h.surface[1], h.surface[2])), cam_source_(h.cam_source),
       grasp_width_(h.width), full_antipodal_(h.full_antipodal != 0), half_antipodal_(h.half_antipodal != 0),
-      device_index_(device_index), n_points_for_learning_(h.n_in_box)
+      device_index_(device_index), epoch_(h.epoch), n_points_for_learning_(h.n_in_box), points_fetched_(false), link_(link)
   {
   }
 
@@ -56,6 +80,26 @@ public:
   void setHalfAntipodal(bool b) { half_antipodal_ = b; }
   void setGraspWidth(double w) { grasp_width_ = w; }
 
+  /** grasp_hypothesis.h:149-170.  The reference stores the 3 x n_b matrix and the two index lists in every hypothesis
+   *  (hundreds of MB per cloud); here they are fetched from the GPU the first time one of the three getters
+   *  is called (agh_get_learning_points) and cached in the hypothesis.  That works while the search that produced the
+   *  hypothesis still holds the same cloud and results; afterwards the getters print why and return empty containers. */
+  const Matrix3Xd& getPointsForLearning() const
+  {
+    fetchPoints();
+    return points_for_learning_;
+  }
+  const std::vector<int>& getIndicesPointsForLearningCam1() const
+  {
+    fetchPoints();
+    return indices_cam1_;
+  }
+  const std::vector<int>& getIndicesPointsForLearningCam2() const
+  {
+    fetchPoints();
+    return indices_cam2_;
+  }
+
   /** The geometric fields as an ABI record (input of agh_find_handles). */
   void toRecord(agh_hypothesis& h) const
   {
@@ -74,13 +118,39 @@ public:
     h.half_antipodal = half_antipodal_ ? 1 : 0;
     h.full_antipodal = full_antipodal_ ? 1 : 0;
     h.valid = 1;
+    h.epoch = epoch_;
   }
 
-  /** Number of columns the reference's points_for_learning_ would have (grasp_hypothesis.h:220).  The points
-   *  themselves stay on the GPU as the 80x100 occupancy image that Learning::classify consumes. */
+  /** Number of columns of points_for_learning_ (grasp_hypothesis.h:220) without fetching them. */
   int getNumPointsForLearning() const { return n_points_for_learning_; }
-  /** Position of this hypothesis in the device-side result list of the HandSearch call that produced it. */
+  /** Position of this hypothesis in the device-side result list of the HandSearch call that produced it, and that
+   *  call's stamp (agh_hypothesis::epoch). */
   long getDeviceIndex() const { return device_index_; }
+  int getEpoch() const { return epoch_; }
+  /** The device context that still holds this hypothesis' search results, or nullptr (search gone, re-created, or it has
+   *  run another findHands since). */
+  agh_ctx* getLiveContext() const
+  {
+    if (!link_ || !link_->ctx || device_index_ < 0)
+      return nullptr;
+    std::int32_t e = 0;
+    std::int64_t n = 0;
+    if (agh_get_epoch(link_->ctx, &e, &n) != AGH_OK || e != epoch_ || device_index_ >= n)
+      return nullptr;
+    return link_->ctx;
+  }
+  /** Any context this hypothesis' search still owns (for work that needs a device but none of the search's state). */
+  agh_ctx* getAnyContext() const { return link_ ? link_->ctx : nullptr; }
+
+  /** The 80 x 100 occupancy image Learning::convertToImage would build from the points (learning.cpp:320-365), packed
+   *  (250 words, see agh.h): the hand sweep rasterises it and HandSearch attaches it, so that Learning::classify works on
+   *  any list of hypotheses at any later time, like the reference's.  `block` is shared by the hypotheses of one call. */
+  void setImage(const std::shared_ptr<const std::vector<std::uint32_t> >& block, std::size_t first_word)
+  {
+    image_block_ = block;
+    image_first_ = first_word;
+  }
+  const std::uint32_t* getImage() const { return image_block_ ? image_block_->data() + image_first_ : nullptr; }
 
   /** Training side.  The reference keeps points_for_learning_ and their split by camera in every hypothesis
    *  (grasp_hypothesis.h:220-222) so that Learning::train can rasterise three instances later; here the hand sweep
@@ -99,12 +169,54 @@ public:
   }
 
 private:
+  void fetchPoints() const
+  {
+    if (points_fetched_)
+      return;
+    points_fetched_ = true;  // one attempt: a stale hypothesis stays empty
+    resize_3xn(points_for_learning_, 0);
+    indices_cam1_.clear();
+    indices_cam2_.clear();
+    if (device_index_ < 0)
+      return;  // default-constructed
+    agh_ctx* ctx = getLiveContext();
+    if (!ctx)
+    {
+      std::cout << " Error: getPointsForLearning: the search that produced this hypothesis no longer holds its cloud and "
+                   "results (it ran another findHands or was destroyed); fetch the points before the next search\n";
+      return;
+    }
+    const std::size_t n_b = (std::size_t) n_points_for_learning_;
+    std::vector<std::int32_t> cam(n_b + 1);
+    std::vector<double> dummy(3);
+    std::int64_t n = 0;
+    double* dst = resize_3xn(points_for_learning_, n_b);
+    if (agh_get_learning_points(ctx, device_index_, n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
+    {
+      std::cout << " Error in agh_get_learning_points: " << agh_last_error(ctx) << "\n";
+      resize_3xn(points_for_learning_, 0);
+      return;
+    }
+    for (std::size_t k = 0; k < n_b; k++)  // rotating_hand.cpp:143-151
+      if (cam[k] == 0)
+        indices_cam1_.push_back((int) k);
+      else if (cam[k] == 1)
+        indices_cam2_.push_back((int) k);
+  }
+
   Vector3d axis_, approach_, binormal_, grasp_bottom_, grasp_surface_;
   int cam_source_;
   double grasp_width_;
   bool full_antipodal_, half_antipodal_;
   long device_index_;
+  int epoch_;
   int n_points_for_learning_;
+  mutable bool points_fetched_;
+  mutable Matrix3Xd points_for_learning_;
+  mutable std::vector<int> indices_cam1_, indices_cam2_;
+  std::shared_ptr<detail::SearchLink> link_;
+  std::shared_ptr<const std::vector<std::uint32_t> > image_block_;
+  std::size_t image_first_ = 0;
   std::shared_ptr<const std::vector<std::uint32_t> > training_block_;
   std::size_t training_first_ = 0;
 };

@@ -9,14 +9,17 @@
 //  * uses_determinstic_normal_estimation_ (hand_search.h:84, hard-wired false) is exposed by
 //    setDeterministicNormalEstimation(); `false` reproduces the reference's 50 x rand() % n subsample for ONE thread;
 //  * explicit `indices` define hands_cam_source(i) = pts_cam_source(indices[i]) (the reference reads an empty vector
-//    there, hand_search.cpp:166); an empty `indices` draws num_samples indices with std::rand-free selection sampling
-//    seeded by setSampleSeed() instead of pcl::RandomSample's time seed (hand_search.cpp:36-39).
+//    there, hand_search.cpp:166); an empty `indices` draws num_samples indices like pcl::RandomSample (hand_search.cpp:
+//    36-39; PCL 1.7's algorithm restated, see drawSamples) -- time-seeded like PCL unless setSampleSeed() is called.
 //  * errors follow the reference's convention: a message on std::cout and an empty vector.
 #ifndef AGILE_GRASP_AMD_HAND_SEARCH_H
 #define AGILE_GRASP_AMD_HAND_SEARCH_H
 
 #include <cstdint>
+#include <cstdlib>
+#include <ctime>
 #include <iostream>
+#include <memory>
 #include <vector>
 
 #include "../agh.h"
@@ -33,7 +36,7 @@ public:
     int num_threads, int num_samples, const Matrix4d& cam_tf_left, bool plots_hands)
     : ctx_(nullptr), cam_tf_left_(cam_tf_left), cam_tf_right_(cam_tf_left), num_threads_(num_threads),
       num_samples_(num_samples), plots_hands_(plots_hands), deterministic_(false), sample_seed_(1), device_(0),
-      dirty_(true)
+      dirty_(true), link_(new detail::SearchLink)
   {
     agh_default_params(&params_);
     params_.finger_width = finger_width;
@@ -44,7 +47,11 @@ public:
     (void) num_threads_;
     (void) plots_hands_;
   }
-  ~HandSearch() { agh_destroy(ctx_); }
+  ~HandSearch()
+  {
+    link_->ctx = nullptr;  // hypotheses that outlive the search see that their device state is gone
+    agh_destroy(ctx_);
+  }
   HandSearch(const HandSearch&) = delete;
   HandSearch& operator=(const HandSearch&) = delete;
 
@@ -63,7 +70,11 @@ public:
     params_.rand_seed = seed;
     dirty_ = true;
   }
-  void setSampleSeed(std::uint64_t seed) { sample_seed_ = seed; }
+  void setSampleSeed(std::uint64_t seed)  // pcl::RandomSample::setSeed; default: time(NULL) like PCL
+  {
+    sample_seed_ = seed;
+    sample_seed_set_ = true;
+  }
   void setDevice(int device)
   {
     device_ = device;
@@ -71,17 +82,18 @@ public:
   }
   agh_ctx* context() { return ctx_; }
   /** GraspHypothesis::getPointsForLearning / getIndicesPointsForLearningCam1 / ...Cam2 (grasp_hypothesis.h:149-170) for
-   *  a hypothesis of the most recent findHands of this search, recomputed on the GPU on demand (the hot path keeps only
-   *  the rasterised image).  Returns false (after printing why) on error. */
+   *  a hypothesis of the most recent findHands of this search, into caller-owned containers (the hypothesis' own lazy
+   *  getters do the same and cache the result).  Returns false (after printing why) on error, e.g. for a hypothesis of
+   *  an earlier call or of another search. */
   bool getPointsForLearning(const GraspHypothesis& h, Matrix3Xd& points_for_learning, std::vector<int>& indices_cam1,
     std::vector<int>& indices_cam2)
   {
     indices_cam1.clear();
     indices_cam2.clear();
     resize_3xn(points_for_learning, 0);
-    if (!ctx_ || h.getDeviceIndex() < 0)
+    if (!ctx_ || h.getLiveContext() != ctx_)
     {
-      std::cout << " Error: the hypothesis does not come from this search\n";
+      std::cout << " Error: the hypothesis does not come from the most recent findHands of this search\n";
       return false;
     }
     const std::size_t n_b = (std::size_t) h.getNumPointsForLearning();
@@ -102,9 +114,61 @@ public:
         indices_cam2.push_back((int) k);
     return true;
   }
+  // pcl::RandomSample<PointT>::applyFilter(std::vector<int>&) as hand_search.cpp:36-39 uses it (setSample(num_samples_),
+  // no input indices => all points).  PCL is THIRD PARTY and absent from /root/reference; this restates PCL 1.7's
+  // filters/impl/random_sample.hpp: every index if num_samples >= N, else std::srand(seed) and Vitter's "Algorithm A"
+  // (J. S. Vitter, ACM TOMS 13(1), 1987) with unifRand() = (float) (rand() / double(RAND_MAX)); the result is ascending.
+  // PCL seeds with time(NULL) by default -- so does this unless setSampleSeed() was called -- hence the reference's own
+  // samples are never reproducible and explicit `indices` are what parity tests use.  The srand() side effect on the
+  // process-wide rand() stream is kept (it is the host's libc, as in the reference).
+  static std::vector<std::int32_t> randomSample(std::int64_t n_points, int num_samples, unsigned seed)
+  {
+    std::vector<std::int32_t> idx;
+    unsigned N = (unsigned) n_points;
+    const unsigned sample = num_samples < 0 ? 0u : (unsigned) num_samples;
+    if (sample >= N)
+    {
+      idx.resize((std::size_t) N);
+      for (unsigned i = 0; i < N; i++)
+        idx[i] = (std::int32_t) i;
+      return idx;
+    }
+    if (sample == 0)
+      return idx;
+    idx.resize((std::size_t) sample);
+    std::srand(seed);
+    unsigned top = N - sample, i = 0, index = 0;
+    for (std::size_t n = sample; n >= 2; n--)
+    {
+      const float V = (float) (std::rand() / double(RAND_MAX));
+      unsigned S = 0;
+      float quot = (float) top / (float) N;
+      while (quot > V)
+      {
+        S++;
+        top--;
+        N--;
+        quot = quot * (float) top / (float) N;
+      }
+      index += S;
+      idx[i++] = (std::int32_t) index++;
+      N--;
+    }
+    index += N * (unsigned) (float) (std::rand() / double(RAND_MAX));  // (PCL's cast truncates the variate, not the product)
+    idx[i++] = (std::int32_t) index++;
+    return idx;
+  }
+
+  /** The sample indices of the most recent findHands (the given ones, or the ones drawn for an empty list). */
+  const std::vector<std::int32_t>& getLastSampleIndices() const { return last_samples_; }
+
   /** Training runs (src/nodes/train.cpp): every findHands(calculates_antipodal = true) also attaches the three
    *  instance images to its hypotheses (GraspHypothesis::getTrainingImage), the input of Learning::train*. */
   void setKeepsTrainingImages(bool b) { keeps_training_images_ = b; }
+  /** Default true: every hypothesis carries its packed 80x100 occupancy image (1000 bytes), which makes
+   *  Learning::classify independent of this search's device state (any list, any time, like the reference's).  With
+   *  false, only hypotheses of the most recent findHands can be classified (no image download). */
+  void setKeepsImages(bool b) { keeps_images_ = b; }
 
   std::vector<GraspHypothesis> findHands(const PointCloud::Ptr cloud, const VectorXi& pts_cam_source,
     const std::vector<int>& indices, const PointCloud::Ptr cloud_plot, bool calculates_antipodal, bool uses_clustering)
@@ -187,10 +251,11 @@ public:
     if (indices.empty())
     {
       std::cout << "Generating uniform random indices ...\n";  // hand_search.cpp:34
-      idx = drawSamples(n);
+      idx = randomSample(n, num_samples_, sample_seed_set_ ? (unsigned) sample_seed_ : (unsigned) std::time(nullptr));
     }
     else
       idx.assign(indices.begin(), indices.end());
+    last_samples_ = idx;
     if (calculates_antipodal)
       std::cout << "Calculating normals for all points\n";  // hand_search.cpp:19
     std::cout << "Estimating local axes ...\nFinding hand poses ...\n";  // hand_search.cpp:52,58
@@ -205,7 +270,15 @@ public:
       return fail("agh_find_hands");
     hand_list.reserve((std::size_t) n_out);
     for (std::int64_t i = 0; i < n_out; i++)
-      hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i));
+      hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i, link_));
+    if (keeps_images_ && n_out > 0)
+    {
+      std::shared_ptr<std::vector<std::uint32_t> > block(new std::vector<std::uint32_t>((std::size_t) n_out * 250));
+      if (agh_get_packed_images(ctx_, block->data(), n_out) != (int) n_out)
+        return fail("agh_get_packed_images");
+      for (std::int64_t i = 0; i < n_out; i++)
+        hand_list[(std::size_t) i].setImage(block, (std::size_t) i * 250);
+    }
     if (training && n_out > 0)
     {
       std::shared_ptr<std::vector<std::uint32_t> > block(new std::vector<std::uint32_t>((std::size_t) n_out * 750));
@@ -229,6 +302,8 @@ private:
   {
     if (ctx_ && !dirty_)
       return true;
+    link_->ctx = nullptr;  // hypotheses of the old context are cut loose
+    link_.reset(new detail::SearchLink);
     agh_destroy(ctx_);
     ctx_ = nullptr;
     for (int r = 0; r < 3; r++)
@@ -246,31 +321,8 @@ private:
       return false;
     }
     dirty_ = false;
+    link_->ctx = ctx_;
     return true;
-  }
-
-  // Selection sampling of num_samples_ sorted indices (what pcl::RandomSample does, hand_search.cpp:36-39), with a
-  // splitmix64 stream instead of the time-seeded rand().
-  std::vector<std::int32_t> drawSamples(std::int64_t n)
-  {
-    std::vector<std::int32_t> idx;
-    std::uint64_t s = sample_seed_;
-    std::int64_t need = num_samples_ < n ? num_samples_ : n;
-    for (std::int64_t i = 0; i < n && need > 0; i++)
-    {
-      s += 0x9e3779b97f4a7c15ull;
-      std::uint64_t z = s;
-      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-      z ^= z >> 31;
-      const double u = (double) (z >> 11) / 9007199254740992.0;
-      if (u * (double) (n - i) < (double) need)
-      {
-        idx.push_back((std::int32_t) i);
-        need--;
-      }
-    }
-    return idx;
   }
 
   agh_ctx* ctx_;
@@ -280,10 +332,49 @@ private:
   int num_threads_, num_samples_;
   bool plots_hands_, deterministic_;
   std::uint64_t sample_seed_;
+  bool sample_seed_set_ = false;
+  std::vector<std::int32_t> last_samples_;
   int device_;
   bool dirty_;
   bool keeps_training_images_ = false;
+  bool keeps_images_ = true;
+  std::shared_ptr<detail::SearchLink> link_;
 };
+
+namespace detail
+{
+/** A device context for work that follows a search (classification, training, handle search) when the caller -- like the
+ *  reference's Learning(int) and HandleSearch() -- names none: the given search's, else one a hypothesis of the list
+ *  still links to, else a context of the finder's own (created on first use with default parameters). */
+class ContextFinder
+{
+public:
+  agh_ctx* find(HandSearch* search, const std::vector<GraspHypothesis>& hands_list)
+  {
+    if (search && search->context())
+      return search->context();
+    for (std::size_t i = 0; i < hands_list.size(); i++)
+      if (hands_list[i].getAnyContext())
+        return hands_list[i].getAnyContext();
+    if (!own_)
+    {
+      agh_params p;
+      agh_default_params(&p);
+      agh_ctx* c = nullptr;
+      if (agh_create(&p, &c) != AGH_OK)
+      {
+        std::cout << " Error: cannot create the MI355X grasp-search context: " << agh_last_error(nullptr) << "\n";
+        return nullptr;
+      }
+      own_.reset(c, agh_destroy);
+    }
+    return own_.get();
+  }
+
+private:
+  std::shared_ptr<agh_ctx> own_;
+};
+}  // namespace detail
 
 }  // namespace agile_grasp_amd
 #endif

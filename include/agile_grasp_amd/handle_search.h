@@ -51,19 +51,17 @@ private:
 class HandleSearch
 {
 public:
-  /** the context of the search that produced the hands (one GPU context per Localization) */
-  explicit HandleSearch(HandSearch& search) : search_(search) {}
+  HandleSearch() : search_(nullptr) {}  // handle_search.h:57-68: the context comes from the hands
+  /** Additional: work on the context of `search`. */
+  explicit HandleSearch(HandSearch& search) : search_(&search) {}
 
   /** handle_search.cpp:4-85 */
   std::vector<Handle> findHandles(const std::vector<GraspHypothesis>& hand_list, int min_inliers, double min_length)
   {
     std::vector<Handle> handle_list;
-    agh_ctx* ctx = search_.context();
+    agh_ctx* ctx = finder_.find(search_, hand_list);
     if (!ctx)
-    {
-      std::cout << " Error: handle search needs the context of a preceding hand search\n";
       return handle_list;
-    }
     std::vector<agh_hypothesis> recs(hand_list.size());
     for (std::size_t i = 0; i < hand_list.size(); i++)
       hand_list[i].toRecord(recs[i]);
@@ -90,7 +88,8 @@ public:
   }
 
 private:
-  HandSearch& search_;
+  HandSearch* search_;
+  detail::ContextFinder finder_;
 };
 
 }  // namespace agile_grasp_amd

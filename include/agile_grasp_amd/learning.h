@@ -10,16 +10,19 @@
 // its default uses_linear_kernel = false, i.e. the quadratic kernel; pass true for the shipped model's linear shape.
 // The hands must come from a HandSearch with setKeepsTrainingImages(true) and calculates_antipodal = true.
 //
-// The HOG descriptor and the SVM score are computed on the GPU from the occupancy images the hand search left there,
-// so `hands_list` must come from the most recent HandSearch::findHands of the HandSearch passed to the constructor
-// (they are matched by GraspHypothesis::getDeviceIndex()).  cam_pos is the pair of camera origins the search
-// already holds (localization.cpp:147-150); it is accepted for signature compatibility.
+// classify is stateless like the reference's: every hypothesis carries its packed 80x100 occupancy image (what
+// convertToImage builds from points_for_learning_; rasterised by the hand sweep, attached by HandSearch), so any list --
+// filtered, re-ordered, accumulated over several clouds or searches -- can be classified at any later time.  When the
+// whole list belongs to the most recent findHands of one live search, the images that search left on the GPU are used
+// directly (no upload).  cam_pos is accepted for signature compatibility: the images were rasterised with the camera
+// origins the search holds (localization.cpp:147-150 passes the same two).
 #ifndef AGILE_GRASP_AMD_LEARNING_H
 #define AGILE_GRASP_AMD_LEARNING_H
 
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -34,16 +37,17 @@ namespace agile_grasp_amd
 class Learning
 {
 public:
-  explicit Learning(HandSearch& search, int num_threads = 1) : search_(search), num_threads_(num_threads)
-  {
-    (void) num_threads_;
-  }
+  Learning() : search_(nullptr), num_threads_(1) {}                                 // learning.h:64-67
+  explicit Learning(int num_threads) : search_(nullptr), num_threads_(num_threads) {}  // learning.h:73-76
+  /** Additional: work on the device context of `search` instead of finding one through the hypotheses. */
+  explicit Learning(HandSearch& search, int num_threads = 1) : search_(&search), num_threads_(num_threads) {}
 
   std::vector<GraspHypothesis> classify(const std::vector<GraspHypothesis>& hands_list, const std::string& svm_filename,
     const Matrix3Xd& cam_pos, bool is_plotting = false)
   {
     (void) cam_pos;
     (void) is_plotting;
+    (void) num_threads_;
     std::cout << "Predicting ...\n";
     std::vector<GraspHypothesis> antipodal_hands;
     std::ifstream f(svm_filename.c_str());
@@ -52,33 +56,65 @@ public:
       std::cout << " Error: File " << svm_filename << " does not exist!\n";  // learning.cpp:172-178
       return antipodal_hands;
     }
-    agh_ctx* ctx = search_.context();
+    agh_ctx* ctx = contextFor(hands_list);
     if (!ctx)
-    {
-      std::cout << " Error: no hand search has run on this device context\n";
       return antipodal_hands;
-    }
     if (agh_load_svm_file(ctx, svm_filename.c_str()) != AGH_OK)
     {
       std::cout << " Exception: " << agh_last_error(ctx) << "\n";  // learning.cpp:187-191
       return antipodal_hands;
     }
-    std::vector<unsigned char> keep(hands_list.size() + 1, 0);
-    std::int64_t n_kept = 0;
-    if (agh_classify(ctx, keep.data(), (std::int64_t) keep.size(), &n_kept) != AGH_OK)
+    const std::size_t n = hands_list.size();
+    std::vector<unsigned char> keep_of(n, 0);  // per list entry
+    bool all_live = n > 0;
+    for (std::size_t i = 0; i < n && all_live; i++)
+      all_live = hands_list[i].getLiveContext() == ctx;
+    if (all_live)
     {
-      std::cout << " Error: " << agh_last_error(ctx) << "\n";
-      return antipodal_hands;
+      // the list is (a subset of) the most recent findHands of this context: its images are still on the device
+      std::int32_t epoch = 0;
+      std::int64_t n_dev = 0, n_kept = 0;
+      if (agh_get_epoch(ctx, &epoch, &n_dev) != AGH_OK || n_dev < 0)
+      {
+        std::cout << " Error: " << agh_last_error(ctx) << "\n";
+        return antipodal_hands;
+      }
+      std::vector<unsigned char> keep((std::size_t) n_dev + 1, 0);
+      if (agh_classify(ctx, keep.data(), (std::int64_t) keep.size(), &n_kept) != AGH_OK)
+      {
+        std::cout << " Error: " << agh_last_error(ctx) << "\n";
+        return antipodal_hands;
+      }
+      for (std::size_t i = 0; i < n; i++)
+        keep_of[i] = keep[(std::size_t) hands_list[i].getDeviceIndex()];
     }
-    for (std::size_t i = 0; i < hands_list.size(); i++)  // input order preserved (learning.cpp:236-243)
+    else if (n > 0)
     {
-      const long k = hands_list[i].getDeviceIndex();
-      if (k >= 0 && (std::size_t) k < keep.size() && keep[(std::size_t) k])
+      std::vector<std::uint32_t> images(n * 250);
+      for (std::size_t i = 0; i < n; i++)
+      {
+        const std::uint32_t* im = hands_list[i].getImage();
+        if (!im)
+        {
+          std::cout << " Error: hypothesis " << i << " carries no occupancy image and its search has moved on "
+                       "(HandSearch::setKeepsImages(false), or a hand-made hypothesis)\n";
+          return antipodal_hands;
+        }
+        for (int w = 0; w < 250; w++)
+          images[i * 250 + (std::size_t) w] = im[w];
+      }
+      if (agh_classify_images(ctx, images.data(), (std::int64_t) n, keep_of.data(), nullptr) != AGH_OK)
+      {
+        std::cout << " Error: " << agh_last_error(ctx) << "\n";
+        return antipodal_hands;
+      }
+    }
+    for (std::size_t i = 0; i < n; i++)  // input order preserved (learning.cpp:236-243)
+      if (keep_of[i])
       {
         antipodal_hands.push_back(hands_list[i]);
         antipodal_hands.back().setFullAntipodal(true);
       }
-    }
     std::cout << " " << antipodal_hands.size() << " antipodal grasps found.\n";
     return antipodal_hands;
   }
@@ -131,7 +167,9 @@ public:
     for (std::size_t i = 0; i < indices_selected.size(); i++)
       pushInstances(hands_list[(std::size_t) indices_selected[i]], cam_pos, instances);
     std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    hint_ctx_ = anyContextOf(hands_list);
     convertData(instances, file_name, is_plotting);
+    hint_ctx_ = nullptr;
   }
 
   /** learning.cpp:76-141 */
@@ -159,7 +197,9 @@ public:
       }
     }
     std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    hint_ctx_ = anyContextOf(hands_list);
     convertData(instances, file_name, is_plotting);
+    hint_ctx_ = nullptr;
   }
 
   /** learning.cpp:143-163 */
@@ -171,7 +211,9 @@ public:
       if (!hands_list[i].isHalfAntipodal() || hands_list[i].isFullAntipodal())  // skip the merely half-antipodal
         pushInstances(hands_list[i], cam_pos, instances);
     std::cout << "Converting " << instances.size() << " training examples (grasps) to images\n";
+    hint_ctx_ = anyContextOf(hands_list);
     convertData(instances, file_name, is_plotting);
+    hint_ctx_ = nullptr;
   }
 
   /** learning.cpp:249-318: images -> HOG -> CvSVM::train -> CvSVM::save.  Returns false (after printing why) where the
@@ -180,12 +222,9 @@ public:
     bool uses_linear_kernel = false)
   {
     (void) is_plotting;
-    agh_ctx* ctx = search_.context();
+    agh_ctx* ctx = contextFor(std::vector<GraspHypothesis>());
     if (!ctx)
-    {
-      std::cout << " Error: no hand search has run on this device context\n";
       return false;
-    }
     const std::size_t n = instances.size();
     std::vector<std::uint32_t> images(n * 250);
     std::vector<signed char> labels(n);
@@ -216,7 +255,8 @@ public:
       std::cout << " Error: " << agh_last_error(ctx) << "\n";
       return false;
     }
-    if (agh_save_svm_file(file_name.c_str(), kernel, sv.data(), n_sv, 3528, alpha.data(), rho) != AGH_OK)
+    if (agh_save_svm_file_ex(file_name.c_str(), kernel, sv.data(), n_sv, 3528, alpha.data(), rho, 1.0, 1000,
+          1.1920928955078125e-07) != AGH_OK)
     {
       std::cout << " Error: cannot write " << file_name << "\n";
       return false;
@@ -228,6 +268,19 @@ public:
   }
 
 private:
+  agh_ctx* contextFor(const std::vector<GraspHypothesis>& hands_list)
+  {
+    return hint_ctx_ ? hint_ctx_ : finder_.find(search_, hands_list);
+  }
+
+  static agh_ctx* anyContextOf(const std::vector<GraspHypothesis>& hands_list)
+  {
+    for (std::size_t i = 0; i < hands_list.size(); i++)
+      if (hands_list[i].getAnyContext())
+        return hands_list[i].getAnyContext();
+    return nullptr;
+  }
+
   // the instance for the hand as it is plus the two simulated single-camera views (learning.cpp:64-69, 92-97, 154-158)
   void pushInstances(const GraspHypothesis& h, const Matrix3Xd& cam_pos, std::vector<Instance>& instances) const
   {
@@ -258,8 +311,10 @@ private:
     std::cout << std::endl;
   }
 
-  HandSearch& search_;
+  HandSearch* search_;
   int num_threads_;
+  agh_ctx* hint_ctx_ = nullptr;         // a live context of the hands being trained on (set around convertData)
+  detail::ContextFinder finder_;
 };
 
 }  // namespace agile_grasp_amd

@@ -6,7 +6,8 @@
 // path (NaN removal, workspace box, per-camera 3 mm voxelisation: localization.cpp:25-45, 216-355; its output ORDER
 // defines the point indices the search works on) runs on the GPU as well (agh_preprocess).
 // Not carried over: the RANSAC table-plane removal behind uses_clustering (localization.cpp:51-98,
-// pcl::SACSegmentation; training path only) and the Plot members.
+// pcl::SACSegmentation; training path only) -- localizeHands(..., uses_clustering = true) prints an error and returns an
+// empty list -- and the Plot members.
 #ifndef AGILE_GRASP_AMD_LOCALIZATION_H
 #define AGILE_GRASP_AMD_LOCALIZATION_H
 
@@ -115,8 +116,16 @@ public:
     }
     // localization.cpp:17-45 on the GPU (agh_preprocess): camera id = (position >= size_left), removal of non-finite
     // points WITHOUT re-indexing the camera ids (the reference's behaviour), workspace box, per-camera 3 mm voxels in
-    // lexicographic order.  Unlike pcl::removeNaNFromPointCloud(*cloud_in, *cloud_in, ...) the caller's cloud is left
-    // untouched.
+    // lexicographic order.
+    if (uses_clustering)
+    {
+      // localization.cpp:51-98 removes the table plane with pcl::SACSegmentation (RANSAC) before the search; that step
+      // is not part of this build.  Searching the unsegmented cloud instead would label hands on the table and build a
+      // different training set while returning normally, so the request fails like the reference's other errors do.
+      std::cout << " Error: uses_clustering (table-plane removal, pcl::SACSegmentation) is not available in this build; "
+                   "remove the plane before localizeHands or pass uses_clustering = false\n";
+      return hand_list;
+    }
     std::cout << "Generating camera sources for " << cloud_in->size() << " points ...\n";
     std::cout << "Filtering workspace ...\nVoxelizing point cloud\n";
     ensureSearch();
@@ -125,8 +134,7 @@ public:
     if (!search_->preprocess(cloud_in, size_left, workspace_, 0.003, voxels, pts_cam_source))
       return hand_list;
     std::cout << " Created " << voxels->points.size() << " voxels\n";
-    if (uses_clustering)
-      std::cout << " (table-plane removal needs pcl::SACSegmentation and is not part of this build; continuing)\n";
+    remove_nan_in_place(*cloud_in);  // localization.cpp:27 filters the caller's cloud in place
     hand_list = search_->findHandsInSearchedCloud(indices, calculates_antipodal);
     if (filters_boundaries_)
     {
@@ -182,13 +190,8 @@ public:
   std::vector<GraspHypothesis> predictAntipodalHands(const std::vector<GraspHypothesis>& hand_list,
     const std::string& svm_filename)
   {
-    if (!search_)
-    {
-      std::cout << " Error: predictAntipodalHands needs a preceding localizeHands\n";
-      return std::vector<GraspHypothesis>();
-    }
-    Learning learn(*search_, num_threads_);
-    Matrix3Xd cams_mat;  // the search already holds both camera origins (localization.cpp:147-150)
+    Learning learn(num_threads_);  // localization.cpp:146
+    Matrix3Xd cams_mat;  // the images were rasterised with both camera origins already (localization.cpp:147-150)
     std::vector<GraspHypothesis> antipodal_hands = learn.classify(hand_list, svm_filename, cams_mat);
     std::cout << antipodal_hands.size() << " antipodal hand configurations found\n";
     return antipodal_hands;
@@ -197,12 +200,7 @@ public:
   /** localization.cpp:390-409 (the plotting branches aside) */
   std::vector<Handle> findHandles(const std::vector<GraspHypothesis>& hand_list, int min_inliers, double min_length)
   {
-    if (!search_)
-    {
-      std::cout << " Error: findHandles needs a preceding localizeHands\n";
-      return std::vector<Handle>();
-    }
-    HandleSearch handle_search(*search_);
+    HandleSearch handle_search;  // localization.cpp:392
     return handle_search.findHandles(hand_list, min_inliers, min_length);
   }
 

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -36,6 +37,7 @@ inline int loadPCDFile(const std::string& file_name, PointCloud& cloud)
   std::vector<std::string> fields, types;
   std::vector<int> sizes, counts;
   long long width = 0, height = 1, points = -1;
+  bool has_points = false;
   std::string data_kind, line;
   while (std::getline(in, line))
   {
@@ -63,7 +65,11 @@ inline int loadPCDFile(const std::string& file_name, PointCloud& cloud)
     else if (key == "HEIGHT")
       ls >> height;
     else if (key == "POINTS")
-      ls >> points;
+    {
+      if (!(ls >> points))
+        return -1;
+      has_points = true;
+    }
     else if (key == "DATA")
     {
       ls >> data_kind;
@@ -74,8 +80,25 @@ inline int loadPCDFile(const std::string& file_name, PointCloud& cloud)
     return -1;
   if (counts.empty())
     counts.assign(fields.size(), 1);
-  if (points < 0)
+  if (counts.size() != fields.size())
+    return -1;
+  // the header is untrusted input: every number is checked before it sizes a buffer or an offset
+  const long long kMaxPoints = 1ll << 30;  // agh_set_cloud's limit
+  if (width < 0 || height < 0 || width > kMaxPoints || height > kMaxPoints)
+    return -1;
+  if (!has_points)
     points = width * height;
+  if (points < 0 || points > kMaxPoints)
+    return -1;
+  for (std::size_t f = 0; f < fields.size(); f++)
+  {
+    if (sizes[f] != 1 && sizes[f] != 2 && sizes[f] != 4 && sizes[f] != 8)
+      return -1;
+    if (counts[f] < 1 || counts[f] > 65536)
+      return -1;
+    if (types[f] != "F" && types[f] != "U" && types[f] != "I")
+      return -1;
+  }
   std::vector<int> offset(fields.size(), 0);
   int ix = -1, iy = -1, iz = -1, irgb = -1, point_bytes = 0, n_cols = 0;
   for (std::size_t f = 0; f < fields.size(); f++)
@@ -92,9 +115,16 @@ inline int loadPCDFile(const std::string& file_name, PointCloud& cloud)
     else if ((fields[f] == "rgb" || fields[f] == "rgba") && sizes[f] == 4)
       irgb = (int) f;
   }
-  if (ix < 0 || iy < 0 || iz < 0)
+  if (ix < 0 || iy < 0 || iz < 0 || point_bytes <= 0 || point_bytes > (1 << 24))
     return -1;
-  cloud.points.assign((std::size_t) points, PointXYZRGBA());
+  try
+  {
+    cloud.points.assign((std::size_t) points, PointXYZRGBA());
+  }
+  catch (const std::exception&)  // a header that promises more points than memory holds: the documented -1, no throw
+  {
+    return -1;
+  }
   bool dense = true;
   if (data_kind == "ascii")
   {
@@ -172,6 +202,138 @@ inline int loadPCDFile(const std::string& file_name, PointCloud& cloud)
   return 0;
 }
 #endif
+
+// ---- sensor_msgs/PointCloud2 and agile_grasp/CloudSized -> the cloud localizeHands takes --------------
+// GraspLocalizer::cloud_callback / cloud_sized_callback (grasp_localizer.cpp:40-78) call pcl::fromROSMsg on the incoming
+// message; CloudSized (msg/CloudSized.msg) is a PointCloud2 plus the number of points of the left camera.  The structs
+// below carry the wire fields of the two messages for builds without ROS; fromROSMsg is a template on the message type,
+// so it reads a real sensor_msgs::PointCloud2 just as well (same member names).
+struct PointField  // sensor_msgs/PointField
+{
+  enum { INT8 = 1, UINT8 = 2, INT16 = 3, UINT16 = 4, INT32 = 5, UINT32 = 6, FLOAT32 = 7, FLOAT64 = 8 };
+  std::string name;
+  std::uint32_t offset;
+  std::uint8_t datatype;
+  std::uint32_t count;
+  PointField() : offset(0), datatype(0), count(1) {}
+  PointField(const std::string& n, std::uint32_t o, std::uint8_t d, std::uint32_t c = 1) : name(n), offset(o), datatype(d), count(c) {}
+};
+struct MsgHeader  // std_msgs/Header (the part the node reads: grasp_localizer.cpp:44-51)
+{
+  std::uint32_t seq;
+  std::string frame_id;
+  MsgHeader() : seq(0) {}
+};
+struct PointCloud2  // sensor_msgs/PointCloud2
+{
+  MsgHeader header;
+  std::uint32_t height, width;
+  std::vector<PointField> fields;
+  bool is_bigendian;
+  std::uint32_t point_step, row_step;
+  std::vector<std::uint8_t> data;
+  bool is_dense;
+  PointCloud2() : height(0), width(0), is_bigendian(false), point_step(0), row_step(0), is_dense(false) {}
+};
+struct Int64Msg  // std_msgs/Int64
+{
+  std::int64_t data;
+  Int64Msg() : data(0) {}
+};
+struct CloudSized  // msg/CloudSized.msg:1-2
+{
+  PointCloud2 cloud;
+  Int64Msg size_left;
+};
+
+/** pcl::fromROSMsg(msg, cloud) for pcl::PointXYZRGBA as grasp_localizer.cpp:55-57,73 uses it: x, y, z are read at their
+ *  field offsets (FLOAT32, or FLOAT64 narrowed), the packed colour from a 4-byte "rgba" or "rgb" field if there is one,
+ *  rows may be padded (row_step), is_dense is taken from the message.  The message is untrusted input: offsets and sizes
+ *  are checked against point_step / data.size() first.  @return 0, or -1 (after printing why) on a malformed message */
+template <typename CloudMsg>
+inline int fromROSMsg(const CloudMsg& msg, PointCloud& cloud)
+{
+  cloud.points.clear();
+  cloud.is_dense = msg.is_dense;
+  int fx = -1, fy = -1, fz = -1, fc = -1;
+  for (std::size_t f = 0; f < msg.fields.size(); f++)
+  {
+    const std::string& nm = msg.fields[f].name;
+    if (nm == "x")
+      fx = (int) f;
+    else if (nm == "y")
+      fy = (int) f;
+    else if (nm == "z")
+      fz = (int) f;
+    else if ((nm == "rgba" || nm == "rgb") && fc < 0)
+      fc = (int) f;
+  }
+  if (fx < 0 || fy < 0 || fz < 0)
+  {
+    std::cout << " Error: the PointCloud2 has no x / y / z fields\n";
+    return -1;
+  }
+  if (msg.is_bigendian)
+  {
+    std::cout << " Error: big-endian PointCloud2 data is not supported\n";
+    return -1;
+  }
+  const std::uint64_t step = msg.point_step, row = msg.row_step, w = msg.width, h = msg.height;
+  const int idx[3] = { fx, fy, fz };
+  for (int a = 0; a < 3; a++)
+  {
+    const unsigned dt = msg.fields[(std::size_t) idx[a]].datatype;
+    const std::uint64_t sz = dt == PointField::FLOAT32 ? 4 : dt == PointField::FLOAT64 ? 8 : 0;
+    if (sz == 0 || (std::uint64_t) msg.fields[(std::size_t) idx[a]].offset + sz > step)
+    {
+      std::cout << " Error: PointCloud2 field " << msg.fields[(std::size_t) idx[a]].name << " is not a float inside point_step\n";
+      return -1;
+    }
+  }
+  if (fc >= 0)
+  {
+    const unsigned dt = msg.fields[(std::size_t) fc].datatype;
+    const bool four = dt == PointField::FLOAT32 || dt == PointField::UINT32 || dt == PointField::INT32;
+    if (!four || (std::uint64_t) msg.fields[(std::size_t) fc].offset + 4 > step)
+      fc = -1;  // like PCL: a colour field that does not match is skipped, the points are still read
+  }
+  if (w * h > (1ull << 30) || step == 0 || (w > 0 && row < w * step) || (h > 0 && (h - 1) * row + w * step > msg.data.size()))
+  {
+    std::cout << " Error: PointCloud2 width / height / point_step / row_step do not fit its data\n";
+    return -1;
+  }
+  cloud.points.resize((std::size_t) (w * h));
+  for (std::uint64_t r = 0; r < h; r++)
+    for (std::uint64_t c = 0; c < w; c++)
+    {
+      const std::uint8_t* p = msg.data.data() + r * row + c * step;
+      PointCloud::PointType& q = cloud.points[(std::size_t) (r * w + c)];
+      float* dst[3] = { &q.x, &q.y, &q.z };
+      for (int a = 0; a < 3; a++)
+      {
+        const std::uint8_t* src = p + msg.fields[(std::size_t) idx[a]].offset;
+        if (msg.fields[(std::size_t) idx[a]].datatype == PointField::FLOAT32)
+          std::memcpy(dst[a], src, 4);
+        else
+        {
+          double v;
+          std::memcpy(&v, src, 8);
+          *dst[a] = (float) v;
+        }
+      }
+      if (fc >= 0)
+        std::memcpy(&q.rgba, p + msg.fields[(std::size_t) fc].offset, 4);
+    }
+  return 0;
+}
+
+/** cloud_sized_callback (grasp_localizer.cpp:63-78): the cloud and size_left of a CloudSized message. */
+template <typename CloudSizedMsg>
+inline int fromCloudSized(const CloudSizedMsg& msg, PointCloud& cloud, int& size_left)
+{
+  size_left = (int) msg.size_left.data;
+  return fromROSMsg(msg.cloud, cloud);
+}
 
 /** msg/Grasp.msg:1-5 */
 struct Grasp

@@ -20,6 +20,7 @@
 
 #ifdef AGILE_GRASP_AMD_HAVE_PCL_EIGEN
 #include <Eigen/Dense>
+#include <pcl/filters/filter.h>
 #include <pcl/io/pcd_io.h>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
@@ -41,6 +42,11 @@ inline double* resize_3xn(Matrix3Xd& m, std::size_t n)  // column-major storage 
   return m.data();
 }
 inline int loadPCDFile(const std::string& f, PointCloud& c) { return pcl::io::loadPCDFile<pcl::PointXYZRGBA>(f, c); }
+inline void remove_nan_in_place(PointCloud& c)  // localization.cpp:26-27
+{
+  std::vector<int> nan_indices;
+  pcl::removeNaNFromPointCloud(c, c, nan_indices);
+}
 }  // namespace agile_grasp_amd
 
 #else  // stand-ins
@@ -101,6 +107,7 @@ struct PointXYZRGBA  // pcl::PointXYZRGBA: 32 bytes, xyz at offset 0
 struct PointCloud
 {
   typedef std::shared_ptr<PointCloud> Ptr;
+  typedef PointXYZRGBA PointType;
   std::vector<PointXYZRGBA> points;
   bool is_dense = false;  // pcl::PointCloud::is_dense: "no point has a non-finite coordinate"
   std::size_t size() const { return points.size(); }
@@ -108,6 +115,23 @@ struct PointCloud
 inline double mat4(const Matrix4d& m, int r, int c) { return m(r, c); }
 inline Vector3d make_vec3(double x, double y, double z) { return Vector3d(x, y, z); }
 inline bool cloud_is_dense(const PointCloud& c) { return c.is_dense; }
+// pcl::removeNaNFromPointCloud(c, c, idx) (localization.cpp:26-27): a dense cloud is passed through, otherwise the points
+// with a non-finite coordinate are dropped in place and the cloud is marked dense
+inline void remove_nan_in_place(PointCloud& c)
+{
+  if (c.is_dense)
+    return;
+  std::size_t j = 0;
+  for (std::size_t i = 0; i < c.points.size(); i++)
+  {
+    const PointXYZRGBA& p = c.points[i];
+    if (p.x - p.x != 0.0f || p.y - p.y != 0.0f || p.z - p.z != 0.0f)  // NaN or infinity
+      continue;
+    c.points[j++] = p;
+  }
+  c.points.resize(j);
+  c.is_dense = true;
+}
 }  // namespace agile_grasp_amd
 #endif
 

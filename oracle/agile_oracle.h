@@ -61,7 +61,7 @@ typedef struct orc_hypothesis
   uint8_t half_antipodal, full_antipodal, svm_keep, valid;
   int32_t finger_index; /* eroded hand index e (finger_hand.cpp:190) */
   int32_t depth_index;  /* number of successful deepen steps (finger_hand.cpp:204-225) */
-  int32_t pad_;
+  int32_t epoch;  /* the product stamps its calls here; the oracle leaves 0 */
 } orc_hypothesis;
 
 typedef struct orc_frame

@@ -54,7 +54,7 @@ HYP_DTYPE = np.dtype(
         ("valid", "u1"),
         ("finger_index", "<i4"),
         ("depth_index", "<i4"),
-        ("pad_", "<i4"),
+        ("epoch", "<i4"),
     ]
 )
 assert HYP_DTYPE.itemsize == 160

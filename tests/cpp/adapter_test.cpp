@@ -71,6 +71,14 @@ int main(int argc, char** argv)
     std::vector<int> cam1, cam2;
     if (!hand_search.getPointsForLearning(h, pts, cam1, cam2))
       return 3;
+    // the reference's accessors on the hypothesis itself (learning.cpp:387-395) give the same
+    if (h.getPointsForLearning().cols() != pts.cols() || h.getIndicesPointsForLearningCam1() != cam1 ||
+        h.getIndicesPointsForLearningCam2() != cam2)
+      return 4;
+    for (size_t k = 0; k < pts.cols(); k++)
+      for (int r = 0; r < 3; r++)
+        if (h.getPointsForLearning()(r, k) != pts(r, k))
+          return 4;
     double sum[3] = { 0, 0, 0 };
     for (size_t k = 0; k < pts.cols(); k++)
       for (int r = 0; r < 3; r++)

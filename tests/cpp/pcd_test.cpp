@@ -1,6 +1,7 @@
 // pcd_test.cpp -- the PCD-filename entry point of the facade (localization.cpp:175-212) and the message builders
 // (grasp_localizer.cpp:107-180), the way src/nodes/test.cpp and src/tests/test_local_axes.cpp use the reference.
 //   pcd_test parse <file.pcd>                       -> point count, is_dense and a checksum (no GPU needed)
+//   pcd_test msg <cloud_sized.bin>                  -> the same for a serialised agile_grasp/CloudSized message (no GPU)
 //   pcd_test run <left.pcd> <right.pcd> <svm> <ws6 as "a,b,c,d,e,f"> <cam_left3> <cam_right3> <idx,idx,...>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +45,64 @@ int main(int argc, char** argv)
       col += p.rgba;
     }
     std::printf("PCD %zu %d %zu %.17g %llu\n", c.points.size(), c.is_dense ? 1 : 0, nan, sum, col);
+    return 0;
+  }
+  if (argc >= 3 && std::strcmp(argv[1], "msg") == 0)
+  {
+    // cloud_sized.bin: u32 height, width, point_step, row_step, is_dense, is_bigendian, n_fields; per field u32 name length,
+    // the name, u32 offset, datatype, count; u64 data length, the data; i64 size_left
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f)
+      return 2;
+    CloudSized m;
+    unsigned hdr[7];
+    if (std::fread(hdr, 4, 7, f) != 7)
+      return 2;
+    m.cloud.height = hdr[0];
+    m.cloud.width = hdr[1];
+    m.cloud.point_step = hdr[2];
+    m.cloud.row_step = hdr[3];
+    m.cloud.is_dense = hdr[4] != 0;
+    m.cloud.is_bigendian = hdr[5] != 0;
+    for (unsigned k = 0; k < hdr[6]; k++)
+    {
+      unsigned len = 0, v[3];
+      if (std::fread(&len, 4, 1, f) != 1 || len > 64)
+        return 2;
+      std::string name(len, ' ');
+      if (std::fread(&name[0], 1, len, f) != len || std::fread(v, 4, 3, f) != 3)
+        return 2;
+      m.cloud.fields.push_back(PointField(name, v[0], (std::uint8_t) v[1], v[2]));
+    }
+    unsigned long long dl = 0;
+    if (std::fread(&dl, 8, 1, f) != 1)
+      return 2;
+    m.cloud.data.resize((size_t) dl);
+    long long sl = 0;
+    if ((dl > 0 && std::fread(m.cloud.data.data(), 1, (size_t) dl, f) != dl) || std::fread(&sl, 8, 1, f) != 1)
+      return 2;
+    m.size_left.data = sl;
+    std::fclose(f);
+    PointCloud c;
+    int size_left = -1;
+    if (fromCloudSized(m, c, size_left) != 0)
+    {
+      std::printf("CONVERT_FAILED\n");
+      return 0;
+    }
+    double sum = 0;
+    unsigned long long col = 0;
+    size_t nan = 0;
+    for (size_t i = 0; i < c.points.size(); i++)
+    {
+      const PointXYZRGBA& p = c.points[i];
+      if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))
+        sum += (double) p.x + 2.0 * (double) p.y + 3.0 * (double) p.z;
+      else
+        nan++;
+      col += p.rgba;
+    }
+    std::printf("MSG %zu %d %zu %.17g %llu %d\n", c.points.size(), c.is_dense ? 1 : 0, nan, sum, col, size_left);
     return 0;
   }
   if (argc < 9 || std::strcmp(argv[1], "run") != 0)

@@ -514,3 +514,89 @@ def test_train_example_trains_a_loadable_model(tmp_path):
     kernel, sv, alpha, rho = O.load_svm_model(model)  # a CvSVM file of the quadratic-kernel shape
     assert kernel == 1 and sv.shape[0] == alpha.shape[0] >= 2 and np.isfinite(rho)
     assert (alpha > 0).any() and (alpha < 0).any() and np.all(np.abs(alpha) <= 1.0)
+
+
+# ---- row f3: sensor_msgs/PointCloud2 / agile_grasp/CloudSized -> xyz + size_left (grasp_localizer.cpp:40-78) ----
+def _write_cloud_sized(path, xyz, size_left, layout, dense=False, bigendian=False, truncate=0, bad_offset=False,
+                       height=1, row_pad=0):
+    """Serialise a CloudSized message the way pcd_test's `msg` mode reads it.  layout: 'xyz' (12-byte points),
+    'xyzrgba' (pcl::PointXYZRGBA's 32-byte wire layout: x y z at 0/4/8, rgba at 16), 'f64' (double coordinates)."""
+    n = len(xyz)
+    rgba = (np.arange(n, dtype=np.uint32) * 2654435761 & 0xffffffff).astype(np.uint32)
+    if layout == "xyz":
+        step, fields = 12, [("x", 0, 7), ("y", 4, 7), ("z", 8, 7)]
+        rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    elif layout == "xyzrgba":
+        step, fields = 32, [("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("rgba", 16, 6)]
+        rec = np.zeros(n, dtype={"names": ["x", "y", "z", "c"], "formats": ["<f4", "<f4", "<f4", "<u4"],
+                                 "offsets": [0, 4, 8, 16], "itemsize": 32})
+        rec["c"] = rgba
+    else:
+        step, fields = 28, [("intensity", 0, 7), ("x", 4, 8), ("y", 12, 8), ("z", 20, 8)]
+        rec = np.zeros(n, dtype={"names": ["x", "y", "z"], "formats": ["<f8", "<f8", "<f8"], "offsets": [4, 12, 20],
+                                 "itemsize": 28})
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if bad_offset:
+        fields[2] = (fields[2][0], step - 2, fields[2][2])
+    width = n // height
+    assert width * height == n
+    rows = rec.tobytes()
+    data = b"".join(rows[r * width * step:(r + 1) * width * step] + b"\xab" * row_pad for r in range(height))
+    if truncate:
+        data = data[:-truncate]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<7I", height, width, step, width * step + row_pad, int(dense), int(bigendian), len(fields)))
+        for name, off, dt in fields:
+            f.write(struct.pack("<I", len(name)) + name.encode() + struct.pack("<3I", off, dt, 1))
+        f.write(struct.pack("<Q", len(data)) + data + struct.pack("<q", size_left))
+    return rgba if layout == "xyzrgba" else np.zeros(n, np.uint32)
+
+
+@pytest.mark.parametrize("layout,height,row_pad", [("xyz", 1, 0), ("xyzrgba", 1, 0), ("f64", 1, 0), ("xyzrgba", 4, 24)])
+def test_pointcloud2_reader(tmp_path, layout, height, row_pad):
+    exe = _build_pcd(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    xyz = xyz[:3000]
+    path = str(tmp_path / "m.bin")
+    rgba = _write_cloud_sized(path, xyz, 1234, layout, height=height, row_pad=row_pad)
+    out = subprocess.run([exe, "msg", path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    tok = [l for l in out.stdout.splitlines() if l.startswith("MSG")][0].split()
+    fin = np.isfinite(xyz).all(1)
+    exp = 0.0
+    for r in xyz[fin].astype(np.float64):
+        exp += r[0] + 2.0 * r[1] + 3.0 * r[2]
+    assert int(tok[1]) == len(xyz) and int(tok[2]) == 0 and int(tok[3]) == int((~fin).sum())
+    assert float(tok[4]) == exp and int(tok[5]) == int(rgba.astype(np.uint64).sum()) and int(tok[6]) == 1234
+
+
+@pytest.mark.parametrize("kw", [dict(bigendian=True), dict(truncate=5), dict(bad_offset=True)])
+def test_pointcloud2_reader_refuses_malformed_messages(tmp_path, kw):
+    exe = _build_pcd(tmp_path)
+    xyz = _raw_cloud()[0][:100]
+    path = str(tmp_path / "m.bin")
+    _write_cloud_sized(path, xyz, 50, "xyzrgba", **kw)
+    out = subprocess.run([exe, "msg", path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "CONVERT_FAILED" in out.stdout and "Error" in out.stdout
+
+
+@pytest.mark.parametrize("edit", ["POINTS -5", "POINTS 99999999999999", "WIDTH -3", "SIZE 4 4 0 4", "SIZE 4 4 -4 4",
+                                  "COUNT 1 1 0 1", "COUNT 1 1 1", "TYPE F F Q U"])
+def test_pcd_reader_rejects_hostile_headers(tmp_path, edit):
+    """header numbers are untrusted; every violation is the documented -1, never an exception or an
+    out-of-bounds copy."""
+    exe = _build_pcd(tmp_path)
+    xyz = _raw_cloud()[0][:50]
+    path = str(tmp_path / "c.pcd")
+    _write_pcd(path, xyz, True)
+    raw = open(path, "rb").read()
+    key = edit.split()[0].encode()
+    lines = raw.split(b"\n")
+    k = [i for i, l in enumerate(lines[:12]) if l.startswith(key + b" ")][0]
+    lines[k] = edit.encode()
+    if key == b"WIDTH":  # POINTS then follows from WIDTH x HEIGHT
+        lines = [l for i, l in enumerate(lines) if not (i < 12 and l.startswith(b"POINTS "))]
+    open(path, "wb").write(b"\n".join(lines))
+    out = subprocess.run([exe, "parse", path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "LOAD_FAILED" in out.stdout

@@ -363,6 +363,45 @@ def test_full_size_c2_against_oracle(svm_model):
     assert len(hyps) > 300
 
 
+@pytest.mark.parametrize("name", ["C1", "C4", "C5_0"])
+def test_full_size_other_configs_against_oracle(svm_model, name):
+    """The BASELINE configs besides C2/C3, whole result list (frames, hypotheses, SVM labels) bit-identical to the oracle:
+    C1 (single view, 50k points, 500 samples: every point from camera 0), C4 (1M points, 8000 samples: multi-tile sweeps
+    with the parked-points path, the 4096-point moments class, the large scheduling sort), C5_0 (first cloud of the
+    batch, seed 10)."""
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config(name)
+    w, rho = svm_model
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ctx.load_svm(w, rho)
+    keep = ctx.classify()
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert_hyps_equal(hyps, ref["hyps"])
+    okeep, _ = O.classify(ref["images"], w, rho)
+    assert np.array_equal(keep, okeep)
+    assert len(hyps) > sc.samples.size // 10
+    nt, nh = ctx.neighbor_counts()
+    if name == "C4":
+        assert nh.max() > 2176  # at least one sample streams several tiles through the sweep
+    # the stateless classification path (images carried by the hypotheses) gives the same labels and decision values
+    packed = ctx.packed_images()
+    assert np.array_equal(binding_unpack(packed), ref["images"].reshape(len(hyps), -1))
+    keep2, sums2 = ctx.classify_images(packed)
+    _, osums = O.classify(ref["images"], w, rho)
+    assert np.array_equal(keep2, okeep) and np.array_equal(sums2, osums)
+
+
+def binding_unpack(words):
+    from agile_grasp_amd import binding
+
+    return binding.unpack_images(words)
+
+
 def test_large_sample_list_matches_small_one(tiny_scene):
     """70 000 samples (the list of 64 repeated) take the large-S paths -- three-kernel concatenation, many tiles in the
     scheduling sort, thousands of eigen work-groups -- and must give, position by position, what the 64 give."""

@@ -267,3 +267,28 @@ def test_points_for_learning_match_numpy_transcription(tiny_scene):
             assert np.array_equal(res["cams"][k], g["cam_in_box"])
             checked += 1
     assert checked > 10
+
+
+def test_oracle_runs_config_c1(svm_model):
+    """BASELINE config C1 (single view, 50k points, 500 samples: the reference's own CPU-runnable case).  No golden exists
+    for it (the reference ships no PCD), so this pins the invariants of the result instead: orthonormal right-handed
+    frames facing the (only) camera, sample-major / orientation-ascending order, every point from camera 0, and an SVM
+    verdict for every hypothesis."""
+    from agile_grasp_amd import synthetic
+
+    sc = synthetic.config("C1")
+    assert sc.n == 50_000 and sc.samples.size == 500 and not sc.cam.any()
+    r = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+    fr, hy = r["frames"], r["hyps"]
+    ok = fr["valid"] != 0
+    assert ok.sum() > 450 and len(hy) > 50
+    n, a, b = fr["normal"][ok], fr["axis"][ok], fr["binormal"][ok]
+    for u, v in ((n, n), (a, a), (b, b)):
+        assert np.allclose((u * v).sum(1), 1.0, atol=1e-12)
+    assert np.allclose((n * a).sum(1), 0, atol=1e-12) and np.allclose(np.cross(n, b), a, atol=1e-12)
+    to_cam = fr["sample"][ok] - sc.cam_origins[0]
+    assert ((n * to_cam).sum(1) <= 0).all()  # quadric.cpp:294-301
+    key = hy["sample"].astype(np.int64) * 8 + hy["orientation"]
+    assert (np.diff(key) > 0).all() and not hy["cam_source"].any()
+    keep, sums = O.classify(r["images"], *svm_model)
+    assert keep.shape == (len(hy),) and np.array_equal(keep.astype(bool), sums <= 0)
