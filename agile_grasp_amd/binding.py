@@ -85,8 +85,34 @@ EXPORTS = [
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
     "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images",
-    "agh_save_svm_file_ex",
+    "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_set_segment_records",
+    "agh_shard_slice", "agh_find_hands_sharded_device", "agh_find_hands_sharded", "agh_classify_sharded_device",
+    "agh_classify_sharded",
 ]
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId: call on one rank, hand the 128 bytes to the others."""
+    buf = (C.c_uint8 * 128)()
+    rc = load_library().agh_comm_unique_id(buf)
+    if rc != 0:
+        raise AghError(rc, "agh_comm_unique_id failed (is RCCL installed?)")
+    return bytes(buf)
+
+
+def comm_init_local(contexts) -> None:
+    """The contexts (one host thread each) become the ranks of an in-process communicator: the sharded schedule with
+    device copies instead of RCCL, for validation on a single GPU."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = load_library().agh_comm_init_local(arr, C.c_int32(len(contexts)))
+    if rc != 0:
+        raise AghError(rc, "agh_comm_init_local failed")
+
+
+def shard_slice(n: int, rank: int, n_ranks: int):
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    load_library().agh_shard_slice(C.c_int64(n), C.c_int32(rank), C.c_int32(n_ranks), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def pack_images(images: np.ndarray) -> np.ndarray:
@@ -146,6 +172,7 @@ def load_library():
         lib.agh_selftest_math.restype = C.c_int64
         lib.agh_destroy.restype = None
         lib.agh_default_params.restype = None
+        lib.agh_shard_slice.restype = None
         _LIB = lib
     return _LIB
 
@@ -373,6 +400,60 @@ class Context:
         self._check(self.lib.agh_classify_images(self._h, _p(packed, C.c_uint32), C.c_int64(n), _p(keep, C.c_uint8),
                                                  _p(sums, C.c_double)))
         return keep[:n], sums[:n]
+
+    # ---- multi-GPU: samples of one cloud sharded over the ranks of a communicator ----
+    def comm_init(self, rank: int, n_ranks: int, unique_id: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.agh_comm_init(self._h, C.c_int32(rank), C.c_int32(n_ranks), buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.agh_comm_destroy(self._h))
+
+    def comm_set_segment_records(self, records: int):
+        self._check(self.lib.agh_comm_set_segment_records(self._h, C.c_int64(records)))
+
+    def comm_rank(self):
+        r, n = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.agh_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def find_hands_sharded(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
+        samples = np.ascontiguousarray(samples, np.int32)
+        cap = max(8 * samples.shape[0], 1)
+        out = np.zeros(cap, HYP_DTYPE)
+        n = C.c_int64(0)
+        self._check(self.lib.agh_find_hands_sharded(self._h, _p(samples, C.c_int32), C.c_int64(samples.shape[0]),
+                                                    C.c_int(1 if calculates_antipodal else 0),
+                                                    out.ctypes.data_as(C.c_void_p), C.c_int64(cap), C.byref(n)))
+        r, g = self.comm_rank()
+        lo, hi = shard_slice(samples.shape[0], r, g)
+        self.last_samples = hi - lo
+        self.shard_n = n.value
+        e, mine = self.epoch()
+        self.last_n = max(mine, 0)
+        return out[:n.value].copy()
+
+    def classify_sharded(self):
+        """(records with svm_keep set, keep flags) of the last find_hands_sharded."""
+        n = self.shard_n
+        out = np.zeros(max(n, 1), HYP_DTYPE)
+        keep = np.zeros(max(n, 1), np.uint8)
+        nk = C.c_int64(0)
+        self._check(self.lib.agh_classify_sharded(self._h, out.ctypes.data_as(C.c_void_p), _p(keep, C.c_uint8), C.c_int64(n),
+                                                  C.byref(nk)))
+        return out[:n].copy(), keep[:n].copy()
+
+    def find_hands_sharded_torch(self, samples_t, out_t, nout_t, calculates_antipodal: bool = False, stream=None):
+        S = samples_t.shape[0]
+        cap = out_t.numel() // 160
+        self._check(self.lib.agh_find_hands_sharded_device(
+            self._h, C.c_void_p(samples_t.data_ptr()), C.c_int64(S), C.c_int(1 if calculates_antipodal else 0),
+            C.c_void_p(out_t.data_ptr()), C.c_int64(cap), C.c_void_p(nout_t.data_ptr()),
+            C.c_void_p(stream) if stream else None))
+
+    def classify_sharded_torch(self, keep_t=None, stream=None):
+        self._check(self.lib.agh_classify_sharded_device(
+            self._h, C.c_void_p(keep_t.data_ptr()) if keep_t is not None else None, C.c_void_p(stream) if stream else None))
 
     def hog(self):
         desc = np.zeros((max(self.last_n, 1), 3528), np.float32)

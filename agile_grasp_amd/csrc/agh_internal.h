@@ -18,6 +18,7 @@ constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (q
 constexpr int kSumStride = 40;     // doubles per sample in the sums buffer
 constexpr int kSlots = 8;          // hypothesis slots per sample = hand orientations (rotating_hand.cpp:13)
 constexpr int kImageWords = 250;   // 80x100 occupancy bitmap, one bit per pixel
+constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
 
 // Uniform grid over the cloud's bounding box (stands in for the kd-tree of hand_search.cpp:10-11).
 struct GridDesc
@@ -104,6 +105,8 @@ struct VoxWorkspace
 {
   double lo[3], hi[3];
 };
+
+struct Comm;  // shard.hip
 
 struct Ctx
 {
@@ -231,6 +234,20 @@ struct Ctx
   double* d_cls_sums = nullptr;
   int64_t cls_images_cap = 0;
 
+  // multi-GPU: the sample set of one cloud sharded over the ranks of a communicator (shard.hip)
+  Comm* comm = nullptr;
+  uint8_t* d_xbuf = nullptr;      // n_ranks segments of [160-byte header | seg_records records], all-gathered in place
+  int64_t xbuf_bytes = 0;
+  double* d_nbuf = nullptr;       // n_ranks segments of per-sample normals (antipodal mode), all-gathered in place
+  int64_t nbuf_doubles = 0;
+  int64_t* d_xcnt = nullptr;      // n_ranks RAND50 draw counts + scratch
+  int64_t shard_seg_override = 0;    // agh_comm_set_segment_records
+  bool shard_full_exchange = false;  // exchange all 8 slots per sample instead of the 2-per-sample prefix
+  int64_t shard_seg_records = 0, shard_seg_bytes = 0, shard_S = 0;
+  agh_hypothesis* shard_out = nullptr;  // the caller's merged list of the last sharded search
+  int64_t shard_cap = 0;
+  int64_t* shard_nout = nullptr;
+
   long long* d_dbg = nullptr;  // AGH_DEBUG_CLOCKS: per-sample phase timestamps of k_hand_sweep (dumped to a file)
   int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep
   int debug_stop_moments = 0;  // AGH_DEBUG_STOP_MOMENTS
@@ -252,6 +269,9 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);
+int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st);
+int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
+  bool write_normals, hipStream_t st);
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
 int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
@@ -265,6 +285,12 @@ void hog_tables_host(HogTablesDev* t);
 int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);
 
 void timing_mark(Ctx* c, const char* name, hipStream_t st);
+void timing_begin(Ctx* c, hipStream_t st);
+int32_t next_epoch();
+int ensure_call_buffers(Ctx* c, int64_t S);
+int ensure_draws(Ctx* c, int64_t count, hipStream_t st);
+int normals_pass(Ctx* c, int64_t p0, int64_t p1, hipStream_t st);
+void comm_release(Ctx* c);
 
 // ---- device helpers ----
 #if defined(__HIPCC__)

@@ -22,7 +22,10 @@ namespace
 {
 thread_local std::string g_create_error;
 std::atomic<int32_t> g_epoch{ 0 };  // stamps of agh_find_hands* calls, unique across the contexts of a process
+}  // namespace
 
+namespace agh
+{
 int32_t next_epoch()
 {
   int32_t e;
@@ -31,7 +34,10 @@ int32_t next_epoch()
   while (e == 0);
   return e;
 }
-constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
+}  // namespace agh
+
+namespace
+{
 
 #define HIPCHK(ctx, expr)                                                                             \
   do                                                                                                  \
@@ -184,6 +190,10 @@ void build_geometry(const agh_params& p, HandGeom* g, std::string* err)
     *err = "hand geometry packs more than 4 finger-slot thresholds (or bite depths) into one look-up cell";
 }
 
+}  // namespace
+
+namespace agh
+{
 int ensure_call_buffers(Ctx* c, int64_t S)
 {
   if (c->training_images && c->images_cam_cap < std::max<int64_t>(std::max<int64_t>(S, c->s_cap), 1024))
@@ -255,6 +265,24 @@ __global__ void k_iota(int32_t* out, int base, int n)
     out[i] = base + i;
 }
 
+// hand_search.cpp:13-26: findQuadrics over the cloud points [p0, p1) with r = nn_radius_normals, writing cloud_normals_
+int normals_pass(Ctx* c, int64_t p0, int64_t p1, hipStream_t st)
+{
+  for (int64_t b0 = p0; b0 < p1; b0 += kNormalsChunk)
+  {
+    const int nb = (int) std::min<int64_t>(kNormalsChunk, p1 - b0);
+    hipLaunchKernelGGL(k_iota, dim3((nb + 255) / 256), dim3(256), 0, st, c->d_samples, (int) b0, nb);
+    const int rc = taubin_frames(c, c->d_samples, nb, c->p.nn_radius_normals, c->d_frames, c->d_nt, true, st);
+    if (rc != AGH_OK)
+      return rc;
+  }
+  return AGH_OK;
+}
+}  // namespace agh
+
+namespace agh
+{
+
 void timing_begin(Ctx* c, hipStream_t st)
 {
   if (c->p.profile != 1 && c->ev_used <= 60000)
@@ -268,7 +296,7 @@ void timing_begin(Ctx* c, hipStream_t st)
     timing_mark(c, "start", st);
 }
 
-}  // namespace
+}  // namespace agh
 
 namespace agh
 {
@@ -416,12 +444,13 @@ void agh_destroy(agh_ctx* ctx)
   (void) hipSetDevice(c->device);
   if (c->stream)
     (void) hipStreamSynchronize(c->stream);
+  comm_release(c);
   void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_vmask, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_images_cam, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -812,16 +841,10 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
       c->normals_cap = c->n;
     }
     HIPCHK(c, hipMemsetAsync(c->d_normals, 0, sizeof(double) * 3 * c->n, st));
-    for (int64_t b0 = 0; b0 < c->n; b0 += chunk)
+    if ((rc = normals_pass(c, 0, c->n, st)) != AGH_OK)
     {
-      const int nb = (int) std::min<int64_t>(chunk, c->n - b0);
-      hipLaunchKernelGGL(k_iota, dim3((nb + 255) / 256), dim3(256), 0, st, c->d_samples, (int) b0, nb);
-      rc = taubin_frames(c, c->d_samples, nb, c->p.nn_radius_normals, c->d_frames, c->d_nt, true, st);
-      if (rc != AGH_OK)
-      {
-        c->err = "normals pass launch failed";
-        return rc;
-      }
+      c->err = "normals pass launch failed";
+      return rc;
     }
     c->has_normals = true;
   }
@@ -878,7 +901,7 @@ static int flags_to_status(Ctx* c, const int32_t* flags)
              "voxelise the cloud (localization.cpp:43) or reduce the radii";
     return AGH_ERR_CAPACITY;
   }
-  if (flags[0] & 2)
+  if ((flags[0] & 2) && !(flags[0] & 16))
   {
     c->err = "output buffer too small for the hypotheses found";
     return AGH_ERR_CAPACITY;
@@ -887,6 +910,14 @@ static int flags_to_status(Ctx* c, const int32_t* flags)
   {
     c->err = "a sample index is outside the cloud";
     return AGH_ERR_INVALID_ARGUMENT;
+  }
+  if (flags[0] & 16)
+  {
+    // sharded search: every rank reads the same segment headers, so every rank lands here and switches together
+    c->shard_full_exchange = true;
+    c->err = "a rank found more hypotheses than its exchange segment holds; the context now exchanges full-size segments: "
+             "repeat the call";
+    return AGH_ERR_CAPACITY;
   }
   return AGH_OK;
 }

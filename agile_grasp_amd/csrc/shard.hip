@@ -1,0 +1,776 @@
+// shard.hip -- one cloud's sample set sharded over the GPUs of a node (north star: "the sample set shards
+// across the 8 GPUs of one node with an RCCL all-gather of hypotheses over xGMI").
+//
+// The reference's two OpenMP loops (hand_search.cpp:77-80 findQuadrics, 135-138 findHands) run over independent samples
+// that read a shared immutable cloud and write their own result slots.  Rank g of G takes the contiguous slice
+// [g*S/G, (g+1)*S/G) of the sample list, runs the unchanged single-GPU chain (K1a..K2, K4) on it, and the ranks' compacted
+// lists are concatenated in rank order -- which is the reference's sample-major order.  The exchange is ONE in-place
+// ncclAllGather of fixed-size segments [160-byte header (count) | seg_records x agh_hypothesis], issued from here (host
+// code stays C++; no Python in the data path) on the search's stream, followed by one merge kernel.
+//
+// Where the reference's loops share state, the shards exchange it first:
+//  * calculates_antipodal: cloud_normals_ (hand_search.cpp:13-26) is filled by an all-points pass; each rank does a point
+//    range of it and the 3 x N doubles are all-gathered in place.  findQuadrics over the samples then overwrites the
+//    samples' own columns (hand_search.cpp:102): those normals are all-gathered too and scattered by every rank.
+//  * AGH_NORMALS_RAND50: the rand() stream is consumed in sample order (quadric.cpp:184), so a rank's first draw offset is
+//    the number of draws the earlier slices consume: one int per rank, all-gathered between K1b and K1c.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU deployment does not need it installed.
+// agh_comm_init_local replaces the all-gather by device copies between the contexts of one process (one host thread per
+// rank): RCCL refuses two ranks on one GPU, and this is how the schedule is validated on a single-GPU machine -- every
+// kernel and every offset is the same, only the transport differs.
+#include "agh_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+namespace agh
+{
+
+namespace
+{
+struct Rccl
+{
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+Rccl* rccl()
+{
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = std::getenv("AGH_RCCL_LIB");
+    const char* names[] = { env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
+    for (const char* n : names)
+      if (n && (r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+        break;
+    if (!r.lib)
+    {
+      r.err = "RCCL not found (librccl.so.1; set AGH_RCCL_LIB)";
+      return;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId)) dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank)) dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy)) dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather)) dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString)) dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+      r.err = "RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather";
+  });
+  return &r;
+}
+
+// n contexts of one process exchanging through device copies (agh_comm_init_local)
+struct LocalGroup
+{
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<const void*> send;
+  void barrier()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const uint64_t g = generation;
+    if (++arrived == n)
+    {
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    }
+    else
+      cv.wait(lk, [&] { return generation != g; });
+  }
+};
+}  // namespace
+
+struct Comm
+{
+  int rank = 0, n_ranks = 1;
+  ncclComm_t nccl = nullptr;
+  std::shared_ptr<LocalGroup> local;
+};
+
+void comm_release(Ctx* c)
+{
+  if (!c->comm)
+    return;
+  if (c->comm->nccl && rccl()->CommDestroy)
+    (void) rccl()->CommDestroy(c->comm->nccl);
+  delete c->comm;
+  c->comm = nullptr;
+}
+
+namespace
+{
+#define HIPCHK(ctx, expr)                                                                             \
+  do                                                                                                  \
+  {                                                                                                   \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+    {                                                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                \
+      return AGH_ERR_HIP;                                                                             \
+    }                                                                                                 \
+  } while (0)
+
+// In-place all-gather: rank r's contribution already sits at buf + r * bytes.
+int all_gather(Ctx* c, void* buf, size_t bytes, hipStream_t st)
+{
+  Comm* cm = c->comm;
+  if (bytes == 0 || (cm->n_ranks == 1 && !cm->nccl))
+    return AGH_OK;
+  if (cm->nccl)
+  {
+    const ncclResult_t r = rccl()->AllGather((const char*) buf + (size_t) cm->rank * bytes, buf, bytes, ncclChar, cm->nccl, st);
+    if (r != ncclSuccess)
+    {
+      c->err = std::string("ncclAllGather: ") + rccl()->GetErrorString(r);
+      return AGH_ERR_HIP;
+    }
+    return AGH_OK;
+  }
+  LocalGroup* g = cm->local.get();
+  HIPCHK(c, hipStreamSynchronize(st));  // my segment is complete
+  {
+    std::lock_guard<std::mutex> lk(g->m);
+    g->send[(size_t) cm->rank] = (const char*) buf + (size_t) cm->rank * bytes;
+  }
+  g->barrier();
+  for (int q = 0; q < cm->n_ranks; q++)
+    if (q != cm->rank)
+      HIPCHK(c, hipMemcpyAsync((char*) buf + (size_t) q * bytes, g->send[(size_t) q], bytes, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  g->barrier();  // nobody reuses a segment before everyone has copied it
+  return AGH_OK;
+}
+
+constexpr int kHeaderBytes = 160;  // one record's size: keeps the records of a segment 16-byte aligned
+
+__host__ __device__ inline int64_t shard_lo(int64_t n, int64_t r, int64_t G)
+{
+  return (n * r) / G;
+}
+
+// RAND50: draws my slice consumes (50 per neighbourhood of more than 50 points, quadric.cpp:177-193)
+__global__ void k_shard_draw_count(const int32_t* __restrict__ nt, int S, int64_t* __restrict__ out)
+{
+  int cnt = 0;
+  for (int i = threadIdx.x; i < S; i += 64)
+    cnt += nt[i] > 50 ? 50 : 0;
+  for (int o = 32; o > 0; o >>= 1)
+    cnt += __shfl_xor(cnt, o);
+  if (threadIdx.x == 0)
+    *out = cnt;
+}
+__global__ void k_shard_draw_base(const int64_t* __restrict__ counts, int rank, int32_t* __restrict__ total_io)
+{
+  int64_t b = 0;
+  for (int q = 0; q < rank; q++)
+    b += counts[q];
+  *total_io += (int32_t) b;
+}
+
+// the slice's sample normals (valid frames only) into my segment of the normals exchange buffer: 4 doubles per sample
+__global__ void k_shard_pack_normals(const agh_frame* __restrict__ frames, int S, double* __restrict__ seg)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S)
+    return;
+  const agh_frame& f = frames[i];
+  seg[4 * i + 0] = f.normal[0];
+  seg[4 * i + 1] = f.normal[1];
+  seg[4 * i + 2] = f.normal[2];
+  seg[4 * i + 3] = f.valid ? 1.0 : 0.0;
+}
+// cloud_normals_.col(indices[i]) = normal (hand_search.cpp:102) for every sample of every rank
+__global__ void k_shard_scatter_normals(const double* __restrict__ nbuf, int64_t seg_doubles, const int32_t* __restrict__ samples,
+  int64_t S, int G, double* __restrict__ normals, int n_points)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S)
+    return;
+  int q = (int) ((i * G) / S);  // owner of sample i: the q with lo(q) <= i < lo(q + 1)
+  while (q + 1 < G && shard_lo(S, q + 1, G) <= i)
+    q++;
+  while (q > 0 && shard_lo(S, q, G) > i)
+    q--;
+  const double* v = nbuf + (int64_t) q * seg_doubles + 4 * (i - shard_lo(S, q, G));
+  const int p = samples[i];
+  if (v[3] != 0.0 && p >= 0 && p < n_points)
+  {
+    normals[3 * (int64_t) p + 0] = v[0];
+    normals[3 * (int64_t) p + 1] = v[1];
+    normals[3 * (int64_t) p + 2] = v[2];
+  }
+}
+
+// Concatenate the ranks' segments in rank order: sample positions become positions in the full list, every record gets
+// this call's stamp, *n_out the total.  flags: 2 = the caller's buffer is too small, 16 = a rank found more hypotheses
+// than its segment holds (the segment header carries the true count).
+__global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__ xbuf, int64_t seg_bytes, int64_t seg_records,
+  int G, int64_t S, agh_hypothesis* __restrict__ out, int64_t cap, int64_t* __restrict__ n_out, uint8_t* __restrict__ keep,
+  int32_t* __restrict__ flags, int32_t epoch)
+{
+  __shared__ int64_t off[65];
+  __shared__ int over;
+  if (threadIdx.x == 0)
+  {
+    int64_t o = 0;
+    int ov = 0;
+    for (int q = 0; q < G; q++)
+    {
+      int64_t cnt = *reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes);
+      if (cnt > seg_records)
+      {
+        ov = 1;
+        cnt = seg_records;
+      }
+      off[q] = o;
+      o += cnt;
+    }
+    off[G] = o;
+    over = ov;
+    if (blockIdx.x == 0)
+    {
+      *n_out = o;
+      if (ov)
+        atomicOr(&flags[0], 16);
+      if (o > cap)
+        atomicOr(&flags[0], 2);
+    }
+  }
+  __syncthreads();
+  const int64_t total = off[G];
+  // 10 threads per record, 16 bytes each
+  for (int64_t t = (int64_t) blockIdx.x * 250 + threadIdx.x; threadIdx.x < 250 && t < total * 10; t += (int64_t) gridDim.x * 250)
+  {
+    const int64_t h = t / 10;
+    const int part = (int) (t % 10);
+    if (h >= cap)
+      break;
+    int q = 0;
+    while (q + 1 < G && off[q + 1] <= h)
+      q++;
+    const uint8_t* src = xbuf + (int64_t) q * seg_bytes + kHeaderBytes + (h - off[q]) * (int64_t) sizeof(agh_hypothesis);
+    uint4 v = reinterpret_cast<const uint4*>(src)[part];
+    if (part == 8)  // bytes 128..143: sample, orientation, cam_source, n_in_box
+      v.x = (unsigned) ((int) v.x + (int) shard_lo(S, q, G));
+    if (part == 9)  // bytes 144..159: flags, finger_index, depth_index, epoch
+    {
+      if (keep)
+        keep[h] = (uint8_t) ((v.x >> 16) & 0xffu);  // svm_keep
+      v.w = (unsigned) epoch;
+    }
+    reinterpret_cast<uint4*>(out + h)[part] = v;
+  }
+}
+
+template <typename T>
+int grow(Ctx* c, T** p, int64_t* have, int64_t want)
+{
+  if (want <= *have && *p)
+    return AGH_OK;
+  if (*p)
+    (void) hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  if (hipMalloc((void**) p, (size_t) std::max<int64_t>(want, 1) * sizeof(T)) != hipSuccess)
+  {
+    c->err = "out of device memory for the shard exchange buffers";
+    return AGH_ERR_HIP;
+  }
+  *have = want;
+  return AGH_OK;
+}
+
+int exchange_and_merge(Ctx* c, uint8_t* d_keep, hipStream_t st)
+{
+  Comm* cm = c->comm;
+  int rc = all_gather(c, c->d_xbuf, (size_t) c->shard_seg_bytes, st);
+  if (rc != AGH_OK)
+    return rc;
+  hipLaunchKernelGGL(k_shard_merge, dim3(256), dim3(256), 0, st, (const uint8_t*) c->d_xbuf, c->shard_seg_bytes, c->shard_seg_records,
+    cm->n_ranks, c->shard_S, c->shard_out, c->shard_cap, c->shard_nout, d_keep, c->d_flags, c->epoch);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+}  // namespace
+
+}  // namespace agh
+
+using namespace agh;
+
+extern "C" {
+
+void agh_shard_slice(int64_t n, int32_t rank, int32_t n_ranks, int64_t* lo, int64_t* hi)
+{
+  if (n_ranks < 1)
+    n_ranks = 1;
+  if (lo)
+    *lo = shard_lo(n, rank, n_ranks);
+  if (hi)
+    *hi = shard_lo(n, (int64_t) rank + 1, n_ranks);
+}
+
+int agh_comm_unique_id(uint8_t id[AGH_COMM_ID_BYTES])
+{
+  static_assert(AGH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  if (!id)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Rccl* r = rccl();
+  if (!r->err.empty())
+    return AGH_ERR_STATE;
+  ncclUniqueId u;
+  if (r->GetUniqueId(&u) != ncclSuccess)
+    return AGH_ERR_HIP;
+  std::memcpy(id, u.internal, AGH_COMM_ID_BYTES);
+  return AGH_OK;
+}
+
+int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[AGH_COMM_ID_BYTES])
+{
+  if (!ctx || !id)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+  {
+    c->err = "agh_comm_init: need 0 <= rank < n_ranks <= 64";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  if (c->comm)
+  {
+    c->err = "agh_comm_init: the context already belongs to a communicator";
+    return AGH_ERR_STATE;
+  }
+  Rccl* r = rccl();
+  if (!r->err.empty())
+  {
+    c->err = r->err;
+    return AGH_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, AGH_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t res = r->CommInitRank(&comm, n_ranks, u, rank);
+  if (res != ncclSuccess)
+  {
+    c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
+    return AGH_ERR_HIP;
+  }
+  c->comm = new Comm();
+  c->comm->rank = rank;
+  c->comm->n_ranks = n_ranks;
+  c->comm->nccl = comm;
+  return AGH_OK;
+}
+
+int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
+{
+  if (!ctxs || n_ranks < 1 || n_ranks > 64)
+    return AGH_ERR_INVALID_ARGUMENT;
+  for (int q = 0; q < n_ranks; q++)
+    if (!ctxs[q] || ctxs[q]->c.comm)
+      return AGH_ERR_STATE;
+  std::shared_ptr<LocalGroup> g(new LocalGroup());
+  g->n = n_ranks;
+  g->send.assign((size_t) n_ranks, nullptr);
+  for (int q = 0; q < n_ranks; q++)
+  {
+    Comm* cm = new Comm();
+    cm->rank = q;
+    cm->n_ranks = n_ranks;
+    cm->local = g;
+    ctxs[q]->c.comm = cm;
+  }
+  return AGH_OK;
+}
+
+int agh_comm_destroy(agh_ctx* ctx)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  (void) hipSetDevice(ctx->c.device);
+  (void) hipDeviceSynchronize();
+  comm_release(&ctx->c);
+  return AGH_OK;
+}
+
+int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records)
+{
+  if (!ctx || records < 0)
+    return AGH_ERR_INVALID_ARGUMENT;
+  ctx->c.shard_seg_override = records;
+  ctx->c.shard_full_exchange = false;
+  return AGH_OK;
+}
+
+int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (rank)
+    *rank = ctx->c.comm ? ctx->c.comm->rank : 0;
+  if (n_ranks)
+    *n_ranks = ctx->c.comm ? ctx->c.comm->n_ranks : 1;
+  return AGH_OK;
+}
+
+int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->comm)
+  {
+    c->err = "agh_find_hands_sharded: no communicator (agh_comm_init)";
+    return AGH_ERR_STATE;
+  }
+  if (!c->has_cloud)
+  {
+    c->err = "agh_find_hands_sharded: no cloud set";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (n_samples < 0 || n_samples > (1 << 24) || (n_samples > 0 && (!d_sample_idx || !d_out)) || !d_n_out || cap < 0)
+  {
+    c->err = "agh_find_hands_sharded: bad arguments";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  const bool rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50;
+  if (rand_mode && calculates_antipodal && c->comm->n_ranks > 1)
+  {
+    // the all-points pass would need the draw counts of every earlier point range before its first frame kernel
+    c->err = "agh_find_hands_sharded: calculates_antipodal with AGH_NORMALS_RAND50 is not sharded (the rand() stream runs "
+             "through all N points in order); use deterministic normals or one GPU for this offline pass";
+    return AGH_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  const int G = c->comm->n_ranks, r = c->comm->rank;
+  const int64_t S = n_samples;
+  const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = hi - lo;
+  const int64_t Smax = (S + G - 1) / G;
+  int64_t seg_records = std::min<int64_t>(8 * Smax, std::max<int64_t>(2 * Smax, 1024));
+  if (c->shard_seg_override > 0)
+    seg_records = std::min<int64_t>(8 * Smax, c->shard_seg_override);
+  if (c->shard_full_exchange)
+    seg_records = 8 * Smax;
+  const int64_t seg_bytes = kHeaderBytes + seg_records * (int64_t) sizeof(agh_hypothesis);
+  const int64_t pcnt = (c->n + G - 1) / G;  // points per rank of the all-points pass
+  int rc = ensure_call_buffers(c, std::max<int64_t>(Smax, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
+  if (rc != AGH_OK)
+    return rc;
+  if ((rc = grow(c, &c->d_xbuf, &c->xbuf_bytes, (int64_t) G * seg_bytes)) != AGH_OK)
+    return rc;
+  if (!c->d_xcnt)
+  {
+    int64_t have = 0;
+    if ((rc = grow(c, &c->d_xcnt, &have, 128)) != AGH_OK)
+      return rc;
+  }
+  if (rand_mode && (rc = ensure_draws(c, 50 * S, st)) != AGH_OK)
+    return rc;
+  timing_begin(c, st);
+  c->zero_flags_pending = true;
+  c->epoch = next_epoch();
+  c->last_s = Sr;
+  c->last_nout = -1;
+  c->shard_seg_records = seg_records;
+  c->shard_seg_bytes = seg_bytes;
+  c->shard_S = S;
+  c->shard_out = d_out;
+  c->shard_cap = cap;
+  c->shard_nout = d_n_out;
+  uint8_t* my_seg = c->d_xbuf + (int64_t) r * seg_bytes;
+  agh_hypothesis* my_out = reinterpret_cast<agh_hypothesis*>(my_seg + kHeaderBytes);
+  int64_t* my_count = reinterpret_cast<int64_t*>(my_seg);
+  // what agh_classify* / the introspection getters see afterwards is this rank's own part
+  c->last_cap = seg_records;
+  c->d_out_last = my_out;
+  c->d_nout_last = my_count;
+  if (S == 0 || c->n == 0)
+  {
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
+    c->zero_flags_pending = false;
+    HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
+    HIPCHK(c, hipMemsetAsync(c->d_xbuf, 0, (size_t) G * seg_bytes, st));
+    c->last_s = 0;
+    return AGH_OK;
+  }
+  const int32_t* my_idx = d_sample_idx + lo;
+  if (calculates_antipodal)
+  {
+    // hand_search.cpp:13-26 sharded by point range; the buffer is padded to G equal ranges for the in-place all-gather
+    if ((int64_t) G * pcnt > c->normals_cap || !c->d_normals)  // (normals_cap counts points)
+    {
+      if (c->d_normals)
+        (void) hipFree(c->d_normals);
+      c->d_normals = nullptr;
+      c->normals_cap = 0;
+      HIPCHK(c, hipMalloc((void**) &c->d_normals, sizeof(double) * 3 * (size_t) (G * pcnt)));
+      c->normals_cap = (int64_t) G * pcnt;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_normals, 0, sizeof(double) * 3 * (size_t) (G * pcnt), st));
+    const int64_t p0 = std::min<int64_t>(c->n, (int64_t) r * pcnt), p1 = std::min<int64_t>(c->n, (int64_t) (r + 1) * pcnt);
+    if ((rc = normals_pass(c, p0, p1, st)) != AGH_OK)
+    {
+      c->err = "normals pass launch failed";
+      return rc;
+    }
+    if ((rc = all_gather(c, c->d_normals, sizeof(double) * 3 * (size_t) pcnt, st)) != AGH_OK)
+      return rc;
+    c->has_normals = true;
+  }
+  if (Sr > 0)
+  {
+    if ((rc = taubin_moments_eigen(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_nt, st)) != AGH_OK)
+    {
+      c->err = "taubin launch failed";
+      return rc;
+    }
+  }
+  else if (c->zero_flags_pending)
+  {
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
+    c->zero_flags_pending = false;
+  }
+  if (rand_mode && G > 1)
+  {
+    hipLaunchKernelGGL(k_shard_draw_count, dim3(1), dim3(64), 0, st, (const int32_t*) c->d_nt, (int) Sr, c->d_xcnt + r);
+    if ((rc = all_gather(c, c->d_xcnt, sizeof(int64_t), st)) != AGH_OK)
+      return rc;
+    hipLaunchKernelGGL(k_shard_draw_base, dim3(1), dim3(1), 0, st, (const int64_t*) c->d_xcnt, r, c->d_flags + 2);
+  }
+  if (Sr > 0 && (rc = taubin_frame_stage(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_frames, c->d_nt, calculates_antipodal != 0, st)) != AGH_OK)
+  {
+    c->err = "taubin launch failed";
+    return rc;
+  }
+  if (calculates_antipodal && G > 1)
+  {
+    const int64_t seg_d = 4 * Smax;
+    if ((rc = grow(c, &c->d_nbuf, &c->nbuf_doubles, (int64_t) G * seg_d)) != AGH_OK)
+      return rc;
+    if (Sr > 0)
+      hipLaunchKernelGGL(k_shard_pack_normals, dim3((unsigned) ((Sr + 255) / 256)), dim3(256), 0, st, (const agh_frame*) c->d_frames,
+        (int) Sr, c->d_nbuf + (int64_t) r * seg_d);
+    if ((rc = all_gather(c, c->d_nbuf, sizeof(double) * (size_t) seg_d, st)) != AGH_OK)
+      return rc;
+    hipLaunchKernelGGL(k_shard_scatter_normals, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, (const double*) c->d_nbuf, seg_d,
+      d_sample_idx, S, G, c->d_normals, (int) c->n);
+  }
+  if (Sr > 0)
+  {
+    if ((rc = hand_sweep(c, my_idx, Sr, calculates_antipodal != 0, st)) != AGH_OK)
+    {
+      c->err = "hand sweep launch failed";
+      return rc;
+    }
+    // K4 straight into my segment of the exchange buffer; an overflow of the segment shows as count > seg_records
+    if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st)) != AGH_OK)
+    {
+      c->err = "compaction launch failed";
+      return rc;
+    }
+  }
+  else
+    HIPCHK(c, hipMemsetAsync(my_count, 0, sizeof(int64_t), st));
+  if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
+    return rc;
+  timing_mark(c, "shard_exchange", st);
+  return AGH_OK;
+}
+
+int agh_classify_sharded_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (!c->comm || !c->shard_out)
+  {
+    c->err = "agh_classify_sharded: needs a preceding agh_find_hands_sharded";
+    return AGH_ERR_STATE;
+  }
+  if (!c->has_svm)
+  {
+    c->err = "agh_classify_sharded: no SVM loaded";
+    return AGH_ERR_NO_SVM;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  // K3 on my own hypotheses: their images are here, svm_keep lands in my segment's records
+  int rc = hog_svm(c, std::min<int64_t>(c->last_s * 8, c->shard_seg_records), nullptr, st);
+  if (rc != AGH_OK)
+    return rc;
+  return exchange_and_merge(c, d_keep, st);
+}
+
+static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
+{
+  int32_t flags[8];
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+  if (n)
+    HIPCHK(c, hipMemcpyAsync(n, c->shard_nout, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (flags[0] & 16)
+    return 16;
+  if (flags[0] & 1)
+  {
+    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity";
+    return AGH_ERR_CAPACITY;
+  }
+  if (flags[0] & 2)
+  {
+    c->err = "output buffer too small for the hypotheses found";
+    return AGH_ERR_CAPACITY;
+  }
+  if (flags[0] & 4)
+  {
+    c->err = "a sample index is outside the cloud";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  return AGH_OK;
+}
+
+int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out)
+{
+  if (!ctx || !n_out)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  *n_out = 0;
+  if (!c->has_cloud)
+  {
+    c->err = "agh_find_hands_sharded: no cloud set";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (n_samples < 0 || (n_samples > 0 && !sample_idx) || cap < 0 || (cap > 0 && !out))
+  {
+    c->err = "agh_find_hands_sharded: bad arguments";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  for (int64_t i = 0; i < n_samples; i++)
+    if (sample_idx[i] < 0 || sample_idx[i] >= c->n)
+    {
+      c->err = "agh_find_hands_sharded: sample index out of range";
+      return AGH_ERR_INVALID_ARGUMENT;
+    }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
+  if (rc != AGH_OK)
+    return rc;
+  if (n_samples > c->idx_cap || !c->d_idx_own)
+  {
+    if (c->d_idx_own)
+      (void) hipFree(c->d_idx_own);
+    c->d_idx_own = nullptr;
+    c->idx_cap = 0;
+    HIPCHK(c, hipMalloc((void**) &c->d_idx_own, sizeof(int32_t) * (size_t) std::max<int64_t>(n_samples, 1024)));
+    c->idx_cap = std::max<int64_t>(n_samples, 1024);
+  }
+  if (n_samples > 0)
+    HIPCHK(c, hipMemcpyAsync(c->d_idx_own, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
+  int64_t n = 0;
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    // (s_cap >= n_samples, so d_out_own holds the complete list: 8 slots per sample)
+    rc = agh_find_hands_sharded_device(ctx, c->d_idx_own, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
+      c->stream);
+    if (rc != AGH_OK)
+    {
+      (void) hipStreamSynchronize(c->stream);
+      return rc;
+    }
+    rc = shard_flags(c, c->stream, &n);
+    if (rc != 16)
+      break;
+    // a rank found more than its segment holds: every rank sees the same headers, so every rank repeats with 8 per sample
+    c->shard_full_exchange = true;
+    rc = AGH_ERR_CAPACITY;
+    c->err = "a rank found more hypotheses than its exchange segment holds";
+  }
+  if (rc != AGH_OK)
+    return rc;
+  *n_out = n;
+  if (n > cap)
+  {
+    c->err = "output buffer too small for the hypotheses found";
+    return AGH_ERR_CAPACITY;
+  }
+  if (n > 0)
+    HIPCHK(c, hipMemcpy(out, c->d_out_own, sizeof(agh_hypothesis) * n, hipMemcpyDeviceToHost));
+  // (last_nout stays -1 for the merged list: the per-rank state the getters see is this rank's own part)
+  int64_t mine = 0;
+  HIPCHK(c, hipMemcpy(&mine, c->d_nout_last, sizeof(int64_t), hipMemcpyDeviceToHost));
+  c->last_nout = std::min<int64_t>(mine, c->shard_seg_records);
+  return AGH_OK;
+}
+
+int agh_classify_sharded(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64_t cap, int64_t* n_kept)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (n_kept)
+    *n_kept = 0;
+  if (!c->comm || !c->shard_out || c->shard_out != c->d_out_own)
+  {
+    c->err = "agh_classify_sharded: needs a preceding agh_find_hands_sharded (host variant)";
+    return AGH_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t room = c->s_cap * 8;
+  if (room > c->keep_cap)
+  {
+    if (c->d_keep)
+      (void) hipFree(c->d_keep);
+    if (c->d_svm_sums)
+      (void) hipFree(c->d_svm_sums);
+    c->d_keep = nullptr;
+    c->d_svm_sums = nullptr;
+    c->keep_cap = 0;
+    HIPCHK(c, hipMalloc((void**) &c->d_keep, (size_t) room));
+    HIPCHK(c, hipMalloc((void**) &c->d_svm_sums, (size_t) room * sizeof(double)));
+    c->keep_cap = room;
+  }
+  int rc = agh_classify_sharded_device(ctx, c->d_keep, c->stream);
+  if (rc != AGH_OK)
+    return rc;
+  int64_t n = 0;
+  rc = shard_flags(c, c->stream, &n);
+  if (rc != AGH_OK)
+    return rc == 16 ? AGH_ERR_CAPACITY : rc;
+  if (n > cap)
+  {
+    c->err = "agh_classify_sharded: buffers too small";
+    return AGH_ERR_CAPACITY;
+  }
+  if (n > 0 && out)
+    HIPCHK(c, hipMemcpy(out, c->d_out_own, sizeof(agh_hypothesis) * n, hipMemcpyDeviceToHost));
+  if (n > 0 && keep)
+  {
+    HIPCHK(c, hipMemcpy(keep, c->d_keep, (size_t) n, hipMemcpyDeviceToHost));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++)
+      k += keep[i] ? 1 : 0;
+    if (n_kept)
+      *n_kept = k;
+  }
+  return AGH_OK;
+}
+
+}  // extern "C"

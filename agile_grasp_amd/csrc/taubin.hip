@@ -1280,6 +1280,15 @@ __global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* _
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st)
 {
+  const int rc = taubin_moments_eigen(c, d_samples, S, radius, d_nt, st);
+  if (rc != AGH_OK || c->debug_stop_moments)
+    return rc;
+  return taubin_frame_stage(c, d_samples, S, radius, d_frames, d_nt, write_normals, st);
+}
+
+// K1a + K1b for S samples (the sharded search exchanges the RAND50 draw counts between this stage and the next)
+int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st)
+{
   if (S == 0)
     return AGH_OK;
   GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
@@ -1312,6 +1321,16 @@ int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, ag
   hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4 + 1), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
     c->d_flags, (const int*) c->d_weight, c->d_order);
   timing_mark(c, "taubin_eigen", st);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+// K1c (and the RAND50 draw offsets, continuing from the count in d_flags[2]) for the same S samples
+int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
+  bool write_normals, hipStream_t st)
+{
+  if (S == 0)
+    return AGH_OK;
+  const int Si = (int) S;
   const int rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50 ? 1 : 0;
   if (rand_mode)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);

@@ -1,41 +1,49 @@
-"""Multi-GPU sharding of the grasp search (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI).
+"""Bookkeeping of the sample-sharded search (one process per GPU), mirrored from csrc/shard.hip for the host side of
+bench.py and for the CPU (gloo) tests.  The data path itself is C++ + RCCL: agh_find_hands_sharded_device.
 
-The path shards over independent units and needs no data-path collective:
-  * samples of one cloud are independent work items (reference OMP loops A/B, hand_search.cpp:77-80,135-138):
-    ``shard_slice`` hands rank g the contiguous slice g of the sample list, so concatenating the ranks' result
-    lists in rank order reproduces the single-GPU (= reference) order;
-  * clouds of a batch are independent: ``bench.py --gpus N`` gives every rank one cloud.
-The only exchange is the optional hand-over of the results: ONE all-gather per step of a fixed-size buffer
-``[header | 8*S records of 160 B]`` whose header carries the rank's record count (no variable-count exchange;
-xGMI ring all-gathers of a few MB are latency bound, so one large fixed collective beats several small ones).
+Rank g of G takes the contiguous slice [g*S/G, (g+1)*S/G) of the sample list (agh_shard_slice) -- the reference's OpenMP
+loops run over independent samples (hand_search.cpp:77-80, 135-138), so the ranks' lists concatenated in rank order ARE
+the reference's sample-major list.  Each rank contributes one fixed-size segment
+``[160-byte header: int64 count | seg_records records of 160 B]`` to ONE in-place all-gather.
 """
 from __future__ import annotations
 
 import numpy as np
 
 RECORD_BYTES = 160
+HEADER_BYTES = 160
 
 
 def shard_slice(n_items: int, rank: int, world: int) -> slice:
-    """Contiguous, balanced slice of rank ``rank`` (first ``n_items % world`` ranks get one extra item)."""
-    q, r = divmod(n_items, world)
-    lo = rank * q + min(rank, r)
-    return slice(lo, lo + q + (1 if rank < r else 0))
+    """The slice rank ``rank`` of ``world`` takes (the C ABI's agh_shard_slice; needs no GPU)."""
+    from . import binding
+
+    lo, hi = binding.shard_slice(n_items, rank, world)
+    return slice(lo, hi)
 
 
-def buffer_bytes(n_samples: int) -> int:
-    """Bytes of one rank's exchange buffer: a 160-byte header (int64 count first) + 8 slots per sample."""
-    return (8 * n_samples + 1) * RECORD_BYTES
+def segment_records(n_samples: int, world: int, full: bool = False) -> int:
+    """Record slots of one rank's segment: max(2 ceil(S/G), 1024), never more than 8 ceil(S/G) (`full`: 8 ceil(S/G))."""
+    smax = -(-n_samples // world)
+    return 8 * smax if full else min(8 * smax, max(2 * smax, 1024))
 
 
-def buffer_bytes_records(n_records: int) -> int:
-    """Bytes of the buffer prefix holding the header and the first ``n_records`` record slots.  Exchanging a prefix
-    is valid because records are compacted to the front; receivers compare the header count with the slots sent."""
-    return (n_records + 1) * RECORD_BYTES
+def segment_bytes(seg_records: int) -> int:
+    return HEADER_BYTES + seg_records * RECORD_BYTES
+
+
+def pack_segment(records: np.ndarray, seg_records: int) -> np.ndarray:
+    """A rank's compacted records as its exchange segment.  The header carries the TRUE count; records beyond the
+    segment are dropped, which the receivers detect (count > seg_records)."""
+    buf = np.zeros(segment_bytes(seg_records), np.uint8)
+    buf[:8] = np.frombuffer(np.int64(len(records)).tobytes(), np.uint8)
+    k = min(len(records), seg_records)
+    buf[HEADER_BYTES:HEADER_BYTES + k * RECORD_BYTES] = np.frombuffer(records[:k].tobytes(), np.uint8)
+    return buf
 
 
 def all_gather_records(local_t, gather_t):
-    """One collective: every rank contributes its whole fixed-size buffer; gather_t is world * len(local_t)."""
+    """One collective through torch.distributed (the CPU tests' gloo, or RCCL when bench.py falls back to torch)."""
     import torch.distributed as dist
 
     if dist.get_backend() == "nccl":
@@ -49,25 +57,18 @@ def all_gather_records(local_t, gather_t):
     return gather_t
 
 
-def unpack_gathered(gathered: np.ndarray, world: int, dtype: np.dtype):
-    """Split an all-gathered byte buffer into the per-rank record arrays (rank order = reference order)."""
-    per = gathered.size // world
+def merge_segments(gathered: np.ndarray, world: int, n_samples: int, seg_records: int, dtype: np.dtype) -> np.ndarray:
+    """k_shard_merge on the host: concatenate the ranks' records in rank order, sample positions re-based to the full
+    list.  Raises OverflowError if a rank found more than its segment holds (the caller repeats with full segments)."""
+    per = segment_bytes(seg_records)
+    assert gathered.size == world * per
     out = []
     for g in range(world):
         blob = gathered[g * per:(g + 1) * per]
         n = int(np.frombuffer(blob[:8].tobytes(), np.int64)[0])
-        if (n + 1) * RECORD_BYTES > per:
-            raise OverflowError(f"rank {g} produced {n} records but only {per // RECORD_BYTES - 1} slots were exchanged")
-        recs = np.frombuffer(blob[RECORD_BYTES:RECORD_BYTES + n * RECORD_BYTES].tobytes(), dtype)
+        if n > seg_records:
+            raise OverflowError(f"rank {g} found {n} hypotheses, its segment holds {seg_records}")
+        recs = np.frombuffer(blob[HEADER_BYTES:HEADER_BYTES + n * RECORD_BYTES].tobytes(), dtype).copy()
+        recs["sample"] += shard_slice(n_samples, g, world).start
         out.append(recs)
-    return out
-
-
-def merge_sample_sharded(per_rank_records, slices):
-    """Concatenate sample-sharded results, re-basing the per-rank sample positions to the global sample list."""
-    merged = []
-    for recs, sl in zip(per_rank_records, slices):
-        r = recs.copy()
-        r["sample"] += sl.start
-        merged.append(r)
-    return np.concatenate(merged) if merged else np.zeros(0)
+    return np.concatenate(out) if out else np.zeros(0, dtype)

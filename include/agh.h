@@ -228,6 +228,50 @@ int agh_save_svm_file_ex(const char* path, int32_t kernel_type, const float* sv,
 int agh_load_svm_model(agh_ctx* ctx, int32_t kernel_type, const float* sv, int32_t n_sv, int32_t n_weights,
   const double* alpha, double rho);
 
+/* ---- multi-GPU: the sample set of ONE cloud sharded over the GPUs of a node --------------------------
+ * The reference's two OpenMP loops run over independent samples (hand_search.cpp:77-80, 135-138); here rank g of G takes
+ * the contiguous slice [g*S/G, (g+1)*S/G) of the sample list, so the concatenation of the ranks' results in rank order IS
+ * the reference's sample-major list.  One process per GPU, one context per process; every rank sets the SAME cloud
+ * (agh_set_cloud*) and passes the SAME sample list.  The only data-path communication is RCCL all-gathers over xGMI,
+ * issued from this library on the search's stream:
+ *   - the ranks' compacted hypothesis lists (one all-gather; fixed-size segments, see agh_find_hands_sharded_device);
+ *   - with calculates_antipodal: the all-points normals pass is sharded by point range and cloud_normals_ (3 x N doubles,
+ *     hand_search.cpp:13-26) is all-gathered before the hand search, and so are the samples' own normals
+ *     (hand_search.cpp:102); with AGH_NORMALS_RAND50: the ranks' rand() draw counts (one int each).
+ * The merged list is byte-identical to the single-GPU list apart from the per-call stamp.
+ *
+ * agh_comm_unique_id: ncclGetUniqueId; call on ONE rank and hand the 128 bytes to the others out of band (MPI, a
+ * torch.distributed broadcast, a file).  agh_comm_init: ncclCommInitRank on the context's device (collective: every rank
+ * calls it).  agh_comm_init_local: n contexts of THIS process (one host thread each; they may share a device) exchange
+ * through device copies instead of RCCL -- RCCL refuses two ranks on one GPU, and this is how the sharded schedule is
+ * validated on a single-GPU machine.  A context belongs to at most one communicator. */
+#define AGH_COMM_ID_BYTES 128
+int agh_comm_unique_id(uint8_t id[AGH_COMM_ID_BYTES]);
+int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[AGH_COMM_ID_BYTES]);
+int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks);
+int agh_comm_destroy(agh_ctx* ctx);
+int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks); /* 0 / 1 without a communicator */
+/* Tuning: record slots of one rank's exchange segment (0 = the default described at agh_find_hands_sharded_device; values
+ * above 8 per sample are clipped).  Every rank must use the same value. */
+int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records);
+/* The slice of an n-item list that rank `rank` of `n_ranks` takes: [*lo, *hi). */
+void agh_shard_slice(int64_t n, int32_t rank, int32_t n_ranks, int64_t* lo, int64_t* hi);
+/* HandSearch::findHands with the samples sharded over the communicator's ranks (collective).  Arguments as for
+ * agh_find_hands_device; on return (asynchronously on hip_stream) every rank's d_out holds the complete list and
+ * *d_n_out its length.  Each rank contributes a segment of max(2 ceil(S/G), 1024) records (never more than 8 ceil(S/G)): scenes
+ * yield well under one hypothesis per sample, and xGMI all-gathers of this size are latency bound.  If a rank found more,
+ * the call reports AGH_ERR_CAPACITY at the next agh_synchronize / in the host variant and switches the context to
+ * full-size segments (8 per sample) for the following calls; the host variant retries by itself. */
+int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
+int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out);
+/* Learning::classify after a sharded search (collective): every rank classifies the hypotheses of its own samples (their
+ * images are local), the labels travel with a second all-gather of the segments; d_out of the search is updated in
+ * place (svm_keep), d_keep (optional, room for the search's cap) receives the flags in list order. */
+int agh_classify_sharded_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream);
+int agh_classify_sharded(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64_t cap, int64_t* n_kept);
+
 /* Introspection for parity tests / plotting (host buffers). */
 int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap);
 int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, int64_t cap);

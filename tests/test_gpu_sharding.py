@@ -1,0 +1,167 @@
+"""The sample-sharded search (csrc/shard.hip) on the GPU.  A single-GPU box cannot host two RCCL ranks, so the G-rank
+schedule runs on G contexts of one process, one host thread each, whose communicator exchanges through device copies
+(agh_comm_init_local): kernels, offsets and buffers are exactly those of the RCCL path, only the transport differs.
+RCCL itself (dlopen, ncclCommInitRank, ncclAllGather on the search's stream) is exercised as a one-rank communicator."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("sample", "orientation", "cam_source", "n_in_box", "half_antipodal", "full_antipodal", "finger_index", "depth_index",
+          "axis", "approach", "binormal", "bottom", "surface", "width", "valid")
+
+
+def _run_ranks(ctxs, fn):
+    """fn(rank, ctx) on one thread per rank (the collectives block until every rank arrives)."""
+    out, err = [None] * len(ctxs), [None] * len(ctxs)
+
+    def work(r):
+        try:
+            out[r] = fn(r, ctxs[r])
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in th), "a rank hangs in a collective"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def _group(sc, G, **kw):
+    from agile_grasp_amd import binding
+
+    ctxs = [binding.Context(sc.cam_origins, **kw) for _ in range(G)]
+    for c in ctxs:
+        c.set_cloud(sc.xyz, sc.cam)  # every rank holds the same cloud
+    binding.comm_init_local(ctxs)
+    return ctxs
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_sharded_search_equals_single_gpu(small_scene, svm_model, G):
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    one.load_svm(*svm_model)
+    ref_keep = one.classify()
+    ctxs = _group(sc, G)
+    for c in ctxs:
+        c.load_svm(*svm_model)
+    res = _run_ranks(ctxs, lambda r, c: (c.find_hands_sharded(sc.samples), c.classify_sharded()))
+    for r, (hyps, (recs, keep)) in enumerate(res):
+        _same(hyps, ref)  # every rank holds the complete list
+        assert len(set(hyps["epoch"].tolist())) == 1 and hyps["epoch"][0] != 0
+        _same(recs, ref)
+        assert np.array_equal(keep, ref_keep) and np.array_equal(recs["svm_keep"], ref_keep)
+        assert ctxs[r].comm_rank() == (r, G)
+    # a rank's own getters describe its slice
+    lo, hi = binding.shard_slice(sc.samples.size, 1, G)
+    assert len(ctxs[1].frames()) == hi - lo
+    assert int(ref_keep.sum()) > 0 and len(ref) > 50
+
+
+def test_sharded_antipodal_pass(tiny_scene):
+    """calculates_antipodal: the all-points normals pass sharded by point range, cloud_normals_ and the samples' own
+    normals all-gathered before the hand search (hand_search.cpp:13-26, 102)."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples, calculates_antipodal=True)
+    ref_normals = one.normals()
+    assert ref["half_antipodal"].sum() > 0
+    ctxs = _group(sc, 3)
+    res = _run_ranks(ctxs, lambda r, c: (c.find_hands_sharded(sc.samples, calculates_antipodal=True), c.normals()))
+    for hyps, normals in res:
+        _same(hyps, ref)
+        assert np.array_equal(normals, ref_normals)
+
+
+def test_sharded_rand50_mode(small_scene):
+    """The reference's production mode draws 50 x rand() % n per neighbourhood in sample order (quadric.cpp:177-193): a
+    rank's first draw offset is what the earlier slices consume."""
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    one = binding.Context(sc.cam_origins, normals_mode=binding.NORMALS_RAND50, rand_seed=5)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    ctxs = _group(sc, 4, normals_mode=binding.NORMALS_RAND50, rand_seed=5)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        _same(hyps, ref)
+    with pytest.raises(binding.AghError) as e:  # the offline all-points pass is not sharded in this mode: loud
+        _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples, calculates_antipodal=True))
+    assert e.value.code == -8
+
+
+def test_segment_overflow_switches_every_rank_to_full_segments(small_scene):
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    ctxs = _group(sc, 2)
+    for c in ctxs:
+        c.comm_set_segment_records(8)  # far too small: a rank finds ~50
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):  # the host variant retries by itself
+        _same(hyps, ref)
+
+
+def test_sharded_edge_cases(tiny_scene):
+    """More ranks than samples (empty slices), an empty sample list, a communicator of one."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    few = sc.samples[:3]
+    ref = one.find_hands(few)
+    ctxs = _group(sc, 5)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(few)):
+        _same(hyps, ref)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(np.zeros(0, np.int32))):
+        assert len(hyps) == 0
+    solo = _group(sc, 1)
+    _same(solo[0].find_hands_sharded(sc.samples), one.find_hands(sc.samples))
+    with pytest.raises(binding.AghError):
+        one.find_hands_sharded(sc.samples)  # no communicator
+
+
+def test_rccl_communicator_of_one(tiny_scene, svm_model):
+    """RCCL bound at run time, ncclCommInitRank on the context's device, ncclAllGather on the search's stream."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctx = binding.Context(sc.cam_origins)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    ref = ctx.find_hands(sc.samples)
+    ctx.load_svm(*svm_model)
+    ref_keep = ctx.classify()
+    ctx.comm_init(0, 1, binding.comm_unique_id())
+    assert ctx.comm_rank() == (0, 1)
+    hyps = ctx.find_hands_sharded(sc.samples)
+    _same(hyps, ref)
+    recs, keep = ctx.classify_sharded()
+    assert np.array_equal(keep, ref_keep)
+    anti = ctx.find_hands_sharded(sc.samples, calculates_antipodal=True)
+    ctx.comm_destroy()
+    _same(anti, ctx.find_hands(sc.samples, calculates_antipodal=True))
