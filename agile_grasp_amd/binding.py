@@ -446,6 +446,9 @@ class Context:
     def find_hands_sharded_torch(self, samples_t, out_t, nout_t, calculates_antipodal: bool = False, stream=None):
         S = samples_t.shape[0]
         cap = out_t.numel() // 160
+        r, g = self.comm_rank()
+        lo, hi = shard_slice(S, r, g)
+        self.last_samples = hi - lo
         self._check(self.lib.agh_find_hands_sharded_device(
             self._h, C.c_void_p(samples_t.data_ptr()), C.c_int64(S), C.c_int(1 if calculates_antipodal else 0),
             C.c_void_p(out_t.data_ptr()), C.c_int64(cap), C.c_void_p(nout_t.data_ptr()),

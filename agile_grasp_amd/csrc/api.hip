@@ -1006,7 +1006,16 @@ int agh_synchronize(agh_ctx* ctx)
       }
   }
 #endif
-  return check_flags(c, c->stream);
+  const int rc = check_flags(c, c->stream);
+  if (rc == AGH_OK && c->last_nout < 0 && c->d_nout_last)  // the count of an asynchronous call, now known to the host
+  {
+    int64_t n = 0;
+    if (hipMemcpy(&n, c->d_nout_last, sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess)
+      c->last_nout = std::min<int64_t>(n, c->last_cap);
+    else
+      (void) hipGetLastError();  // (the caller may have released its buffer: not an error of this call)
+  }
+  return rc;
 }
 
 int agh_get_epoch(agh_ctx* ctx, int32_t* epoch, int64_t* n_hyp)

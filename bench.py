@@ -1,21 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- grasp hypotheses/sec of the MI355X-native HandSearch::findHands path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4] [--normals det|rand50]
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4] [--normals det|rand50] [--shard samples|clouds]
 
-One "step" = one pass of the hot path over one cloud whose points and sample indices are already resident in
-HBM: uniform-grid build (the reference's kd-tree build, hand_search.cpp:10-11) -> Taubin moments / eigen / frame
-(findQuadrics) -> hand sweep (findHands) -> compaction [-> HOG + linear SVM for C3].  N = 1 runs BASELINE config C2
-(two-view 300k-point cloud, 2000 samples; quadric fit + hand sweep) -- the configuration the metric is quoted on.
-For N > 1 every rank owns one cloud of the C5 batch (seeds 10..), runs the same per-GPU work, and the fixed-slot
-hypothesis records are all-gathered over RCCL/xGMI (one collective per step): weak scaling, value = hypotheses
-of all ranks per second.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one cloud whose points and sample indices are already resident in HBM:
+uniform-grid build (the reference's kd-tree build, hand_search.cpp:10-11) -> Taubin moments / eigen / frame
+(findQuadrics) -> hand sweep (findHands) -> compaction [-> HOG + linear SVM for C3].
+
+N = 1 runs BASELINE config C2 (two-view 300k-point cloud, 2000 samples; quadric fit + hand sweep) -- the configuration the
+metric is quoted on.
+
+N > 1, default (--shard samples): the SAME cloud and the SAME 2000 samples, the sample set sharded over the N GPUs
+(rank g searches samples [g S/N, (g+1) S/N)); every rank builds the search grid of the cloud, and the ranks' hypothesis
+lists are exchanged by ONE RCCL all-gather per step issued by the library itself (agh_find_hands_sharded_device, C++ ->
+ncclAllGather on the search's stream over xGMI).  Total work is fixed: "scaling": "strong"; value = hypotheses of the
+merged list per second.  This is the north star's sharding; it pays only when the sample count warrants it (2000 samples
+leave 250 work-groups per GPU at N = 8: see DESIGN.md section 6).
+--shard clouds: every rank owns one cloud of the C5 batch (seeds 10..) and searches all of its samples; the results are
+all-gathered the same way (weak scaling; the mode for a stream of independent clouds).
+
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,29 +43,37 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def cpu_baseline(sc, n_sub: int, normals_mode: int, classify: bool, svm):
     """The oracle (a CPU port of the reference's OpenMP path: static schedule over the samples, hand_search.cpp:77-79,
     135-137) timed on this box's host cores on the same cloud.  The call includes what the reference's call includes (the
-    search-structure build); the port does not scale to every core of a large host (fork/join and allocator contention
-    over a few thousand samples), so a few thread counts are tried and the best one is reported with its count."""
+    search-structure build).  The port does not scale to every core of a large host (fork/join and allocator contention
+    over a few thousand samples), so a few thread counts are tried first; the reported value is the MEDIAN of five runs at
+    the best count, with the 4-thread (the reference's launch files: num_threads 4) and 1-thread figures beside it."""
     from oracle import oracle_py as O
 
     cores = os.cpu_count() or 1
     sub = sc.samples[:n_sub]
-    best = None
-    for threads in sorted({min(cores, t) for t in (16, 32, 64, cores)}):
+
+    def once(threads):
         p = O.default_params(sc.cam_origins, normals_mode=normals_mode, num_threads=threads)
-        O.find_hands(p, sc.xyz, sc.cam, sub[:8])  # warm-up (page-in, OpenMP pool)
         t0 = time.perf_counter()
         r = O.find_hands(p, sc.xyz, sc.cam, sub, want_images=classify)
         if classify:
             O.classify(r["images"], svm[0], svm[1], num_threads=threads)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, threads, len(r["hyps"]))
-    dt, threads, n_hyp = best
-    return {"value": n_hyp / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
+        return time.perf_counter() - t0, len(r["hyps"])
+
+    once(min(cores, 16))  # warm-up (page-in, OpenMP pool)
+    scan = {t: once(t)[0] for t in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)})}
+    best = min(scan, key=scan.get)
+    runs = [once(best) for _ in range(5)]
+    dt = statistics.median(r[0] for r in runs)
+    n_hyp = runs[0][1]
+    t4 = statistics.median(once(min(4, cores))[0] for _ in range(3))
+    t1 = once(1)[0]
+    return {"value": n_hyp / dt, "unit": "hypotheses/s", "cores": best, "kind": "port",
             "sample": f"{'all' if n_sub == sc.samples.size else 'first ' + str(n_sub) + ' of the'} {sc.samples.size} samples of the "
-                      f"same cloud, {'rand50' if normals_mode else 'deterministic'} normals, best of OpenMP x16/32/64/{cores}: "
-                      f"x{threads}, {dt:.2f} s",
-            "samples_per_s": n_sub / dt}
+                      f"same cloud, {'rand50' if normals_mode else 'deterministic'} normals; median of 5 runs at the best of "
+                      f"OpenMP x{'/'.join(str(t) for t in scan)} (x{best}: {dt:.3f} s)",
+            "samples_per_s": n_sub / dt,
+            "threads_4": {"value": n_hyp / t4, "seconds": t4}, "threads_1": {"value": n_hyp / t1, "seconds": t1},
+            "host_cores": cores}
 
 
 def main():
@@ -64,10 +83,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "small"])
     ap.add_argument("--normals", default="det", choices=["det", "rand50"])
+    ap.add_argument("--shard", default="samples", choices=["samples", "clouds"],
+                    help="N > 1: shard one cloud's samples over the GPUs (default) or give every GPU its own cloud")
     ap.add_argument("--cpu-samples", type=int, default=1 << 30,
                     help="samples of the cloud the CPU baseline is timed on (default: all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
+    ap.add_argument("--spin-seconds", type=float, default=0.5,
+                    help="untimed run of the same step before the warm-up steps, so that the clocks are at their steady state")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,9 +111,12 @@ def main():
 
     classify = args.config == "C3"
     base = "C2" if args.config == "C3" else args.config
-    # N = 1: the C2 cloud (seed 2).  N > 1: rank r owns cloud r of the C5 batch (seeds 10 + r), same size.
-    sc = synthetic.config(base) if not distributed else synthetic.config(f"C5_{rank}") if base == "C2" else \
-        synthetic.make_scene(1_000_000, 8000, seed=40 + rank, two_view=True, n_objects=48, name=f"C4_{rank}")
+    by_cloud = distributed and args.shard == "clouds"
+    if by_cloud:  # rank r owns cloud r of the C5 batch (seeds 10 + r), same size as C2 (or a C4-sized one)
+        sc = synthetic.config(f"C5_{rank}") if base == "C2" else \
+            synthetic.make_scene(1_000_000, 8000, seed=40 + rank, two_view=True, n_objects=48, name=f"C4_{rank}")
+    else:  # one cloud: the whole of it on one GPU, or its samples sharded over the GPUs
+        sc = synthetic.config(base)
     normals_mode = binding.NORMALS_RAND50 if args.normals == "rand50" else binding.NORMALS_DETERMINISTIC
     ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0 if args.no_events else 2)
     svm = None
@@ -99,36 +125,69 @@ def main():
         svm = (z["w"], float(z["rho"]))
         ctx.load_svm(*svm)
 
+    # ---- the communicator of the sharded search: created by the library (C++ -> RCCL), id handed over by torch ----
+    exchange = None
+    if distributed:
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(binding.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+            exchange = "library: ncclAllGather issued from C++ on the search's stream"
+        except Exception as e:  # keep the run alive, say so in the result line
+            exchange = f"torch.distributed all_gather_into_tensor (the library's communicator failed: {e})"
+        ok = torch.tensor([1 if exchange.startswith("library") else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and exchange.startswith("library"):
+            ctx.comm_destroy()
+            exchange = "torch.distributed all_gather_into_tensor (another rank's communicator failed)"
+    lib_comm = exchange is not None and exchange.startswith("library")
+
     S = sc.samples.size
     xyz_t = torch.from_numpy(sc.xyz).to(dev)
     cam_t = torch.from_numpy(sc.cam).to(dev)
     s_t = torch.from_numpy(sc.samples).to(dev)
-    # exchange buffer = [160-byte header whose first int64 is the record count | 8*S records of 160 B]
-    buf_t = torch.zeros(sharding.buffer_bytes(S), dtype=torch.uint8, device=dev)
-    nout_t = buf_t[:8].view(torch.int64)
-    out_t = buf_t[160:]
-    keep_t = torch.zeros(8 * S, dtype=torch.uint8, device=dev)
-    # The exchange sends a PREFIX of the buffer: header + S record slots (one per sample; a cloud yields ~0.4
-    # hypotheses per sample), 320 KB instead of 2.5 MB per rank -- xGMI all-gathers of this size are latency bound.
-    # The header carries the true count, so a rank that produced more is detected (checked after the timed region)
-    # and the run is repeated with the full 8*S slots.
-    xch_records = [min(S, 8 * S)]
-    gather_full = torch.zeros(world * buf_t.numel(), dtype=torch.uint8, device=dev) if distributed else None
+    out_t = torch.zeros(8 * S * 160 * (world if by_cloud else 1), dtype=torch.uint8, device=dev)
+    nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    keep_t = torch.zeros(8 * S * (world if by_cloud else 1), dtype=torch.uint8, device=dev)
+    sl = sharding.shard_slice(S, rank, world) if distributed and not by_cloud else slice(0, S)
+    # fall-back exchange (torch): the same segments the library would gather
+    seg = [sharding.segment_records(S if not by_cloud else S * world, world)]
+    fb_local = fb_gather = None
+    if distributed and not lib_comm:
+        fb_local = torch.zeros(sharding.segment_bytes(8 * S), dtype=torch.uint8, device=dev)
+        fb_gather = torch.zeros(world * fb_local.numel(), dtype=torch.uint8, device=dev)
     # An explicit (non-null) stream: work on the legacy null stream serialises against every other blocking stream
     # (the context's own one included), which costs ~10 us per launch as soon as any torch op is interleaved.
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+    # cloud-per-GPU through the library: the "list" is the concatenation of the ranks' sample lists, rank r's slice of it
+    # is its own samples -- the same sharded call, every rank searching its own cloud
+    s_all_t = None
+    if by_cloud and lib_comm:
+        s_all_t = torch.zeros(world * S, dtype=torch.int32, device=dev)
+        s_all_t[rank * S:(rank + 1) * S] = s_t
 
     def step():
         ctx.set_cloud_torch(xyz_t, cam_t, stream=stream)          # grid build (kd-tree build in the reference)
-        ctx.find_hands_torch(s_t, out_t, nout_t, stream=stream)   # findQuadrics + findHands + concatenation
-        if classify:
-            ctx.classify_torch(keep_t, stream=stream)             # Learning::classify
-        if distributed:
-            nb = sharding.buffer_bytes_records(xch_records[0])
-            sharding.all_gather_records(buf_t[:nb], gather_full[:world * nb])   # ONE RCCL all-gather per step
+        if not distributed:
+            ctx.find_hands_torch(s_t, out_t, nout_t, stream=stream)   # findQuadrics + findHands + concatenation
+            if classify:
+                ctx.classify_torch(keep_t, stream=stream)             # Learning::classify
+        elif lib_comm:
+            ctx.find_hands_sharded_torch(s_all_t if by_cloud else s_t, out_t, nout_t, stream=stream)
+            if classify:
+                ctx.classify_sharded_torch(keep_t, stream=stream)
+        else:
+            n_loc = fb_local[:8].view(torch.int64)
+            ctx.find_hands_torch(s_t[sl], fb_local[160:], n_loc, stream=stream)
+            if classify:
+                ctx.classify_torch(keep_t, stream=stream)
+            nb = sharding.segment_bytes(seg[0])
+            sharding.all_gather_records(fb_local[:nb], fb_gather[:world * nb])
 
     def fence():
         torch.cuda.synchronize()
@@ -136,6 +195,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clocks: a cold GPU runs the first milliseconds below its sustained clock and these kernels are issue bound, so the
+    # same step runs untimed for a moment first (the W warm-up steps and the K timed steps follow unchanged).
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spin_seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    fence()
     while True:
         for _ in range(args.warmup):
             step()
@@ -148,11 +215,19 @@ def main():
         dt = time.perf_counter() - t0
         if not distributed:
             break
-        nb = sharding.buffer_bytes_records(xch_records[0])
-        counts = gather_full[:world * nb].view(world, nb)[:, :8].contiguous().view(torch.int64)
-        if int(counts.max().item()) <= xch_records[0]:
+        if lib_comm:
+            try:
+                ctx.synchronize()  # raises AGH_ERR_CAPACITY if a rank overflowed its segment; the context then uses full ones
+                break
+            except binding.AghError as e:
+                if e.code != -4:
+                    raise
+                continue
+        nb = sharding.segment_bytes(seg[0])
+        counts = fb_gather[:world * nb].view(world, nb)[:, :8].contiguous().view(torch.int64)
+        if int(counts.max().item()) <= seg[0]:
             break
-        xch_records[0] = 8 * S  # some rank overflowed the compact slots: measure again with the full exchange
+        seg[0] = 8 * S
     ctx.synchronize()  # raises if any neighbourhood overflowed the kernels' capacity
     # HIP events on the launch stream bracket k_hand_sweep inside the timed region (2 events per step; bracketing all
     # six phases costs ~35 us per step, so the full breakdown comes from a second, untimed pass of K steps).
@@ -166,20 +241,21 @@ def main():
         ctx.set_profile(2)
     else:
         kern_all = {}
-    n_hyp = int(nout_t.item())
-    n_kept = int(keep_t[:n_hyp].sum().item()) if classify else None
-    nt, nh = ctx.neighbor_counts()
-
-    tvals = torch.tensor([dt, float(n_hyp)], dtype=torch.float64, device=dev)
-    if distributed:
-        tmax = tvals.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tvals.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0].item())
-        total_hyp = float(tsum[1].item())
-    else:
+    if not distributed or lib_comm:
+        n_hyp = int(nout_t.item())       # the complete (merged) list
         total_hyp = float(n_hyp)
+    else:
+        nb = sharding.segment_bytes(seg[0])
+        counts = fb_gather[:world * nb].view(world, nb)[:, :8].contiguous().view(torch.int64)
+        n_hyp = int(counts[rank].item())
+        total_hyp = float(counts.sum().item())
+    n_kept = int(keep_t[:n_hyp].sum().item()) if classify else None
+    nt, nh = ctx.neighbor_counts()       # of this rank's own samples
+
+    tvals = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
+        dt = float(tvals[0].item())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -188,22 +264,30 @@ def main():
         # r = 0.08 neighbour (12 B xyz + 4 B id/cam) and writes 160 B + a 1000 B image per hypothesis slot kept.
         k_ms = {k: v / args.steps for k, v in kern_all.items()}
         k_ms["hand_sweep"] = kern.get("hand_sweep", 0.0) / args.steps   # the one measured inside the timed region
-        sweep_bytes = 16.0 * float(nh.sum()) + 200.0 * S + (160.0 + 1000.0) * n_hyp
+        n_local_hyp = n_hyp if not distributed else (int(ctx.epoch()[1]) if ctx.epoch()[1] >= 0 else n_hyp // world)
+        n_local_samples = sl.stop - sl.start
+        sweep_bytes = 16.0 * float(nh.sum()) + 200.0 * n_local_samples + (160.0 + 1000.0) * n_local_hyp
         sweep_s = k_ms.get("hand_sweep", 0.0) * 1e-3
         achieved = sweep_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(f"{args.config}:{args.normals}", {}).get("hand_sweep_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # whole-path algorithmic bytes (B_alg of BASELINE.md section 4)
-        b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_hyp + (24.0 * 0 + 14112 if classify else 0)
-        # fp64 VALU work of the (n_i . n_j)^6 stage, the time-dominant kernel in deterministic mode
-        ks = np.where((normals_mode == 1) & (nt > 50), 50, nt).astype(np.float64)
-        frame_flops = float((ks * ks * 9.0).sum())
-        frame_s = k_ms.get("taubin_frame", 0.0) * 1e-3
+        traffic, traffic_src = None, None
+        if not distributed:
+            for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+                tf = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tf):
+                    try:
+                        traffic = json.load(open(tf)).get(f"{args.config}:{args.normals}", {}).get("hand_sweep_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                    if traffic is not None:
+                        traffic_src = (f"static: profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                       "workload, gfx950 corrections applied); not measured in this run")
+                        break
+        # whole-path algorithmic bytes (B_alg of BASELINE.md section 4), of this rank's share
+        b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_local_hyp + (14112 if classify else 0)
+        scaling = "weak" if by_cloud or not distributed else "strong"
+        par = "single GPU" if not distributed else (
+            f"cloud-per-gpu x{world}: every rank searches its own cloud, one all-gather of the lists" if by_cloud else
+            f"sample-sharded x{world}: rank g searches samples [g S/N, (g+1) S/N) of the same cloud, one all-gather of the lists")
         res = {
             "metric": "grasp hypotheses/sec on 300k-pt cloud @2000 samples" if base == "C2" else
                       "grasp hypotheses/sec (config %s)" % args.config,
@@ -214,34 +298,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: two-view {sc.n}-point tabletop cloud, {S} samples per GPU, "
-                                   f"{'rand50' if normals_mode else 'deterministic'} normals"
+            "config": {"workload": f"{args.config}: two-view {sc.n}-point tabletop cloud, {S} samples"
+                                   f"{' per GPU' if by_cloud else ''}, {'rand50' if normals_mode else 'deterministic'} normals"
                                    f"{', + HOG/linear SVM' if classify else ''}",
-                       "points": sc.n, "samples": S, "hypotheses_per_cloud": n_hyp,
-                       "parallelism": f"cloud-per-gpu x{world}" + (" + all-gather" if distributed else "")},
-            "samples_per_s": S * world * args.steps / dt,
+                       "points": sc.n, "samples": S, "hypotheses": int(total_hyp), "parallelism": par},
+            "samples_per_s": S * (world if by_cloud else 1) * args.steps / dt,
             "roofline": {"bound": "hbm", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0)},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
+                         "launch_samples": n_local_samples},
             "kernel_ms_per_step": k_ms,
             "path_algorithmic_bytes": b_alg,
             "path_GBps": b_alg / (dt / args.steps) / 1e9,
-            "taubin_frame_fp64": {"gflops": frame_flops / frame_s / 1e9 if frame_s > 0 else 0.0, "peak_gflops": 78600.0,
-                                  "note": "fp64 VALU mul/add of the n x n (n_i.n_j)^6 column sums, 9 flop per pair"},
         }
+        if distributed:
+            res["config"]["exchange"] = exchange
+            res["config"]["segment_records"] = seg[0] if not lib_comm else None
         if classify:
             res["config"]["svm_kept"] = n_kept
         if not args.no_cpu_baseline and not distributed:
-            cb = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)
-            res["cpu_baseline"] = cb
+            res["cpu_baseline"] = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res))
     if distributed:
+        if lib_comm:
+            ctx.comm_destroy()
         dist.destroy_process_group()
 
 
