@@ -79,7 +79,7 @@ HANDLE_DTYPE = np.dtype([("axis", "<f8", 3), ("center", "<f8", 3), ("approach", 
 assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200 and HANDLE_DTYPE.itemsize == 136
 
 EXPORTS = [
-    "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device",
+    "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device", "agh_set_cloud_batch", "agh_set_cloud_batch_device",
     "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
@@ -230,6 +230,28 @@ class Context:
         self._check(self.lib.agh_set_cloud(self._h, _p(xyz, C.c_float), C.c_int64(stride), camp,
                                            C.c_int64(xyz.shape[0])))
         self.n = xyz.shape[0]
+
+    def set_cloud_batch(self, clouds, cams):
+        """A batch of clouds in one context: `clouds` / `cams` are lists of (n_k, 3) float32 / (n_k,) int32 arrays.  Returns
+        the offsets; point and sample indices of later calls are positions in the concatenation."""
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32)[:, :3] for c in clouds]), np.float32)
+        cam = np.ascontiguousarray(np.concatenate([np.asarray(c, np.int32) for c in cams]), np.int32)
+        off = np.zeros(len(clouds) + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clouds])
+        self._check(self.lib.agh_set_cloud_batch(self._h, _p(xyz, C.c_float), C.c_int64(12), _p(cam, C.c_int32),
+                                                 _p(off, C.c_int64), C.c_int32(len(clouds))))
+        self.n = xyz.shape[0]
+        return off
+
+    def set_cloud_batch_torch(self, xyz_t, cam_t, offsets, stream=None):
+        assert xyz_t.is_cuda and xyz_t.is_contiguous()
+        off = np.ascontiguousarray(offsets, np.int64)
+        self._keep = [xyz_t, cam_t]
+        self.n = xyz_t.shape[0]
+        self._check(self.lib.agh_set_cloud_batch_device(
+            self._h, C.c_void_p(xyz_t.data_ptr()), C.c_int64(xyz_t.stride(0) * 4),
+            C.c_void_p(cam_t.data_ptr()) if cam_t is not None else None, _p(off, C.c_int64), C.c_int32(off.shape[0] - 1),
+            C.c_void_p(stream) if stream else None))
 
     def preprocess(self, xyz: np.ndarray, size_left: int, workspace, cell_size: float = 0.003, dense: bool = False) -> int:
         """NaN removal + workspace box + per-camera voxelisation on the GPU; the result becomes the context's cloud."""

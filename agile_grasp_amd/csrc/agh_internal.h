@@ -35,11 +35,18 @@ struct GridDesc
 };
 
 // Everything a search kernel needs to walk the grid.
+// A context holds a BATCH of n_clouds >= 1 clouds laid end to end in one point array (cloud k = points [cloud_off[k],
+// cloud_off[k + 1])); point and sample indices are positions in that array.  Every cloud has its own grid descriptor and
+// its own cell table (kCellCap + 1 entries each, holding positions in the common cell-sorted array), so a ball query only
+// sees its own cloud.  n_clouds == 1 is the plain HandSearch::findHands case.
+constexpr int kMaxClouds = 64;
 struct GridView
 {
-  const GridDesc* desc;
-  const int* cell_start;   // ncell + 1
-  const float4* sorted;    // x, y, z, bits((idx << 1) | cam), cell-major
+  const GridDesc* desc;    // n_clouds descriptors (or, after grid_of_*, the one of the query's cloud)
+  const int* cell_start;   // n_clouds x (kCellCap + 1)
+  const float4* sorted;    // x, y, z, bits((idx << 1) | cam), cloud-major, then cell-major
+  const int* cloud_off;    // n_clouds + 1
+  int n_clouds;
 };
 
 struct HandGeom
@@ -153,12 +160,19 @@ struct Ctx
   agh_handle* d_h_handles = nullptr;
   int64_t h_cap = 0;
 
-  // grid
-  GridDesc* d_desc = nullptr;
-  int* d_cell_start = nullptr;  // kCellCap + 1
-  int* d_cell_count = nullptr;  // kCellCap
+  // grid (per cloud of the batch)
+  int n_clouds = 1;
+  int clouds_cap = 0;               // clouds the tables below are allocated for
+  std::vector<int64_t> cloud_off;   // host copy, n_clouds + 1
+  std::vector<int32_t> cloud_off_i32;
+  bool cloud_off_on_device = false;
+  int* d_cloud_off = nullptr;       // kMaxClouds + 1
+  int32_t* d_scloud = nullptr;      // s_cap: cloud of every sample of the last call (written by k_taubin_moments)
+  GridDesc* d_desc = nullptr;       // clouds_cap
+  int* d_cell_start = nullptr;      // clouds_cap x (kCellCap + 1)
+  int* d_cell_count = nullptr;      // clouds_cap x kCellCap
   int* d_block_sums = nullptr;
-  unsigned long long* d_tile_state = nullptr;  // k_cell_scan look-back descriptors, tagged with the build number
+  unsigned long long* d_tile_state = nullptr;  // clouds_cap x kCellCap / 1024 look-back descriptors of k_cell_scan, tagged with the build number
   unsigned build_gen = 0;
   bool grid_clean = false;      // cell counts, bbox and counters are in their reset state (self-cleaning kernels)
   int* d_cell_of = nullptr;     // n
@@ -288,6 +302,7 @@ void timing_mark(Ctx* c, const char* name, hipStream_t st);
 void timing_begin(Ctx* c, hipStream_t st);
 int32_t next_epoch();
 int ensure_call_buffers(Ctx* c, int64_t S);
+int ensure_clouds(Ctx* c, int C);
 int ensure_draws(Ctx* c, int64_t count, hipStream_t st);
 int normals_pass(Ctx* c, int64_t p0, int64_t p1, hipStream_t st);
 void comm_release(Ctx* c);
@@ -309,6 +324,21 @@ __device__ __forceinline__ int cell_coord(const GridDesc& g, double v, int a)
 {
   int c = (int) floor((v - g.mn[a]) * g.inv_cell);
   return min(max(c, 0), g.dim[a] - 1);
+}
+
+// The view of the grid of cloud k / of the cloud that holds point p (uniform per work-group: scalar loads).
+__device__ __forceinline__ GridView grid_of_cloud(GridView gv, int k)
+{
+  gv.desc += k;
+  gv.cell_start += (int64_t) k * (kCellCap + 1);
+  return gv;
+}
+__device__ __forceinline__ int cloud_of_point(const GridView& gv, int p)
+{
+  int k = 0;
+  for (int j = 1; j < gv.n_clouds; j++)
+    k += p >= gv.cloud_off[j] ? 1 : 0;
+  return k;
 }
 
 // Squared distance exactly as FLANN's L2_Simple<float> accumulates it (see oracle a2): ((0+dx*dx)+dy*dy)+dz*dz.

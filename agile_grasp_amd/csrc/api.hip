@@ -214,7 +214,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_nt, cap)))
     return rc;
-  if ((rc = dev_alloc(c, &c->d_nh, cap)))
+  if ((rc = dev_alloc(c, &c->d_nh, cap)) || (rc = dev_alloc(c, &c->d_scloud, cap)))
     return rc;
   if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)) || (rc = dev_alloc(c, &c->d_vmask, cap)))
     return rc;
@@ -238,6 +238,21 @@ int ensure_call_buffers(Ctx* c, int64_t S)
   if ((rc = dev_alloc(c, &c->d_draw_ofs, cap)))
     return rc;
   c->s_cap = cap;
+  return AGH_OK;
+}
+
+// per-cloud grid tables for a batch of C clouds
+int ensure_clouds(Ctx* c, int C)
+{
+  if (C <= c->clouds_cap)
+    return AGH_OK;
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_desc, (size_t) C)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) C * ((size_t) kCellCap + 1))) ||
+      (rc = dev_alloc(c, &c->d_cell_count, (size_t) C * kCellCap)) ||
+      (rc = dev_alloc(c, &c->d_tile_state, (size_t) C * (kCellCap / 1024))))
+    return rc;
+  c->clouds_cap = C;
+  c->grid_clean = false;  // fresh tables: the next build resets them
   return AGH_OK;
 }
 
@@ -414,9 +429,8 @@ int agh_create(const agh_params* p, agh_ctx** out)
     return fail(AGH_ERR_HIP);
   }
   int rc;
-  if ((rc = dev_alloc(c, &c->d_desc, 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) kCellCap + 1)) ||
-      (rc = dev_alloc(c, &c->d_cell_count, (size_t) kCellCap)) || (rc = dev_alloc(c, &c->d_block_sums, 4096)) ||
-      (rc = dev_alloc(c, &c->d_tile_state, (size_t) kCellCap / 1024)) ||
+  if ((rc = ensure_clouds(c, 1)) || (rc = dev_alloc(c, &c->d_cloud_off, (size_t) kMaxClouds + 1)) ||
+      (rc = dev_alloc(c, &c->d_block_sums, 4096)) ||
       (rc = dev_alloc(c, &c->d_flags, 8)) || (rc = dev_alloc(c, &c->d_nout, 1)) ||
       (rc = dev_alloc(c, &c->d_geom, 1)) || (rc = dev_alloc(c, &c->d_hog, 1)) ||
       (rc = dev_alloc(c, &c->d_svm_w, 3528)))
@@ -449,7 +463,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
-    c->d_weight, c->d_order, c->d_vmask, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
+    c->d_weight, c->d_order, c->d_vmask, c->d_cloud_off, c->d_scloud, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
     c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
   for (void* p : ptrs)
     if (p)
@@ -461,34 +475,63 @@ void agh_destroy(agh_ctx* ctx)
   delete ctx;
 }
 
-int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
-  int64_t n, void* hip_stream)
+int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
+  const int64_t* offsets, int32_t n_clouds, void* hip_stream)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
+  if (!offsets || n_clouds < 1 || n_clouds > kMaxClouds || offsets[0] != 0)
+  {
+    c->err = "agh_set_cloud_batch: need 1 <= n_clouds <= 64 and offsets[0] == 0";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  for (int k = 0; k < n_clouds; k++)
+    if (offsets[k + 1] < offsets[k])
+    {
+      c->err = "agh_set_cloud_batch: offsets must not decrease";
+      return AGH_ERR_INVALID_ARGUMENT;
+    }
+  const int64_t n = offsets[n_clouds];
   if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !d_xyz))
   {
-    c->err = "agh_set_cloud: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4";
+    c->err = "agh_set_cloud: need 0 <= n < 2^30 points in total, stride_bytes >= 12 and a multiple of 4";
     return AGH_ERR_INVALID_ARGUMENT;
   }
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  int rc = ensure_clouds(c, n_clouds);
+  if (rc != AGH_OK)
+    return rc;
   c->n = n;
   c->d_xyz = d_xyz;
   c->stride_floats = stride_bytes / 4;
   c->d_cam = d_cam_source;
   c->has_normals = false;
+  // the offsets travel to the device only when they change (a stream of equally sized clouds re-uses them)
+  bool same = c->n_clouds == n_clouds && (int) c->cloud_off.size() == n_clouds + 1 && c->cloud_off_on_device;
+  for (int k = 0; same && k <= n_clouds; k++)
+    same = c->cloud_off[(size_t) k] == offsets[k];
+  if (!same)
+  {
+    c->n_clouds = n_clouds;
+    c->cloud_off.assign(offsets, offsets + n_clouds + 1);
+    c->cloud_off_i32.assign((size_t) kMaxClouds + 1, (int32_t) n);
+    for (int k = 0; k <= n_clouds; k++)
+      c->cloud_off_i32[(size_t) k] = (int32_t) offsets[k];
+    HIPCHK(c, hipMemcpyAsync(c->d_cloud_off, c->cloud_off_i32.data(), sizeof(int32_t) * (kMaxClouds + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // (pageable source: the copy has left the host vector)
+    c->cloud_off_on_device = true;
+  }
   if (n > c->grid_cap)
   {
-    int rc;
     if ((rc = dev_alloc(c, &c->d_cell_of, (size_t) n)) || (rc = dev_alloc(c, &c->d_rank_of, (size_t) n)) ||
         (rc = dev_alloc(c, &c->d_sorted, (size_t) n)))
       return rc;
     c->grid_cap = n;
   }
   timing_begin(c, st);
-  int rc = grid_build(c, st);
+  rc = grid_build(c, st);
   timing_mark(c, "grid_build", st);
   if (rc != AGH_OK)
   {
@@ -500,11 +543,31 @@ int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes,
   return AGH_OK;
 }
 
+int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
+  int64_t n, void* hip_stream)
+{
+  const int64_t offsets[2] = { 0, n };
+  return agh_set_cloud_batch_device(ctx, d_xyz, stride_bytes, d_cam_source, offsets, 1, hip_stream);
+}
+
 int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, int64_t n)
+{
+  const int64_t offsets[2] = { 0, n };
+  return agh_set_cloud_batch(ctx, xyz, stride_bytes, cam_source, offsets, 1);
+}
+
+int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, const int64_t* offsets,
+  int32_t n_clouds)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
+  if (!offsets || n_clouds < 1 || n_clouds > kMaxClouds)
+  {
+    c->err = "agh_set_cloud_batch: need 1 <= n_clouds <= 64 and offsets";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  const int64_t n = offsets[n_clouds];
   if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz))
   {
     c->err = "agh_set_cloud: need 0 <= n < 2^30, stride_bytes >= 12 and a multiple of 4";
@@ -539,7 +602,7 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
     else
       HIPCHK(c, hipMemsetAsync(c->own_cam, 0, sizeof(int32_t) * n, c->stream));
   }
-  int rc = agh_set_cloud_device(ctx, c->own_xyz, dev_stride, c->own_cam, n, nullptr);
+  int rc = agh_set_cloud_batch_device(ctx, c->own_xyz, dev_stride, c->own_cam, offsets, n_clouds, nullptr);
   if (rc != AGH_OK)
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));

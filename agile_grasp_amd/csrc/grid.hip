@@ -13,6 +13,7 @@ namespace agh
 // Reset state of the self-cleaning fields (also written once by agh_create / after a failed build).
 __global__ void k_desc_reset(GridDesc* d)
 {
+  d += blockIdx.x;
   for (int a = 0; a < 3; a++)
   {
     d->bbox[a] = 0xffffffffu;  // min
@@ -56,9 +57,13 @@ __device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const unsi
 
 // Bounding box of the cloud and, in the work-group that finishes last, the grid descriptor (one launch instead of
 // init + reduce + finish: a launch costs ~4.7 us of its own on this part, more than any of these does work).
-__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int64_t stride, int64_t n, GridDesc* d,
-  double base_cell)
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int64_t stride, const int* __restrict__ cloud_off,
+  GridDesc* d, double base_cell)
 {
+  // blockIdx.y = cloud of the batch
+  const int64_t p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
+  xyz += p0 * stride;
+  d += blockIdx.y;
   float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
   for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
   {
@@ -113,10 +118,16 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int
 // Cell histogram.  Clouds arrive in voxel order (localization.cpp:282-351), so consecutive points mostly share a cell:
 // each run of equal cells inside a wave issues ONE atomic (with return), and every point remembers its rank inside its
 // cell, which makes the scatter below atomic-free.
-__global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xyz, int64_t stride, int64_t n,
-  const GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ rank_of, int* __restrict__ count)
+__global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xyz, int64_t stride,
+  const int* __restrict__ cloud_off, const GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ rank_of,
+  int* __restrict__ count)
 {
-  const GridDesc g = *d;
+  const int64_t p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
+  xyz += p0 * stride;
+  cell_of += p0;
+  rank_of += p0;
+  count += (int64_t) blockIdx.y * kCellCap;
+  const GridDesc g = d[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int64_t step = (int64_t) gridDim.x * blockDim.x;
   const int64_t n_up = (n + 63) & ~(int64_t) 63;  // whole waves iterate together (the shuffles below need all lanes)
@@ -179,9 +190,17 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total)
 }
 
 __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, GridDesc* __restrict__ d,
-  unsigned long long* __restrict__ tile_state, unsigned gen, int* __restrict__ cell_start, int n)
+  unsigned long long* __restrict__ tile_state, unsigned gen, int* __restrict__ cell_start, const int* __restrict__ cloud_off)
 {
   __shared__ int s_prefix;
+  // blockIdx.y = cloud: its own histogram, tile descriptors and cell table; the table holds positions in the common
+  // sorted array, i.e. it starts at the cloud's first point.  (Work-groups are dispatched x-fastest, so the predecessors a
+  // tile waits for were dispatched before it, for every cloud.)
+  const int p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
+  count += (int64_t) blockIdx.y * kCellCap;
+  tile_state += (int64_t) blockIdx.y * (kCellCap / kScanBlock);
+  cell_start += (int64_t) blockIdx.y * (kCellCap + 1);
+  d += blockIdx.y;
   const int ncell = d->ncell;
   // 256 resident work-groups walk the tiles round-robin: tile t only ever waits for tiles < t, which belong to the
   // first pass of lower-numbered groups or to an earlier pass, so the look-back cannot deadlock (and no same-address
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, Grid
     }
   }
   __syncthreads();
-  ex += s_prefix;
+  ex += s_prefix + p0;
   for (int k = 0; k < 4; k++)
   {
     const int i = b0 + threadIdx.x * 4 + k;
@@ -252,16 +271,18 @@ __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, Grid
     ex += v[k];
   }
   if (tile == 0 && threadIdx.x == 0)
-    cell_start[ncell] = n;
+    cell_start[ncell] = p0 + n;
   __syncthreads();  // s_prefix is reused by the next tile of this group
   }
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ xyz, int64_t stride,
-  const int32_t* __restrict__ cam, int64_t n, const int* __restrict__ cell_of, const int* __restrict__ rank_of,
-  const int* __restrict__ cell_start, float4* __restrict__ sorted)
+  const int32_t* __restrict__ cam, const int* __restrict__ cloud_off, const int* __restrict__ cell_of,
+  const int* __restrict__ rank_of, const int* __restrict__ cell_start, float4* __restrict__ sorted)
 {
-  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+  const int64_t p0 = cloud_off[blockIdx.y], p1 = cloud_off[blockIdx.y + 1];
+  cell_start += (int64_t) blockIdx.y * (kCellCap + 1);
+  for (int64_t i = p0 + blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < p1; i += (int64_t) gridDim.x * blockDim.x)
   {
     const int pos = cell_start[cell_of[i]] + rank_of[i];
     const float* p = xyz + i * stride;
@@ -272,33 +293,37 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ xyz, 
 
 int grid_build(Ctx* c, hipStream_t st)
 {
-  const int64_t n = c->n;
-  const int nblk = (int) std::min<int64_t>((n + 255) / 256, 2048);
+  // one launch per stage for the whole batch: blockIdx.y = cloud
+  const int C = c->n_clouds;
+  int64_t nmax = 0;
+  for (int k = 0; k < C; k++)
+    nmax = std::max<int64_t>(nmax, c->cloud_off[(size_t) k + 1] - c->cloud_off[(size_t) k]);
+  const int nblk = (int) std::max<int64_t>(1, std::min<int64_t>((nmax + 255) / 256, 2048));
   if (!c->grid_clean)  // first build of the context, or the previous one failed half-way
   {
-    hipMemsetAsync(c->d_cell_count, 0, sizeof(int) * kCellCap, st);
-    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (kCellCap / kScanBlock), st);
-    hipLaunchKernelGGL(k_desc_reset, dim3(1), dim3(1), 0, st, c->d_desc);
+    hipMemsetAsync(c->d_cell_count, 0, sizeof(int) * (size_t) kCellCap * c->clouds_cap, st);
+    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (size_t) (kCellCap / kScanBlock) * c->clouds_cap, st);
+    hipLaunchKernelGGL(k_desc_reset, dim3(c->clouds_cap), dim3(1), 0, st, c->d_desc);
     c->build_gen = 0;
   }
   c->grid_clean = false;
   if (++c->build_gen >= (1u << 30))  // the tag has 30 bits: start over long before it wraps
   {
-    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (kCellCap / kScanBlock), st);
+    hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (size_t) (kCellCap / kScanBlock) * c->clouds_cap, st);
     c->build_gen = 1;
   }
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
-  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, 128))), dim3(256), 0, st, c->d_xyz, c->stride_floats, n,
-    c->d_desc, base_cell);
-  if (n > 0)
-    hipLaunchKernelGGL(k_cell_count, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, n, c->d_desc,
-      c->d_cell_of, c->d_rank_of, c->d_cell_count);
-  hipLaunchKernelGGL(k_cell_scan, dim3(256), dim3(256), 0, st, c->d_cell_count, c->d_desc,
-    c->d_tile_state, c->build_gen, c->d_cell_start, (int) n);
-  if (n > 0)
-    hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(256), 0, st, c->d_xyz, c->stride_floats, c->d_cam, n, c->d_cell_of,
-      c->d_rank_of, c->d_cell_start, c->d_sorted);
+  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, 128)), C), dim3(256), 0, st, c->d_xyz, c->stride_floats,
+    (const int*) c->d_cloud_off, c->d_desc, base_cell);
+  if (nmax > 0)
+    hipLaunchKernelGGL(k_cell_count, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
+      c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count);
+  hipLaunchKernelGGL(k_cell_scan, dim3(C == 1 ? 256 : 64, C), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_tile_state,
+    c->build_gen, c->d_cell_start, (const int*) c->d_cloud_off);
+  if (nmax > 0)
+    hipLaunchKernelGGL(k_scatter, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, c->d_cam,
+      (const int*) c->d_cloud_off, c->d_cell_of, c->d_rank_of, c->d_cell_start, c->d_sorted);
   if (hipGetLastError() != hipSuccess)
     return AGH_ERR_HIP;
   c->grid_clean = true;

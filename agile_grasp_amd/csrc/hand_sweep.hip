@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   for (int k = tid; k < kImgPlanes * (kImageWords + 2); k += 256)
     (&img[0][0])[k] = 0u;
   const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
+  gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));  // the sample's cloud of the batch
   build_rows(gv, sx, sy, sz, rpad, rt);  // ends with barriers: G and counters are visible afterwards
   if (tid < 64)
     thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
@@ -894,7 +895,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
 {
   if (S == 0)
     return AGH_OK;
-  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
+  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted, c->d_cloud_off, c->n_clouds };
   const double radius = c->p.nn_radius_hands;
   const float r2f = static_cast<float>(radius * radius);
   const double rpad = radius * 1.0001 + 1e-6;

@@ -27,7 +27,7 @@ struct LpEntry
   int id;  // (cloud index << 1) | camera
 };
 
-__global__ __launch_bounds__(1024) void k_learning_points(GridView gv, int64_t n_points, const HandGeom* __restrict__ geom_p,
+__global__ __launch_bounds__(1024) void k_learning_points(GridView gv, const int32_t* __restrict__ scloud, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const agh_hypothesis* __restrict__ hyps, int64_t hyp, float r2f,
   LpEntry* __restrict__ out, int cap, int* __restrict__ n_out)
 {
@@ -36,6 +36,8 @@ __global__ __launch_bounds__(1024) void k_learning_points(GridView gv, int64_t n
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const agh_hypothesis H = hyps[hyp];
   const agh_frame F = frames[H.sample];
+  // the points of the hypothesis' own cloud of the batch: [cloud_off[k], cloud_off[k + 1]) of the sorted array
+  const int64_t k_first = gv.cloud_off[scloud[H.sample]], n_points = gv.cloud_off[scloud[H.sample] + 1];
   const HandGeom& G = *geom_p;
   const int o = H.orientation, e = H.finger_index < 0 ? 0 : H.finger_index, last = H.depth_index;
   double fr[3][3];
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(1024) void k_learning_points(GridView gv, int64_t n
   };
   // pass 1
   double ymin = INFINITY;
-  for (int64_t k = tid; k < n_points; k += 1024)
+  for (int64_t k = k_first + tid; k < n_points; k += 1024)
   {
     bool keep;
     double xr, yr, tz;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_learning_points(GridView gv, int64_t n
   }
   const double box_y = G.boxy[last];
   // pass 2
-  for (int64_t k = tid; k < n_points; k += 1024)
+  for (int64_t k = k_first + tid; k < n_points; k += 1024)
   {
     bool keep;
     double xr, yr, tz;
@@ -168,9 +170,9 @@ extern "C" int agh_get_learning_points(agh_ctx* ctx, int64_t hyp, double* points
     rc = AGH_ERR_HIP;
   if (rc == AGH_OK)
   {
-    GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
+    GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted, c->d_cloud_off, c->n_clouds };
     const double radius = c->p.nn_radius_hands;
-    hipLaunchKernelGGL(k_learning_points, dim3(1), dim3(1024), 0, c->stream, gv, c->n, (const HandGeom*) c->d_geom,
+    hipLaunchKernelGGL(k_learning_points, dim3(1), dim3(1024), 0, c->stream, gv, (const int32_t*) c->d_scloud, (const HandGeom*) c->d_geom,
       (const agh_frame*) c->d_frames, (const agh_hypothesis*) c->d_out_last, hyp, static_cast<float>(radius * radius), d_out,
       n_b, d_n);
     if (hipMemcpyAsync(ent.data(), d_out, sizeof(LpEntry) * (size_t) n_b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

@@ -37,7 +37,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points, double rpad_w, int* __restrict__ weight, int32_t* __restrict__ zero_flags)
+  int n_points, double rpad_w, int* __restrict__ weight, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud)
 {
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
@@ -75,6 +75,12 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
   }
   const float* qp = xyz + (int64_t) samples[s] * stride;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
+  {  // the sample's cloud of the batch: its grid is the one every query of this sample walks
+    const int cloud = cloud_of_point(gv, samples[s]);
+    gv = grid_of_cloud(gv, cloud);
+    if (first_class && tid == 0)
+      scloud[s] = cloud;
+  }
   // Scheduling weight of the sample for the kernels that follow (see k_taubin_eigen's sorter block): the candidate
   // count of its hand-search ball, i.e. the row total k_hand_sweep's gather will walk.  One wave, <= 128 rows.
   if (first_class && wave == 3)
@@ -1291,7 +1297,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
 {
   if (S == 0)
     return AGH_OK;
-  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted };
+  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted, c->d_cloud_off, c->n_clouds };
   const float r2f = static_cast<float>(radius * radius);  // pcl::KdTreeFLANN::radiusSearch squares in double, casts
   const double rpad = radius * 1.0001 + 1e-6;
   const double rpad_w = c->p.nn_radius_hands * 1.0001 + 1e-6;  // scheduling weight = candidates of the hand-search ball
@@ -1305,16 +1311,16 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
-      zf);
+      zf, c->d_scloud);
     zf = nullptr;
     first = false;
   }
   hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
     r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
-    zf);
+    zf, c->d_scloud);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
     r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
-    (int32_t*) nullptr);
+    (int32_t*) nullptr, c->d_scloud);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind

@@ -126,6 +126,19 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
 int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
   int64_t n, void* hip_stream);
 
+/* A BATCH of clouds in one context (BASELINE config C5: a batch of 8 x 300k-point clouds): the n_clouds clouds lie end to
+ * end in one point array, cloud k = points [offsets[k], offsets[k + 1]) (offsets: n_clouds + 1 host integers, offsets[0] =
+ * 0; at most 64 clouds, 2^30 points in total).  Every cloud gets its own search grid, so a radius search only sees the
+ * points of its own cloud; point and sample indices of all later calls are positions in the common array.  One
+ * agh_find_hands* call then searches samples of ALL clouds in one launch set -- thousands of independent work-groups more
+ * per kernel, which is what fills the GPU when a single cloud's 2000 samples do not -- and agh_hypothesis::sample is the
+ * position in that call's sample list, as always.  All clouds share the context's camera origins and hand geometry.
+ * agh_set_cloud* is the batch of one. */
+int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, const int64_t* offsets,
+  int32_t n_clouds);
+int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
+  const int64_t* offsets, int32_t n_clouds, void* hip_stream);
+
 /* The head of Localization::localizeHands (localization.cpp:17-45) on the GPU, followed by the grid build: camera id of
  * raw point i = (i >= size_left); removal of points with a non-finite coordinate (skipped when dense != 0, like
  * pcl::removeNaNFromPointCloud on an is_dense cloud) WITHOUT re-indexing the camera ids (the reference's behaviour);
