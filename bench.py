@@ -76,6 +76,64 @@ def cpu_baseline(sc, n_sub: int, normals_mode: int, classify: bool, svm):
             "host_cores": cores}
 
 
+def batched_throughput(args, dev, stream, normals_mode, classify, svm):
+    """BASELINE config C5's batch on ONE GPU: the clouds with seeds 10.. (each as large as C2, 2000 samples each) laid end to
+    end in one context (agh_set_cloud_batch_device), one launch set per step for all of them -- grid builds, Taubin
+    stages, hand sweep and compaction each see 8 x 2000 work-groups instead of 2000.  Reported beside the single-cloud
+    headline, never instead of it: it is the throughput of a stream of clouds, not the latency of one."""
+    from agile_grasp_amd import binding, synthetic
+
+    C = args.batch_clouds
+    scs = [synthetic.config(f"C5_{k}") for k in range(C)]
+    ctx = binding.Context(scs[0].cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    if classify:
+        ctx.load_svm(*svm)
+    off = np.zeros(C + 1, np.int64)
+    off[1:] = np.cumsum([s.n for s in scs])
+    xyz_t = torch.from_numpy(np.concatenate([s.xyz for s in scs])).to(dev)
+    cam_t = torch.from_numpy(np.concatenate([s.cam for s in scs])).to(dev)
+    samples = np.concatenate([s.samples + off[k] for k, s in enumerate(scs)]).astype(np.int32)
+    s_t = torch.from_numpy(samples).to(dev)
+    S = samples.size
+    out_t = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
+    nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    keep_t = torch.zeros(8 * S, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.set_cloud_batch_torch(xyz_t, cam_t, off, stream=stream)
+        ctx.find_hands_torch(s_t, out_t, nout_t, stream=stream)
+        if classify:
+            ctx.classify_torch(keep_t, stream=stream)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    steps = max(5, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.synchronize()
+    n_hyp = int(nout_t.item())
+    ctx.set_profile(1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    k_ms = {k: v / steps for k, v in ctx.timing().items()}
+    nt, nh = ctx.neighbor_counts()
+    sweep_bytes = 16.0 * float(nh.sum()) + 200.0 * S + (160.0 + 1000.0) * n_hyp
+    sweep_s = k_ms.get("hand_sweep", 0.0) * 1e-3
+    ctx.close()
+    return {"workload": f"C5 batch: {C} two-view 300000-point clouds (seeds 10..{9 + C}), 2000 samples each, one context, one launch "
+                        "set per step", "clouds": C, "samples": S, "hypotheses": n_hyp, "steps": steps, "ms_per_batch": dt * 1e3,
+            "ms_per_cloud": dt * 1e3 / C, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_batch": k_ms,
+            "roofline": {"kernel": "k_hand_sweep", "achieved": sweep_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sweep_bytes / sweep_s / 1e9 / HBM_PEAK_GBS) if sweep_s > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
+                         "note": "HIP events of an untimed pass of the same steps"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +147,8 @@ def main():
                     help="samples of the cloud the CPU baseline is timed on (default: all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
+    ap.add_argument("--batch-clouds", type=int, default=8,
+                    help="N = 1: also time a batch of this many C5 clouds in one context (extra key 'batched'); 0 = skip")
     ap.add_argument("--spin-seconds", type=float, default=0.5,
                     help="untimed run of the same step before the warm-up steps, so that the clocks are at their steady state")
     args = ap.parse_args()
@@ -320,6 +380,8 @@ def main():
             res["config"]["segment_records"] = seg[0] if not lib_comm else None
         if classify:
             res["config"]["svm_kept"] = n_kept
+        if not distributed and args.batch_clouds > 1 and base == "C2":
+            res["batched"] = batched_throughput(args, dev, stream, normals_mode, classify, svm)
         if not args.no_cpu_baseline and not distributed:
             res["cpu_baseline"] = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)
         elif not args.no_cpu_baseline:

@@ -1,4 +1,5 @@
 """Cumulative phase timings of the moments and hand-sweep kernels via their debug_stop early exits (not a test)."""
+# NOTE: needs a library built with the phase-timing hooks: AGH_DEBUG_BUILD=1 python -c "from agile_grasp_amd import build; build.build(force=True)"
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

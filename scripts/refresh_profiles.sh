@@ -8,28 +8,39 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=${TAG:-r01}
-for cfg in C2 C3; do
+TAG=${TAG:-r02}
+for cfg in C2 C3 C4; do
   rm -rf /tmp/kt_$cfg
+  # (--batch-clouds 0: every k_hand_sweep launch of the trace is the single-cloud launch the bench line's roofline describes)
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$cfg -o kt -- python $R/bench.py --config $cfg --steps 50 --warmup 5 \
-    --no-events --no-cpu-baseline > /tmp/kt_$cfg.log 2>&1
+    --no-events --no-cpu-baseline --batch-clouds 0 > /tmp/kt_$cfg.log 2>&1
   db=$(find /tmp/kt_$cfg -name "*.db" | head -1)
   [ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_$(echo $cfg | tr A-Z a-z)_kernel_trace_stats.csv > /dev/null
 done
+# the batch of 8 clouds in one context (what bench.py reports under "batched")
+rm -rf /tmp/kt_batch
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_batch -o kt -- python $R/scripts/batch_bench.py --clouds 8 --steps 30 --no-events \
+  > /tmp/kt_batch.log 2>&1
+db=$(find /tmp/kt_batch -name "*.db" | head -1)
+[ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_batch8_kernel_trace_stats.csv > /dev/null
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --config C2 --steps 10 --warmup 2 \
-    --no-events --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1
+    --no-events --no-cpu-baseline --batch-clouds 0 --spin-seconds 0 > /tmp/pmc_$ctr.log 2>&1
 done
 rm -rf /tmp/pmc_sq
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
-  SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_sq -o sq -- python $R/bench.py --config C2 --steps 10 --warmup 2 --no-events --no-cpu-baseline > /tmp/pmc_sq.log 2>&1
+  SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_sq -o sq -- python $R/bench.py --config C2 --steps 10 --warmup 2 --no-events --no-cpu-baseline \
+  --batch-clouds 0 --spin-seconds 0 > /tmp/pmc_sq.log 2>&1
 q=$(find /tmp/pmc_sq -name "*.db" | head -1); [ -n "$q" ] && python $R/scripts/pmc_table.py $q > $OUT/${TAG}_c2_sq_counters.txt
 f=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
-[ -n "$f" ] && [ -n "$w" ] && python $R/scripts/pmc_traffic.py $f $w C2:det $OUT/pmc_traffic.json > /dev/null
-cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json 2>/dev/null   # bench.py reads roofline.traffic from here
+[ -n "$f" ] && [ -n "$w" ] && python $R/scripts/pmc_traffic.py $f $w C2:det $OUT/${TAG}_pmc_traffic.json > /dev/null
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null   # bench.py reads roofline.traffic from here
 cd $R
-timeout 300 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> /dev/null
+timeout 400 python bench.py --config C2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_c2.json 2> /dev/null   # the driver's own command line
+# the sample-sharded path through the library's RCCL communicator, as far as one GPU can show it (a communicator of one)
+(AGH_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+  bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c2_sharded_x1.json)
 timeout 300 python bench.py --config C3 > $OUT/${TAG}_bench_c3.json 2> /dev/null
 timeout 300 python bench.py --config C2 --normals rand50 --no-cpu-baseline > $OUT/${TAG}_bench_c2_rand50.json 2> /dev/null
 timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TAG}_bench_c4.json 2> /dev/null
