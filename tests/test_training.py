@@ -124,6 +124,32 @@ def test_oracle_solver_satisfies_kkt_when_run_to_convergence():
     assert (np.where(keep == 1, 1, -1) == y).mean() > 0.9
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_oracle_solver_fixed_point_matches_libsvm(kernel):
+    """A real third-party pin of the solver: OpenCV's CvSVMSolver descends from libsvm, and scikit-learn ships libsvm.
+    Run to convergence, the restated solver and libsvm's C-SVC must reach the same dual solution: the same support
+    vectors, alphas and rho to ~1e-6, decision values to ~2e-6, identical labels.  (What this does NOT pin: the iterate at
+    which OpenCV's default criteria -- 1000 steps -- stop; that is the restated pair selection, checked against the numpy
+    transcription.)"""
+    from sklearn.svm import SVC
+
+    X, y = _toy_problem(400, 11, overlap=0.6)
+    r = O.train_svm(X, y, max_iter=400000, eps=1e-6, kernel=kernel)
+    assert r["iterations"] < 400000
+    kw = dict(kernel="linear") if kernel == 0 else dict(kernel="poly", degree=2, gamma=1.0, coef0=0.0)
+    m = SVC(C=1.0, tol=1e-6, shrinking=False, cache_size=500, **kw).fit(X.astype(np.float64), y)
+    Xd = X.astype(np.float64)
+    K = Xd @ Xd.T if kernel == 0 else (Xd @ Xd.T) ** 2
+    dec_orc = K @ r["alpha"] - r["rho"]              # CvSVM::predict: sum > 0 <=> label -1
+    dec_lib = m.decision_function(Xd)                # libsvm: > 0 <=> label +1
+    assert np.abs(dec_lib + dec_orc).max() < 2e-5
+    assert np.array_equal(np.sign(dec_lib), -np.sign(dec_orc))
+    al = np.zeros(len(y))
+    al[m.support_] = m.dual_coef_[0]                 # y_i alpha_i
+    assert np.abs(al + r["alpha"]).max() < 1e-5 and abs(m.intercept_[0] - r["rho"]) < 1e-5
+    assert set(np.nonzero(np.abs(r["alpha"]) > 1e-9)[0]) == set(m.support_.tolist())
+
+
 def test_oracle_solver_default_criteria_and_single_class():
     X, y = _toy_problem(300, 5)
     r = O.train_svm(X, y)  # CvSVMParams defaults: 1000 steps at most
