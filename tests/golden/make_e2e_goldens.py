@@ -41,7 +41,10 @@ from scipy.linalg import lapack  # noqa: E402
 from agile_grasp_amd import synthetic  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
 
-CASES = [("tiny", 64), ("small", 200), ("C2", 256)]
+CASES = [("tiny", 64, False), ("small", 200, False), ("C2", 256, False),
+         # the reference's production mode (HandSearch hard-wires uses_determinstic_normal_estimation_ = false): 50 draws of
+         # rand() % n per neighbourhood of more than 50 points, one stream in sample order, glibc's default seed 1
+         ("small", 200, True), ("C2", 128, True)]
 R_TAUBIN = 0.03
 
 
@@ -97,7 +100,21 @@ def build_MN(p: np.ndarray):
     return M, N
 
 
-def frame_lapack(xyz, cam, cam_origins, sample_index, **search_kw):
+_LIBC = None
+
+
+def libc_rand():
+    """The host's real rand() (quadric.cpp:184)."""
+    global _LIBC
+    if _LIBC is None:
+        import ctypes
+
+        _LIBC = ctypes.CDLL("libc.so.6")
+        _LIBC.rand.restype = ctypes.c_int
+    return _LIBC.rand()
+
+
+def frame_lapack(xyz, cam, cam_origins, sample_index, rand50=False, **search_kw):
     """One Quadric (quadric.cpp:14-305, deterministic normals) with real LAPACK / a general eigen-solver."""
     q = xyz[sample_index]
     idx, n_on_boundary = radius_search(xyz, q, R_TAUBIN, **search_kw)
@@ -118,13 +135,19 @@ def frame_lapack(xyz, cam, cam_origins, sample_index, **search_kw):
     a, b, c = params[0], params[1], params[2]
     d, e, f = 2.0 * params[3], 2.0 * params[4], 2.0 * params[5]
     g, h, i = params[6], params[7], params[8]
-    X, Y, Z = (pts[:, k].astype(np.float64) for k in range(3))
+    sub_cams = cam[idx]
+    if rand50 and n > 50:  # quadric.cpp:177-193 (the clouds hold no NaN, so no re-draw happens)
+        draws = np.array([libc_rand() % n for _ in range(50)])
+        pts_n, sub_cams = pts[draws], cam[idx][draws]
+    else:
+        pts_n = pts
+    X, Y, Z = (pts_n[:, k].astype(np.float64) for k in range(3))
     fx = (((2.0 * a) * X + d * Y) + f * Z) + g  # quadric.cpp:238
     fy = (((2.0 * b) * Y + d * X) + e * Z) + h
     fz = (((2.0 * c) * Z + e * Y) + f * X) + i
     mag = np.sqrt((fx * fx + fy * fy) + fz * fz)
     nrm = np.stack([fx / mag, fy / mag, fz / mag])  # 3 x n
-    cams = cam[idx]
+    cams = sub_cams
     counts = [int((cams == 0).sum()), int((cams == 1).sum())]
     majority = 0 if counts[0] >= counts[1] else 1  # maxCoeff: first maximum
     M3 = np.zeros((3, 3))
@@ -141,7 +164,7 @@ def frame_lapack(xyz, cam, cam_origins, sample_index, **search_kw):
     G = (nrm[0][:, None] * nrm[0][None, :] + nrm[1][:, None] * nrm[1][None, :]) + nrm[2][:, None] * nrm[2][None, :]
     col = seqsum(np.power(G, 6.0))  # quadric.cpp:283: .array().pow(6).colwise().sum()
     mx = 0
-    for k in range(1, n):
+    for k in range(1, nrm.shape[1]):
         if col[k] > col[mx]:
             mx = k
     P = np.eye(3) - np.outer(axis, axis)
@@ -200,14 +223,19 @@ def compare_lists(a, b):
     return rep, common, ka, kb
 
 
-def run_case(name, n_samples, w, rho, **search_kw):
+def run_case(name, n_samples, w, rho, rand50=False, **search_kw):
     sc = synthetic.config(name)
     samples = sc.samples[:n_samples]
-    p = O.default_params(sc.cam_origins)
+    p = O.default_params(sc.cam_origins, normals_mode=O.NORMALS_RAND50 if rand50 else O.NORMALS_DETERMINISTIC, rand_seed=1)
     frames = np.zeros(len(samples), O.FRAME_DTYPE)
     extras = []
+    if rand50:
+        import ctypes
+
+        libc_rand()
+        _LIBC.srand(ctypes.c_uint(1))
     for k, s in enumerate(samples):
-        frames[k], ex = frame_lapack(sc.xyz, sc.cam, sc.cam_origins, int(s), **search_kw)
+        frames[k], ex = frame_lapack(sc.xyz, sc.cam, sc.cam_origins, int(s), rand50=rand50, **search_kw)
         extras.append(ex)
     res = O.hands_from_frames(p, sc.xyz, sc.cam, samples, frames, want_images=True)
     keep, sums = O.classify(res["images"], w, rho)
@@ -219,7 +247,7 @@ def run_case(name, n_samples, w, rho, **search_kw):
     pos_a = {(int(h["sample"]), int(h["orientation"])): i for i, h in enumerate(res["hyps"])}
     pos_b = {(int(h["sample"]), int(h["orientation"])): i for i, h in enumerate(own["hyps"])}
     rep.update({
-        "case": name, "samples": int(len(samples)), "oracle_invalid_frames": int((~valid).sum()),
+        "case": name + ("_rand50" if rand50 else ""), "samples": int(len(samples)), "oracle_invalid_frames": int((~valid).sum()),
         "dggev_info_nonzero": int(sum(e["info"] != 0 for e in extras)),
         "dggev_one_ulp_input_max_angle_rad": float(max(e["self_angle"] for e in extras)),
         "dggev_one_ulp_input_median_angle_rad": float(np.median([e["self_angle"] for e in extras])),
@@ -247,19 +275,22 @@ def run_case(name, n_samples, w, rho, **search_kw):
 def main():
     w, rho = O.load_svm(os.path.join(ROOT, "tests", "golden", "svm_032015_linear_20_20_same"))
     store, report = {}, []
-    for name, ns in CASES:
-        sc, samples, frames, hyps, keep, sums, rep = run_case(name, ns, w, rho)
+    for name, ns, r50 in CASES:
+        sc, samples, frames, hyps, keep, sums, rep = run_case(name, ns, w, rho, rand50=r50)
         report.append(rep)
         print(json.dumps(rep))
-        store[f"{name}_samples"] = samples.astype(np.int32)
-        store[f"{name}_frames"] = frames
-        store[f"{name}_hyps"] = hyps
-        store[f"{name}_keep"] = keep
-        store[f"{name}_sums"] = sums
+        key = name + ("_rand50" if r50 else "")
+        store[f"{key}_samples"] = samples.astype(np.int32)
+        store[f"{key}_frames"] = frames
+        store[f"{key}_hyps"] = hyps
+        store[f"{key}_keep"] = keep
+        store[f"{key}_sums"] = sums
     # FLANN sensitivity (the radius criterion and the order of equal distances are the builder's reading of FLANN)
     sens = []
     for variant, kw in (("inclusive_radius", dict(inclusive=True)), ("ties_descending", dict(ties_descending=True))):
-        for name, ns in CASES:
+        for name, ns, r50 in CASES:
+            if r50:
+                continue
             _, _, frames_v, hyps_v, keep_v, _, _ = run_case(name, ns, w, rho, **kw)
             base_h, base_k = store[f"{name}_hyps"], store[f"{name}_keep"]
             rep, common, ka, kb = compare_lists(hyps_v, base_h)
