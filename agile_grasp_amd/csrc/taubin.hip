@@ -392,11 +392,14 @@ __device__ __forceinline__ double shfl16(double v, int src_in_group, int gbase)
 template <int N>
 __device__ __forceinline__ double bcast16(double v)
 {
+  // one v_mov_b64_dpp: gfx90a+ carries 64-bit operands through DPP for row_newbcast (two 32-bit moves otherwise)
+#if defined(__HIP_DEVICE_COMPILE__)
   const long long x = __builtin_bit_cast(long long, v);
-  int lo = (int) x, hi = (int) (x >> 32);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + N, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + N, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((long long) hi << 32) | (long long) (unsigned) lo);
+  const long long y = __builtin_amdgcn_update_dpp((long long) 0, x, 0x150 + N, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, y);
+#else
+  return v;  // (host pass of the single-source compile: the 64-bit form of the builtin only exists for the device)
+#endif
 }
 template <int N>
 __device__ __forceinline__ int bcast16(int v)
