@@ -24,6 +24,8 @@
 // No MFMA: fp64 separately-rounded mul/add is required for bit parity (MFMA fuses), and the work is LDS/VALU bound.
 #include "agh_internal.h"
 
+#include <utility>
+
 namespace agh
 {
 
@@ -428,20 +430,21 @@ __device__ __forceinline__ void rr_gather(const double (&ar)[9], int kk, double&
   aqq = mine ? x_qq : aqq;
 }
 
+// A pair that is not rotated carries the identity (c = 1, s = 0), and applying it is exact: 1 * x - 0 * y = x bit for bit
+// for every finite x, y except x = -0 with y < 0 -- and these matrices never hold a negative zero (they are built from
+// sums that start at +0, quotients by positive pivots, and entries that are cleared to +0).  So the column and row phases
+// carry no selects: a fifth of the sweep's instructions were v_cndmask pairs guarding updates that are no-ops anyway.
 template <int R, int K>
-__device__ __forceinline__ void rr_columns(double (&ar)[9], double (&vr)[9], double c, double sn, int flag)
+__device__ __forceinline__ void rr_columns(double (&ar)[9], double (&vr)[9], double c, double sn)
 {
   constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
   const double ck = bcast16<p>(c), sk = bcast16<p>(sn);
-  const bool fk = bcast16<p>(flag) == 1;
   const double akp = ar[p], akq = ar[q];
-  const double np_ = ck * akp - sk * akq, nq_ = sk * akp + ck * akq;
-  ar[p] = fk ? np_ : akp;
-  ar[q] = fk ? nq_ : akq;
+  ar[p] = ck * akp - sk * akq;
+  ar[q] = sk * akp + ck * akq;
   const double vkp = vr[p], vkq = vr[q];
-  const double vp_ = ck * vkp - sk * vkq, vq_ = sk * vkp + ck * vkq;
-  vr[p] = fk ? vp_ : vkp;
-  vr[q] = fk ? vq_ : vkq;
+  vr[p] = ck * vkp - sk * vkq;
+  vr[q] = sk * vkp + ck * vkq;
 }
 
 template <int R, int K>
@@ -497,21 +500,19 @@ __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], i
   const double sn = rot ? (neg ? -sb : sb) : 0.0;
   const int flag = rot ? 1 : (cand ? 2 : 0);  // 1 rotate, 2 zero only
   // (3) column phase A <- A J, V <- V J: this lane's row, all four pairs (parameters from the pair's first lane)
-  rr_columns<R, 1>(ar, vr, c, sn, flag);
-  rr_columns<R, 2>(ar, vr, c, sn, flag);
-  rr_columns<R, 3>(ar, vr, c, sn, flag);
-  rr_columns<R, 4>(ar, vr, c, sn, flag);
+  rr_columns<R, 1>(ar, vr, c, sn);
+  rr_columns<R, 2>(ar, vr, c, sn);
+  rr_columns<R, 3>(ar, vr, c, sn);
+  rr_columns<R, 4>(ar, vr, c, sn);
   // (4) row phase A <- J^T A: rows p and q of a pair are the two lanes of the pair; each fetches its mate's row.
   //     Row p: c a_p - s a_q; row q: s a_p + c a_q = c a_q - (-s) a_p (IEEE addition commutes).
   const double se = is_p ? sn : -sn;
-  const bool rot_row = flag == 1;
 #pragma unroll
   for (int j = 0; j < 9; j++)
   {
     const double own = ar[j];
     const double other = shfl16(own, mate, gbase);
-    const double nv = c * own - se * other;
-    ar[j] = rot_row ? nv : own;
+    ar[j] = c * own - se * other;  // (identity for a lane whose pair does not rotate, see rr_columns)
   }
   // (5) the rotated entries are exactly zero (both triangles)
   const bool zero_it = flag != 0;
@@ -519,6 +520,51 @@ __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], i
   rr_zero<R, 2>(ar, kk, gl, zero_it);
   rr_zero<R, 3>(ar, kk, gl, zero_it);
   rr_zero<R, 4>(ar, kk, gl, zero_it);
+}
+
+// ---- the reduction M v = lambda N v -> C y = lambda y (Cholesky N9 = L L^T, Y = L^-1 S, C = Y L^-T) with the matrices in
+// registers: lane gl of a 16-lane group holds row gl of N9, of L and of C, and column gl of S (= row gl: S is symmetric
+// bit for bit) and of Y.  Every dot product runs in the index order of the oracle's loops; an operand that belongs to
+// another row arrives by a DPP row broadcast, so the chains carry no LDS round trips.
+template <int J, int... K>
+__device__ __forceinline__ double chol_dot(double t, const double (&lrow)[9], std::integer_sequence<int, K...>)
+{
+  ((t -= lrow[K] * bcast16<J>(lrow[K])), ...);  // t -= L[i][k] * L[J][k], k = 0 .. J-1 in order
+  return t;
+}
+template <int J>
+__device__ __forceinline__ void chol_step(const double (&nrow)[9], double (&lrow)[9], int gl, int& fail)
+{
+  const double t = chol_dot<J>(nrow[J], lrow, std::make_integer_sequence<int, J>{});
+  const bool mine = gl == J;
+  const bool bad = mine && !(t > 0.0);  // N9 not positive definite: no frame (the sample is dropped loudly downstream)
+  fail |= bcast16<J>(bad ? 1 : 0);
+  const double ljj = bcast16<J>(sqrt((mine && !bad) ? t : 1.0));
+  lrow[J] = mine ? ljj : (gl > J ? t / ljj : 0.0);
+}
+template <int R, int... K>
+__device__ __forceinline__ double ysolve_dot(double t, const double (&lrow)[9], const double (&ycol)[9], std::integer_sequence<int, K...>)
+{
+  ((t -= bcast16<R>(lrow[K]) * ycol[K]), ...);  // t -= L[R][k] * Y[k][j]
+  return t;
+}
+template <int R>
+__device__ __forceinline__ void ysolve_step(const double (&srow)[9], const double (&lrow)[9], double (&ycol)[9])
+{
+  const double t = ysolve_dot<R>(srow[R], lrow, ycol, std::make_integer_sequence<int, R>{});
+  ycol[R] = t / bcast16<R>(lrow[R]);
+}
+template <int J, int... K>
+__device__ __forceinline__ double csolve_dot(double t, const double (&lrow)[9], const double (&crow)[9], std::integer_sequence<int, K...>)
+{
+  ((t -= crow[K] * bcast16<J>(lrow[K])), ...);  // t -= C[i][k] * L[J][k]
+  return t;
+}
+template <int J>
+__device__ __forceinline__ void csolve_step(const double (&yrow)[9], const double (&lrow)[9], double (&crow)[9])
+{
+  const double t = csolve_dot<J>(yrow[J], lrow, crow, std::make_integer_sequence<int, J>{});
+  crow[J] = t / bcast16<J>(lrow[J]);
 }
 
 struct EigSmem
@@ -685,67 +731,65 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
   __syncthreads();
   const bool row = gl < 9;
   const int i = gl;
-  if (row)
-    for (int j = 0; j < 9; j++)
-    {
-      E.A[i][j] = E.M[i][j] - (E.M[i][9] * E.M[j][9]) / n;
-      E.L[i][j] = 0.0;
-    }
-  __syncthreads();
-  // Cholesky N9 = L L^T
+  const int ic = row ? gl : 0;  // (lanes 9..15 of a group compute along on row 0 and are never read)
+  double nrow[9], srow[9], lrow[9], ycol[9], yrow[9], crow[9];
+#pragma unroll
   for (int j = 0; j < 9; j++)
   {
-    if (gl == j)
-    {
-      double sum = E.N[j][j];
-      for (int k = 0; k < j; k++)
-        sum -= E.L[j][k] * E.L[j][k];
-      if (!(sum > 0.0))
-      {
-        E.fail = 1;
-        sum = 1.0;
-      }
-      E.L[j][j] = sqrt(sum);
-    }
-    __syncthreads();
-    if (row && i > j)
-    {
-      double s2 = E.N[i][j];
-      for (int k = 0; k < j; k++)
-        s2 -= E.L[i][k] * E.L[j][k];
-      E.L[i][j] = s2 / E.L[j][j];
-    }
-    __syncthreads();
+    srow[j] = E.M[ic][j] - (E.M[ic][9] * E.M[j][9]) / n;  // S = M9 - m m^T / n (the 10th unknown eliminated)
+    nrow[j] = E.N[ic][j];
+    lrow[j] = 0.0;
   }
-  // Y = L^-1 S (lane = column)
+  int fail = 0;
+  chol_step<0>(nrow, lrow, gl, fail);
+  chol_step<1>(nrow, lrow, gl, fail);
+  chol_step<2>(nrow, lrow, gl, fail);
+  chol_step<3>(nrow, lrow, gl, fail);
+  chol_step<4>(nrow, lrow, gl, fail);
+  chol_step<5>(nrow, lrow, gl, fail);
+  chol_step<6>(nrow, lrow, gl, fail);
+  chol_step<7>(nrow, lrow, gl, fail);
+  chol_step<8>(nrow, lrow, gl, fail);
+  if (gl == 0 && fail)
+    E.fail = 1;
+  ysolve_step<0>(srow, lrow, ycol);
+  ysolve_step<1>(srow, lrow, ycol);
+  ysolve_step<2>(srow, lrow, ycol);
+  ysolve_step<3>(srow, lrow, ycol);
+  ysolve_step<4>(srow, lrow, ycol);
+  ysolve_step<5>(srow, lrow, ycol);
+  ysolve_step<6>(srow, lrow, ycol);
+  ysolve_step<7>(srow, lrow, ycol);
+  ysolve_step<8>(srow, lrow, ycol);
+  // Y is held by columns and C is built by rows: one transposition through LDS; L goes along for the back substitution
   if (row)
   {
-    const int j = gl;
+#pragma unroll
     for (int r = 0; r < 9; r++)
     {
-      double s2 = E.A[r][j];
-      for (int k = 0; k < r; k++)
-        s2 -= E.L[r][k] * E.Y[k][j];
-      E.Y[r][j] = s2 / E.L[r][r];
+      E.Y[r][i] = ycol[r];
+      E.L[i][r] = lrow[r];
     }
   }
   __syncthreads();
-  // C = Y L^-T (lane = row), lower triangle mirrored
+#pragma unroll
+  for (int j = 0; j < 9; j++)
+    yrow[j] = E.Y[ic][j];
+  csolve_step<0>(yrow, lrow, crow);
+  csolve_step<1>(yrow, lrow, crow);
+  csolve_step<2>(yrow, lrow, crow);
+  csolve_step<3>(yrow, lrow, crow);
+  csolve_step<4>(yrow, lrow, crow);
+  csolve_step<5>(yrow, lrow, crow);
+  csolve_step<6>(yrow, lrow, crow);
+  csolve_step<7>(yrow, lrow, crow);
+  csolve_step<8>(yrow, lrow, crow);
   if (row)
+  {
+#pragma unroll
     for (int j = 0; j < 9; j++)
-    {
-      double s2 = E.Y[i][j];
-      for (int k = 0; k < j; k++)
-        s2 -= E.A[i][k] * E.L[j][k];
-      E.A[i][j] = s2 / E.L[j][j];
-    }
-  __syncthreads();
-  if (row)
-    for (int j = i + 1; j < 9; j++)
-      E.A[i][j] = E.A[j][i];
-  if (row)
-    for (int j = 0; j < 9; j++)
-      E.V[i][j] = (i == j) ? 1.0 : 0.0;
+      E.A[i][j] = crow[j];
+  }
   __syncthreads();
   // round-robin Jacobi (oracle jacobi_rr9) with the matrices in registers: lane gl of a 16-lane group holds row gl of A
   // and of V.  The nine rounds of a sweep are unrolled so that every register index is a compile-time constant;
@@ -754,7 +798,7 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 9; j++)
   {
-    ar[j] = row ? E.A[i][j] : 0.0;
+    ar[j] = row ? (j > i ? E.A[j][ic] : crow[j]) : 0.0;  // the lower triangle mirrored into the upper one
     vr[j] = (row && i == j) ? 1.0 : 0.0;
   }
   const int gbase = lane & ~15;
