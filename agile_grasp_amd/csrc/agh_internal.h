@@ -261,6 +261,7 @@ struct Ctx
   agh_hypothesis* shard_out = nullptr;  // the caller's merged list of the last sharded search
   int64_t shard_cap = 0;
   int64_t* shard_nout = nullptr;
+  int64_t shard_last_n = -1;            // length of the merged list, once a host entry point has read it
 
   long long* d_dbg = nullptr;  // AGH_DEBUG_CLOCKS: per-sample phase timestamps of k_hand_sweep (dumped to a file)
   int debug_stop_sweep = 0;    // AGH_DEBUG_STOP_SWEEP: phase-timing aid, see k_hand_sweep

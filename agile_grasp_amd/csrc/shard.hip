@@ -418,6 +418,16 @@ int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records)
   return AGH_OK;
 }
 
+int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp)
+{
+  if (!ctx || !n_hyp)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (!ctx->c.comm || !ctx->c.shard_out)
+    return AGH_ERR_STATE;
+  *n_hyp = ctx->c.shard_last_n;
+  return AGH_OK;
+}
+
 int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks)
 {
   if (!ctx)
@@ -495,6 +505,7 @@ int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int
   c->shard_out = d_out;
   c->shard_cap = cap;
   c->shard_nout = d_n_out;
+  c->shard_last_n = -1;
   uint8_t* my_seg = c->d_xbuf + (int64_t) r * seg_bytes;
   agh_hypothesis* my_out = reinterpret_cast<agh_hypothesis*>(my_seg + kHeaderBytes);
   int64_t* my_count = reinterpret_cast<int64_t*>(my_seg);
@@ -706,6 +717,7 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
   if (rc != AGH_OK)
     return rc;
   *n_out = n;
+  c->shard_last_n = n;
   if (n > cap)
   {
     c->err = "output buffer too small for the hypotheses found";

@@ -264,6 +264,9 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
 int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks);
 int agh_comm_destroy(agh_ctx* ctx);
 int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks); /* 0 / 1 without a communicator */
+/* Length of the merged list of the last agh_find_hands_sharded (host variant) of this context; AGH_ERR_STATE if the context
+ * has no communicator or has not run a sharded search. */
+int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp);
 /* Tuning: record slots of one rank's exchange segment (0 = the default described at agh_find_hands_sharded_device; values
  * above 8 per sample are clipped).  Every rank must use the same value. */
 int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records);

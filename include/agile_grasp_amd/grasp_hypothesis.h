@@ -139,6 +139,17 @@ public:
       return nullptr;
     return link_->ctx;
   }
+  /** The context if it is still at this hypothesis' call (epoch), whatever the position: what a sharded search's list, whose
+   *  positions count over all ranks, is matched by. */
+  agh_ctx* getContextAtEpoch() const
+  {
+    if (!link_ || !link_->ctx || device_index_ < 0)
+      return nullptr;
+    std::int32_t e = 0;
+    if (agh_get_epoch(link_->ctx, &e, nullptr) != AGH_OK || e != epoch_)
+      return nullptr;
+    return link_->ctx;
+  }
   /** Any context this hypothesis' search still owns (for work that needs a device but none of the search's state). */
   agh_ctx* getAnyContext() const { return link_ ? link_->ctx : nullptr; }
 

@@ -162,6 +162,45 @@ public:
   /** The sample indices of the most recent findHands (the given ones, or the ones drawn for an empty list). */
   const std::vector<std::int32_t>& getLastSampleIndices() const { return last_samples_; }
 
+  /** Multi-GPU (one process -- or, with joinLocalCommunicator, one host thread -- per GPU): after this call findHands is a
+   *  COLLECTIVE: every rank passes the same cloud and the same `indices`, searches the slice [rank S / n, (rank + 1) S / n)
+   *  of the samples (the reference's OpenMP fan-out over samples, hand_search.cpp:78,136, across GPUs) and receives the
+   *  complete list through one RCCL all-gather issued by the library (agh_find_hands_sharded).  `id`: the bytes of
+   *  agh_comm_unique_id() from ONE rank, handed to the others out of band.  Returns false (after printing why) on error. */
+  bool joinCommunicator(int rank, int n_ranks, const std::uint8_t id[AGH_COMM_ID_BYTES])
+  {
+    if (!ensureContext())
+      return false;
+    if (agh_comm_init(ctx_, rank, n_ranks, id) != AGH_OK)
+    {
+      std::cout << " Error in agh_comm_init: " << agh_last_error(ctx_) << "\n";
+      return false;
+    }
+    sharded_ = true;
+    return true;
+  }
+  /** The same for searches that live in ONE process (one host thread each; they may share a GPU): the exchange is device
+   *  copies instead of RCCL -- how the sharded schedule is validated on a single-GPU machine. */
+  static bool joinLocalCommunicator(const std::vector<HandSearch*>& searches)
+  {
+    std::vector<agh_ctx*> ctxs;
+    for (std::size_t i = 0; i < searches.size(); i++)
+    {
+      if (!searches[i] || !searches[i]->ensureContext())
+        return false;
+      ctxs.push_back(searches[i]->ctx_);
+    }
+    if (agh_comm_init_local(ctxs.data(), (std::int32_t) ctxs.size()) != AGH_OK)
+    {
+      std::cout << " Error in agh_comm_init_local\n";
+      return false;
+    }
+    for (std::size_t i = 0; i < searches.size(); i++)
+      searches[i]->sharded_ = true;
+    return true;
+  }
+  bool isSharded() const { return sharded_; }
+
   /** Training runs (src/nodes/train.cpp): every findHands(calculates_antipodal = true) also attaches the three
    *  instance images to its hypotheses (GraspHypothesis::getTrainingImage), the input of Learning::train*. */
   void setKeepsTrainingImages(bool b) { keeps_training_images_ = b; }
@@ -264,10 +303,24 @@ public:
       return fail("agh_set_training_images");
     std::vector<agh_hypothesis> out(8 * idx.size() + 1);
     std::int64_t n_out = 0;
-    const int rc = agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
-      (std::int64_t) out.size(), &n_out);
+    const int rc = sharded_
+      ? agh_find_hands_sharded(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
+          (std::int64_t) out.size(), &n_out)
+      : agh_find_hands(ctx_, idx.data(), (std::int64_t) idx.size(), calculates_antipodal ? 1 : 0, out.data(),
+          (std::int64_t) out.size(), &n_out);
     if (rc != AGH_OK)
-      return fail("agh_find_hands");
+      return fail(sharded_ ? "agh_find_hands_sharded" : "agh_find_hands");
+    if (sharded_)
+    {
+      // every rank holds the complete list; the device-side state (images, points) of a hypothesis lives on the rank that
+      // searched its sample, so the hypotheses carry no image here and Learning::classify goes through the collective
+      // agh_classify_sharded (see learning.h)
+      hand_list.reserve((std::size_t) n_out);
+      for (std::int64_t i = 0; i < n_out; i++)
+        hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i, link_));
+      std::cout << " Found " << hand_list.size() << " robot hand poses\n";
+      return hand_list;
+    }
     hand_list.reserve((std::size_t) n_out);
     for (std::int64_t i = 0; i < n_out; i++)
       hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i, link_));
@@ -338,6 +391,7 @@ private:
   bool dirty_;
   bool keeps_training_images_ = false;
   bool keeps_images_ = true;
+  bool sharded_ = false;
   std::shared_ptr<detail::SearchLink> link_;
 };
 

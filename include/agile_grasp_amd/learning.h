@@ -66,7 +66,25 @@ public:
     }
     const std::size_t n = hands_list.size();
     std::vector<unsigned char> keep_of(n, 0);  // per list entry
-    bool all_live = n > 0;
+    // the list of a sharded findHands (HandSearch::joinCommunicator)?  Then classify is a COLLECTIVE like that search was:
+    // each rank scores the hypotheses of its own samples, the labels travel with a second all-gather of the lists
+    std::int64_t n_merged = -1;
+    bool sharded_now = n > 0 && agh_comm_last_count(ctx, &n_merged) == AGH_OK && n_merged >= 0;
+    for (std::size_t i = 0; i < n && sharded_now; i++)
+      sharded_now = hands_list[i].getContextAtEpoch() == ctx && hands_list[i].getDeviceIndex() < n_merged;
+    if (sharded_now)
+    {
+      std::vector<unsigned char> keep((std::size_t) n_merged + 1, 0);
+      std::int64_t n_kept = 0;
+      if (agh_classify_sharded(ctx, nullptr, keep.data(), (std::int64_t) keep.size(), &n_kept) != AGH_OK)
+      {
+        std::cout << " Error: " << agh_last_error(ctx) << "\n";
+        return antipodal_hands;
+      }
+      for (std::size_t i = 0; i < n; i++)
+        keep_of[i] = keep[(std::size_t) hands_list[i].getDeviceIndex()];
+    }
+    bool all_live = n > 0 && !sharded_now;
     for (std::size_t i = 0; i < n && all_live; i++)
       all_live = hands_list[i].getLiveContext() == ctx;
     if (all_live)
@@ -88,7 +106,7 @@ public:
       for (std::size_t i = 0; i < n; i++)
         keep_of[i] = keep[(std::size_t) hands_list[i].getDeviceIndex()];
     }
-    else if (n > 0)
+    else if (n > 0 && !sharded_now)
     {
       std::vector<std::uint32_t> images(n * 250);
       for (std::size_t i = 0; i < n; i++)

@@ -165,3 +165,37 @@ def test_rccl_communicator_of_one(tiny_scene, svm_model):
     anti = ctx.find_hands_sharded(sc.samples, calculates_antipodal=True)
     ctx.comm_destroy()
     _same(anti, ctx.find_hands(sc.samples, calculates_antipodal=True))
+
+
+def test_cpp_adapter_sharded_search(tmp_path, small_scene, svm_model):
+    """The C++ host side: HandSearch::joinLocalCommunicator / findHands / Learning::classify as collectives (one host thread
+    per rank), against the single-GPU C ABI."""
+    import os
+    import subprocess
+
+    from agile_grasp_amd import binding, build
+    from tests.test_cpp_adapter import GOLD, ROOT, _dump
+
+    build.build()
+    sc = small_scene
+    exe = str(tmp_path / "sharded_test")
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sharded_test.cpp"), "-o", exe, "-L" + libdir, "-lagile_grasp_hip",
+                           "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    cloud = str(tmp_path / "cloud.bin")
+    _dump(sc, cloud)
+    out = subprocess.run([exe, cloud, os.path.join(GOLD, "svm_032015_linear_20_20_same"), "3"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    ctx = binding.Context(sc.cam_origins)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(sc.samples)
+    ctx.load_svm(*svm_model)
+    keep = ctx.classify()
+    exp = [[float(h["surface"][0]), float(h["bottom"][1]), float(h["approach"][2]), float(h["width"])] for h in hyps]
+    for g in range(3):
+        assert f"RANK {g} {len(hyps)} {int(keep.sum())}" in lines
+        assert [[float(v) for v in l.split()[1:]] for l in lines if l.startswith(f"H{g} ")] == exp
+        assert [int(l.split()[1]) for l in lines if l.startswith(f"K{g} ")] == list(np.nonzero(keep)[0])
