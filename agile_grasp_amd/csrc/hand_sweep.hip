@@ -25,6 +25,27 @@
 namespace agh
 {
 
+#ifdef AGH_DEBUG_HOOKS
+#define AGH_DBG_AND(x) &&(x)
+#else
+#define AGH_DBG_AND(x)
+#endif
+
+// fmin / fmax for values that are never NaN: one v_min_f64 / v_max_f64.  (The library functions quiet signalling NaNs first
+// -- a `v_max_f64 x, x, x` per operand in IEEE mode -- which tripled the cost of the running minima in the point loops.)
+__device__ __forceinline__ double min_f64_raw(double a, double b)
+{
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct OriState
 {
   double T[3][3];  // frame_ * rot^T
@@ -354,6 +375,10 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   const int K = G.n_depths;
   // ---- pass A: classify every cropped point once per orientation ----
   double ymin_w[2] = { INFINITY, INFINITY }, ymax_w[2] = { -INFINITY, -INFINITY };
+  // The inner loop is written in STAGES over four points per lane -- rotate, y look-up, x look-up, table update -- with no
+  // control flow between the stages: each look-up is a chain of two dependent LDS reads, and with a branch per point (the
+  // earlier form) the compiler waited for every read before issuing the next point's, sixteen exposed LDS round trips per
+  // iteration instead of four.  Points beyond the deepest bite depth take the x look-up along and are masked at the update.
   auto classify = [&](int nc) {
     for (int oo = 0; oo < 2; oo++)
     {
@@ -362,51 +387,65 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         continue;
       const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
       double ymin = ymin_w[oo], ymax = ymax_w[oo];
+      const double ylo = G.ylut_lo, ysc = G.ylut_scale, xlo = G.xlut_lo, xsc = G.xlut_scale;
       for (int t0 = lane; t0 < nc; t0 += 256)
       {
-        // Four independent points per lane, straight-line code (no data-dependent loops), so that the LDS look-ups of
-        // the four points overlap.
+        const bool full = (t0 - lane) + 256 <= nc;  // wave-uniform: every lane has its four points
         double xr[4], yr[4];
-  #pragma unroll
+        bool act[4];
+#pragma unroll
         for (int u = 0; u < 4; u++)
         {
           const int t = t0 + 64 * u;
-          const bool act = t < nc;
-          const double2 p = pts[act ? t : 0];
+          act[u] = full || t < nc;
+          const double2 p = pts[act[u] ? t : 0];
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
-          yr[u] = act ? (sn * p.x + cs * p.y) : INFINITY;
-          if (act)
-          {
-            ymin = fmin(ymin, yr[u]);
-            ymax = fmax(ymax, yr[u]);
-          }
+          yr[u] = sn * p.x + cs * p.y;
         }
-        // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
-  #pragma unroll
+#pragma unroll
         for (int u = 0; u < 4; u++)
         {
-          const int cy = (int) fmin(fmax((yr[u] - G.ylut_lo) * G.ylut_scale, 0.0), 63.0);
-          const int ly = G.ylut[cy];
-          int yk = ly;
-  #pragma unroll
+          ymin = min_f64_raw(ymin, act[u] ? yr[u] : INFINITY);
+          ymax = max_f64_raw(ymax, act[u] ? yr[u] : -INFINITY);
+        }
+        // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
+        int ly[4], lx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+          const int cy = (int) fmin(fmax((yr[u] - ylo) * ysc, 0.0), 63.0);
+          const int cx = (int) fmin(fmax((xr[u] - xlo) * xsc, 0.0), 1023.0);
+          ly[u] = G.ylut[cy];
+          lx[u] = G.xlut[cx];
+        }
+        double dv[4][PY], tv[4][PX];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+#pragma unroll
           for (int j = 0; j < PY; j++)
-            yk += (dep_s[ly + j] <= yr[u]) ? 1 : 0;
-          if (yk < K && debug_stop != 11)
+            dv[u][j] = dep_s[ly[u] + j];
+#pragma unroll
+          for (int j = 0; j < PX; j++)
+            tv[u][j] = thr_s[lx[u] + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+          int yk = ly[u];
+#pragma unroll
+          for (int j = 0; j < PY; j++)
+            yk += (dv[u][j] <= yr[u]) ? 1 : 0;
+          int c = lx[u], e = 0;
+#pragma unroll
+          for (int j = 0; j < PX; j++)
           {
-            const int cx = (int) fmin(fmax((xr[u] - G.xlut_lo) * G.xlut_scale, 0.0), 1023.0);
-            const int lx = G.xlut[cx];
-            int c = lx, e = 0;
-  #pragma unroll
-            for (int j = 0; j < PX; j++)
-            {
-              const double tv = thr_s[lx + j];
-              c += (tv < xr[u]) ? 1 : 0;
-              e |= (tv == xr[u]) ? 1 : 0;
-            }
-            const int key = 2 * c + e;
-            if (debug_stop != 10)
-              atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
+            c += (tv[u][j] < xr[u]) ? 1 : 0;
+            e |= (tv[u][j] == xr[u]) ? 1 : 0;
           }
+          const int key = 2 * c + e;
+          if (act[u] && yk < K AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
+            atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
         }
       }
       ymin_w[oo] = ymin;
