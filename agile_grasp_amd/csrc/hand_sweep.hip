@@ -635,42 +635,48 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
         int nbox = 0, numl = 0, numr = 0;
         for (int t0 = lane; t0 < nc; t0 += 256)
         {
-          // four independent points per lane (straight-line code: the two exactly-rounded divisions of each point
-          // overlap with those of the others)
+          // four independent points per lane in stages (straight-line code: the two exactly-rounded divisions of each point
+          // overlap with those of the others; the image update is the only predicated part)
+          const bool full = (t0 - lane) + 256 <= nc;
           double xr[4], yr[4];
           bool act[4];
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
             const int t = t0 + 64 * u;
-            act[u] = t < nc;
+            act[u] = full || t < nc;
             const double2 p = pts[act[u] ? t : 0];
             xr[u] = cs * p.x + ms * p.y;
             yr[u] = sn * p.x + cs * p.y;
           }
+          int bit[4];
+          bool inbox[4];
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
-            if (act[u] && yr[u] < bite && xr[u] > left && xr[u] < right)  // finger_hand.cpp:158-167
-            {
-              wmin = fmin(wmin, xr[u]);
-              wmax = fmax(wmax, xr[u]);
-            }
+            const bool inw = act[u] && yr[u] < bite && xr[u] > left && xr[u] < right;  // finger_hand.cpp:158-167
+            wmin = min_f64_raw(wmin, inw ? xr[u] : 100000.0);   // (the sentinels are the initial values: no-ops)
+            wmax = max_f64_raw(wmax, inw ? xr[u] : -100000.0);
             const double bx = xr[u] - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
             const double by = yr[u] - sfy;
             const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
             const double vy = (by - 0.0) / img_cell;
-            if (act[u] && yr[u] < box_y)  // rotating_hand.cpp:125-130
+            inbox[u] = act[u] && yr[u] < box_y;  // rotating_hand.cpp:125-130
+            int hc = (int) floor(hx), vc = (int) floor(vy);
+            hc = min(99, max(0, hc));
+            vc = min(79, max(0, vc));
+            bit[u] = (79 - vc) * 100 + hc;
+            nbox += inbox[u] ? 1 : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            if (inbox[u])
             {
-              nbox++;
-              int hc = (int) floor(hx), vc = (int) floor(vy);
-              hc = min(99, max(0, hc));
-              vc = min(79, max(0, vc));
-              const int bit = (79 - vc) * 100 + hc;
               if (TRAIN)  // pid = (index << 1) | camera
-                atomicOr(&img[o + 8 * (int) (pid[t0 + 64 * u] & 1u)][bit >> 5], 1u << (bit & 31));
+                atomicOr(&img[o + 8 * (int) (pid[t0 + 64 * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
               else
-                atomicOr(&img[o][bit >> 5], 1u << (bit & 31));
+                atomicOr(&img[o][bit[u] >> 5], 1u << (bit[u] & 31));
               if (NORMALS)
               {
                 const double* nn = normals + 3 * (int64_t) (pid[t0 + 64 * u] >> 1);
