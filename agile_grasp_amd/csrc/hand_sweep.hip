@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
   // ~1/8 of the lanes that survive costs more than computing the hand-frame coordinates for all of them.
   auto classify1 = [&](const float4& p, bool have, bool& inball, bool& keep, double& tx, double& ty) {
     const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
-    inball = have && d2 < r2f;
+    inball = have & (d2 < r2f);
     const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
     const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
-    keep = inball && (tz > -1.0 * hh) && (tz < hh);
+    keep = inball & (tz > -1.0 * hh) & (tz < hh);  // (bitwise: no exec-mask regions around three compares)
     tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
     ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
   };
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
     }
   };
   auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
-    h0 = r < nrows && i + lane < len;
-    h1 = r < nrows && i + 64 + lane < len;
+    h0 = (r < nrows) & (i + lane < len);
+    h1 = (r < nrows) & (i + 64 + lane < len);
     // unconditional loads (a lane without a candidate reads element 0 and ignores it): a load under a branch would
     // be waited for at the join, which is exactly the latency the pipeline is there to hide
     p0 = gv.sorted[h0 ? rb + i + lane : 0];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
             e |= (tv[u][j] == xr[u]) ? 1 : 0;
           }
           const int key = 2 * c + e;
-          if (act[u] && yk < K AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
+          if (act[u] & (yk < K) AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
             atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
         }
       }
@@ -654,14 +654,14 @@ __global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom*
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
-            const bool inw = act[u] && yr[u] < bite && xr[u] > left && xr[u] < right;  // finger_hand.cpp:158-167
+            const bool inw = act[u] & (yr[u] < bite) & (xr[u] > left) & (xr[u] < right);  // finger_hand.cpp:158-167
             wmin = min_f64_raw(wmin, inw ? xr[u] : 100000.0);   // (the sentinels are the initial values: no-ops)
             wmax = max_f64_raw(wmax, inw ? xr[u] : -100000.0);
             const double bx = xr[u] - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
             const double by = yr[u] - sfy;
             const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
             const double vy = (by - 0.0) / img_cell;
-            inbox[u] = act[u] && yr[u] < box_y;  // rotating_hand.cpp:125-130
+            inbox[u] = act[u] & (yr[u] < box_y);  // rotating_hand.cpp:125-130
             int hc = (int) floor(hx), vc = (int) floor(vy);
             hc = min(99, max(0, hc));
             vc = min(79, max(0, vc));

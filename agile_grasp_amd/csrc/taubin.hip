@@ -156,14 +156,14 @@ __global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float
       }
     };
     auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
-      h0 = r < nrows && i + lane < len;
-      h1 = r < nrows && i + 64 + lane < len;
+      h0 = (r < nrows) & (i + lane < len);
+      h1 = (r < nrows) & (i + 64 + lane < len);
       p0 = gv.sorted[h0 ? rb + i + lane : 0];  // a lane without a candidate reads element 0 and ignores it
       p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
     };
     auto take2 = [&](const float4& p0, bool h0, const float4& p1, bool h1) {
       const float d0 = flann_d2(qx, qy, qz, p0.x, p0.y, p0.z), d1 = flann_d2(qx, qy, qz, p1.x, p1.y, p1.z);
-      const bool s0 = h0 && d0 < r2f, s1 = h1 && d1 < r2f;
+      const bool s0 = h0 & (d0 < r2f), s1 = h1 & (d1 < r2f);  // (bitwise: no exec-mask regions around a compare)
       const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
       if (m0 | m1)
       {
