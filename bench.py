@@ -246,20 +246,32 @@ def main():
     # ---- the communicator of the sharded search: created by the library (C++ -> RCCL), id handed over by torch ----
     exchange = None
     if distributed:
-        try:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(binding.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            ctx.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
-            exchange = "library: ncclAllGather issued from C++ on the search's stream"
-        except Exception as e:  # keep the run alive, say so in the result line
-            exchange = f"torch.distributed all_gather_into_tensor (the library's communicator failed: {e})"
-        ok = torch.tensor([1 if exchange.startswith("library") else 0], device=dev)
+        # every rank takes part in the same sequence of collectives whatever fails locally: the id (with a validity byte) is
+        # broadcast in any case, and the outcome of comm_init is agreed on by an all-reduce
+        idt = torch.zeros(129, dtype=torch.uint8, device=dev)
+        err = None
+        if rank == 0:
+            try:
+                idt[:128] = torch.frombuffer(bytearray(binding.comm_unique_id()), dtype=torch.uint8).to(dev)
+                idt[128] = 1
+            except Exception as e:
+                err = f"agh_comm_unique_id: {e}"
+        dist.broadcast(idt, 0)
+        mine = 0
+        if int(idt[128].item()) == 1:
+            try:
+                ctx.comm_init(rank, world, bytes(idt[:128].cpu().numpy().tobytes()))
+                mine = 1
+            except Exception as e:
+                err = f"agh_comm_init: {e}"
+        ok = torch.tensor([mine], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and exchange.startswith("library"):
-            ctx.comm_destroy()
-            exchange = "torch.distributed all_gather_into_tensor (another rank's communicator failed)"
+        if int(ok.item()) == 1:
+            exchange = "library: ncclAllGather issued from C++ on the search's stream"
+        else:
+            if mine:
+                ctx.comm_destroy()
+            exchange = f"torch.distributed all_gather_into_tensor (the library's communicator failed: {err or 'on another rank'})"
     lib_comm = exchange is not None and exchange.startswith("library")
 
     S = sc.samples.size

@@ -29,11 +29,16 @@ for it in range(iters):
     if it % 8 < 2:  # the first two sizes of every round are checked against a repetition with the same inputs
         ctx.synchronize()
         k = int(n_t.item())
-        a = out_t[:k * 160].cpu().numpy().copy()
+        def records():  # without the per-call stamp (agh_hypothesis::epoch, the last word of every record)
+            r = out_t[:k * 160].cpu().numpy().copy().reshape(k, 160)
+            r[:, 156:160] = 0
+            return r
+
+        a = records()
         ctx.set_cloud_torch(xyz_t[:n], cam_t[:n], stream=ts.cuda_stream)
         ctx.find_hands_torch(s_t, out_t, n_t, stream=ts.cuda_stream)
         ctx.synchronize()
-        assert int(n_t.item()) == k and np.array_equal(out_t[:k * 160].cpu().numpy(), a), ("result changed", it, n, S)
+        assert int(n_t.item()) == k and np.array_equal(records(), a), ("result changed", it, n, S)
     if it % 500 == 499:
         ctx.synchronize()
         print("iteration", it + 1, "ok,", round(time.time() - t0, 1), "s", flush=True)
