@@ -72,3 +72,13 @@ def merge_segments(gathered: np.ndarray, world: int, n_samples: int, seg_records
         recs["sample"] += shard_slice(n_samples, g, world).start
         out.append(recs)
     return np.concatenate(out) if out else np.zeros(0, dtype)
+
+
+# ---- round-1 measurement scripts (scripts/host_overhead.py, xstream_experiment*.py) size their buffers with these ----
+def buffer_bytes(n_samples: int) -> int:
+    """A segment with all 8 slots per sample."""
+    return segment_bytes(8 * n_samples)
+
+
+def buffer_bytes_records(n_records: int) -> int:
+    return segment_bytes(n_records)

@@ -10,7 +10,7 @@
 //    setDeterministicNormalEstimation(); `false` reproduces the reference's 50 x rand() % n subsample for ONE thread;
 //  * explicit `indices` define hands_cam_source(i) = pts_cam_source(indices[i]) (the reference reads an empty vector
 //    there, hand_search.cpp:166); an empty `indices` draws num_samples indices like pcl::RandomSample (hand_search.cpp:
-//    36-39; PCL 1.7's algorithm restated, see drawSamples) -- time-seeded like PCL unless setSampleSeed() is called.
+//    36-39; PCL 1.7's algorithm restated, see randomSample) -- time-seeded like PCL unless setSampleSeed() is called.
 //  * errors follow the reference's convention: a message on std::cout and an empty vector.
 #ifndef AGILE_GRASP_AMD_HAND_SEARCH_H
 #define AGILE_GRASP_AMD_HAND_SEARCH_H

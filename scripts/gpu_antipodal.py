@@ -26,4 +26,4 @@ if bad.size:
     print("max abs diff", np.abs(nr - exp).max())
 if len(hyps) == len(ref["hyps"]):
     for f in hyps.dtype.names:
-        if f != "pad_" and not np.array_equal(hyps[f], ref["hyps"][f]): print("DIFF", f, np.nonzero(hyps[f] != ref["hyps"][f])[0][:10])
+        if f != "epoch" and not np.array_equal(hyps[f], ref["hyps"][f]): print("DIFF", f, np.nonzero(hyps[f] != ref["hyps"][f])[0][:10])

@@ -26,7 +26,7 @@ rh = ref["hyps"]
 print("hyp count", len(hyps), len(rh))
 if len(hyps) == len(rh):
     for f in hyps.dtype.names:
-        if f == "pad_": continue
+        if f == "epoch": continue
         eq = np.array_equal(hyps[f], rh[f])
         print(" ", f, "equal" if eq else ("DIFF max %.3e" % np.abs(hyps[f].astype(np.float64) - rh[f].astype(np.float64)).max()))
     im = ctx.images()
