@@ -30,13 +30,16 @@ namespace agh
 {
 
 constexpr int kSortBins = 256;  // distance buckets of the neighbour sort (= workgroup size)
-constexpr int kChunk = 56;      // neighbours per summation chunk (56 x 37 doubles fit the sort scratch of the 1536 class)
+constexpr int kChunk = 56;      // neighbours per summation chunk (56 x 37 doubles: the term tile shares the LDS of the dead sort scratch)
 
 // ---------------------------------------------------------------------------------------------------------------
 // K1a
 // ---------------------------------------------------------------------------------------------------------------
+// Capacity classes: 1152 neighbours is what a two-view cloud voxelised at the reference's 3 mm holds in a 3 cm ball at most
+// (C2 / C4 / C5: median 560, 99th percentile 980, maximum 1132), and it is the largest class whose 38.4 KB of LDS and 128
+// VGPRs leave room for FOUR work-groups per CU (the 1536 class it replaces ran three); denser clouds fall through to 4096.
 template <int CAP>
-__global__ __launch_bounds__(256) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
+__global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
   int n_points, double rpad_w, int* __restrict__ weight, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud)
@@ -1362,7 +1365,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
     zf = nullptr;
     first = false;
   }
-  hipLaunchKernelGGL(k_taubin_moments<1536>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+  hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
     r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
     zf, c->d_scloud);
   hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
