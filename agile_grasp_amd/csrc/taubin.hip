@@ -902,7 +902,7 @@ __device__ __forceinline__ double wave_max_f64_(double v)
 // THREADS = 256 (one work-group of four waves per sample) or 64 (one wave per sample: the class for at most 128 normals
 // of the r = 0.01 all-points pass).
 template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
+__global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
@@ -1405,10 +1405,10 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
   if (small_class)
-    AGH_LAUNCH_FRAME(1280, 256, 128);
+    AGH_LAUNCH_FRAME(1152, 256, 128);
   else
-    AGH_LAUNCH_FRAME(1280, 256, 0);
-  AGH_LAUNCH_FRAME(4096, 256, 1280);
+    AGH_LAUNCH_FRAME(1152, 256, 0);
+  AGH_LAUNCH_FRAME(4096, 256, 1152);
 #undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
