@@ -102,7 +102,7 @@ __device__ __forceinline__ unsigned lowmask(int n)
 // MODE: 0 = occupancy sweep only; 1 = with the antipodal counts (cloud normals); 2 = mode 1 plus one image per camera
 // for the training instances createInstance(h, cam_pos, cam = 0 / 1) (learning.cpp:389-397).
 template <int MODE, int PX, int PY>
-__global__ __launch_bounds__(256) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
+__global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
