@@ -12,6 +12,7 @@
 namespace agh
 {
 
+constexpr int kBboxBlocks = 128;   // work-groups of k_bbox per cloud (one slot of six extrema each)
 constexpr int kCellCap = 1 << 21;  // cells in the uniform grid table (8 MiB of int32)
 constexpr int kMaxRows = 128;      // (y,z) cell rows one ball query may touch
 constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (quadric.cpp:40-131)
@@ -28,8 +29,6 @@ struct GridDesc
   double inv_cell;
   int dim[3];
   int ncell;
-  unsigned bbox[6];  // order-preserving uint encoding of float min[3], max[3] (scratch for the reduction; the
-                     // work-group that consumes it resets it to {~0, ~0, ~0, 0, 0, 0} for the next build)
   unsigned done;     // work-groups of k_bbox that have contributed (reset by the last one)
   unsigned ticket;   // tile tickets of k_cell_scan (reset by the holder of the last one)
 };
@@ -169,6 +168,7 @@ struct Ctx
   int* d_cloud_off = nullptr;       // kMaxClouds + 1
   int32_t* d_scloud = nullptr;      // s_cap: cloud of every sample of the last call (written by k_taubin_moments)
   GridDesc* d_desc = nullptr;       // clouds_cap
+  float* d_bbox_part = nullptr;     // clouds_cap x kBboxBlocks x 6 partial extrema of k_bbox
   int* d_cell_start = nullptr;      // clouds_cap x (kCellCap + 1)
   int* d_cell_count = nullptr;      // clouds_cap x kCellCap
   int* d_block_sums = nullptr;
@@ -288,6 +288,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
 int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
+int ball_counts(Ctx* c, int64_t S, hipStream_t st);  // d_nh of the last call's samples (agh_get_neighbor_counts)
 int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
 int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st);
@@ -363,7 +364,16 @@ struct RowTable
 };
 
 // Fill rt for the ball (q, rpad).  Must be called by all threads of the block; ends with a barrier.
-__device__ __forceinline__ void build_rows(const GridView& gv, float qx, float qy, float qz, double rpad, RowTable& rt)
+// SLAB: the caller only wants the points p of the ball with |a . (p - q)| < hh (the hand sweep's crop along the hand axis,
+// rotating_hand.cpp:37-51, keeps a 2 hh thick slab of a 2 r ball: about a fifth of its points).  Every row is then clipped
+// to the part of its chord that can hold such a point -- by interval arithmetic over the row's (y, z) cell, widened by
+// kSlabMargin, which is orders of magnitude above the rounding of the caller's own test (the float32 subtraction it
+// starts from is off by < 1e-8 m) -- and rows the slab misses are dropped: half the candidates and half the row segments
+// of the plain ball at C2.  The caller's exact test still decides every point; this only prunes what it never accepts.
+constexpr double kSlabMargin = 1e-6;
+template <bool SLAB = false>
+__device__ __forceinline__ void build_rows(const GridView& gv, float qx, float qy, float qz, double rpad, RowTable& rt,
+  const double* slab_axis = nullptr, double slab_hh = 0.0)
 {
   const GridDesc& g = *gv.desc;
   const int tid = threadIdx.x;
@@ -394,10 +404,36 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
         // (dy, dz are the smallest possible offsets), so only the cells under the chord are candidates -- about a
         // third fewer than the bounding box's
         const double xr = sqrt(rem);
-        const int lxr = max(lx, cell_coord(g, (double) qx - xr, 0)), hxr = min(hx, cell_coord(g, (double) qx + xr, 0));
-        const int base = (cz * g.dim[1] + cy) * g.dim[0];
-        b = gv.cell_start[base + lxr];
-        len = gv.cell_start[base + hxr + 1] - b;
+        double xlo = (double) qx - xr, xhi = (double) qx + xr;
+        bool keep = true;
+        if (SLAB)
+        {
+          // a_y (y - qy) + a_z (z - qz) over the row's cell lies in [L, U]; a point passes only if a_x (x - qx) + that is
+          // inside (-hh, hh), i.e. a_x (x - qx) in (-hh - U, hh - L)
+          const double ya = (y0 - kSlabMargin) - (double) qy, yb = (y0 + g.cell + kSlabMargin) - (double) qy;
+          const double za = (z0 - kSlabMargin) - (double) qz, zb = (z0 + g.cell + kSlabMargin) - (double) qz;
+          const double ey0 = slab_axis[1] * ya, ey1 = slab_axis[1] * yb, ez0 = slab_axis[2] * za, ez1 = slab_axis[2] * zb;
+          const double L = fmin(ey0, ey1) + fmin(ez0, ez1), U = fmax(ey0, ey1) + fmax(ez0, ez1);
+          const double lo_n = (-1.0 * (slab_hh + kSlabMargin)) - U, hi_n = (slab_hh + kSlabMargin) - L;
+          const double ax = slab_axis[0];
+          if (fabs(ax) > 1e-9)
+          {
+            const double b1 = lo_n / ax, b2 = hi_n / ax;
+            xlo = fmax(xlo, ((double) qx + fmin(b1, b2)) - kSlabMargin);
+            xhi = fmin(xhi, ((double) qx + fmax(b1, b2)) + kSlabMargin);
+            keep = xlo <= xhi;
+          }
+          else  // the slab contains the x direction (|a_x (x - qx)| < 1e-9 * 2 r): the row is inside or outside as a whole
+            keep = (lo_n < 0.0) & (hi_n > 0.0);
+          keep = keep | !(L == L && U == U);  // a NaN axis prunes nothing
+        }
+        if (keep)
+        {
+          const int lxr = max(lx, cell_coord(g, xlo, 0)), hxr = min(hx, cell_coord(g, xhi, 0));
+          const int base = (cz * g.dim[1] + cy) * g.dim[0];
+          b = gv.cell_start[base + lxr];
+          len = hxr >= lxr ? gv.cell_start[base + hxr + 1] - b : 0;
+        }
       }
       rt.begin[t] = b;
       rt.prefix[t + 1] = len;

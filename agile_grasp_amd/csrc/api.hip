@@ -248,7 +248,7 @@ int ensure_clouds(Ctx* c, int C)
     return AGH_OK;
   int rc;
   if ((rc = dev_alloc(c, &c->d_desc, (size_t) C)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) C * ((size_t) kCellCap + 1))) ||
-      (rc = dev_alloc(c, &c->d_cell_count, (size_t) C * kCellCap)) ||
+      (rc = dev_alloc(c, &c->d_cell_count, (size_t) C * kCellCap)) || (rc = dev_alloc(c, &c->d_bbox_part, (size_t) C * kBboxBlocks * 6)) ||
       (rc = dev_alloc(c, &c->d_tile_state, (size_t) C * (kCellCap / 1024))))
     return rc;
   c->clouds_cap = C;
@@ -459,7 +459,7 @@ void agh_destroy(agh_ctx* ctx)
   if (c->stream)
     (void) hipStreamSynchronize(c->stream);
   comm_release(c);
-  void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
+  void* ptrs[] = { c->own_xyz, c->own_cam, c->d_desc, c->d_bbox_part, c->d_cell_start, c->d_cell_count, c->d_block_sums, c->d_cell_of,
     c->d_rank_of, c->d_sorted, c->d_samples, c->d_sums, c->d_nt, c->d_nh, c->d_status, c->d_nbr, c->d_eig, c->d_frames, c->d_slots,
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
@@ -1113,6 +1113,15 @@ int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, i
   HIPCHK(c, hipDeviceSynchronize());
   if (n > 0 && n_taubin)
     HIPCHK(c, hipMemcpy(n_taubin, c->d_nt, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (n > 0 && n_hands)  // counted on demand: the sweep only visits the part of the ball the hand can occupy
+  {
+    if (ball_counts(c, n, c->stream) != AGH_OK)
+    {
+      c->err = "k_ball_count launch failed";
+      return AGH_ERR_HIP;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (n > 0 && n_hands)
     HIPCHK(c, hipMemcpy(n_hands, c->d_nh, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   return (int) n;

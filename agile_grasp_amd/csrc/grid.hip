@@ -14,22 +14,17 @@ namespace agh
 __global__ void k_desc_reset(GridDesc* d)
 {
   d += blockIdx.x;
-  for (int a = 0; a < 3; a++)
-  {
-    d->bbox[a] = 0xffffffffu;  // min
-    d->bbox[3 + a] = 0u;       // max
-  }
   d->done = 0u;
   d->ticket = 0u;
 }
 
-__device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const unsigned bb[6])
+__device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const float lo[3], const float hi[3])
 {
   double mn[3], mx[3];
   for (int a = 0; a < 3; a++)
   {
-    mn[a] = n > 0 ? (double) dec_float(bb[a]) : 0.0;
-    mx[a] = n > 0 ? (double) dec_float(bb[3 + a]) : 0.0;
+    mn[a] = n > 0 ? (double) lo[a] : 0.0;
+    mx[a] = n > 0 ? (double) hi[a] : 0.0;
   }
   double cell = base_cell;
   int dim[3];
@@ -57,24 +52,34 @@ __device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const unsi
 
 // Bounding box of the cloud and, in the work-group that finishes last, the grid descriptor (one launch instead of
 // init + reduce + finish: a launch costs ~4.7 us of its own on this part, more than any of these does work).
-__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int64_t stride, const int* __restrict__ cloud_off,
-  GridDesc* d, double base_cell)
+// Every work-group leaves its six extrema in its own slot of `part` (plain stores) and counts itself in; the last one
+// reduces the slots.  (Six atomicMin/Max per work-group on one cache line cost 128 x 6 x ~12 ns = 9 us of serialised
+// same-line atomics: the kernel took 9.8 us; the arrival counter alone is a sixth of that.)
+constexpr int kBboxThreads = 1024;
+__global__ __launch_bounds__(kBboxThreads) void k_bbox(const float* __restrict__ xyz, int64_t stride, const int* __restrict__ cloud_off,
+  GridDesc* d, double base_cell, float* __restrict__ part)
 {
   // blockIdx.y = cloud of the batch
   const int64_t p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
   xyz += p0 * stride;
   d += blockIdx.y;
+  part += (int64_t) blockIdx.y * kBboxBlocks * 6;
   float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+  // (the loop is latency bound: 131072 threads, two points in flight per thread, so a 300k-point cloud takes two rounds)
+  const int64_t step = (int64_t) gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < n; i += 2 * step)
   {
     const float* p = xyz + i * stride;
+    const float* q = xyz + (i + step < n ? i + step : i) * stride;
+    const float pv[3] = { p[0], p[1], p[2] }, qv[3] = { q[0], q[1], q[2] };
     for (int a = 0; a < 3; a++)
     {
-      mn[a] = fminf(mn[a], p[a]);
-      mx[a] = fmaxf(mx[a], p[a]);
+      mn[a] = fminf(mn[a], fminf(pv[a], qv[a]));
+      mx[a] = fmaxf(mx[a], fmaxf(pv[a], qv[a]));
     }
   }
-  __shared__ float smn[4][3], smx[4][3];
+  constexpr int kW = kBboxThreads / 64;
+  __shared__ float smn[kW][3], smx[kW][3];
   __shared__ unsigned last;
   for (int a = 0; a < 3; a++)
     for (int o = 32; o > 0; o >>= 1)
@@ -89,29 +94,44 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ xyz, int
       smx[threadIdx.x >> 6][a] = mx[a];
     }
   __syncthreads();
-  if (threadIdx.x < 3 && n > 0)  // one atomic pair per block and axis: same-address atomics cost ~12 ns each
+  if (threadIdx.x < 3)
   {
     const int a = threadIdx.x;
-    const float lo = fminf(fminf(smn[0][a], smn[1][a]), fminf(smn[2][a], smn[3][a]));
-    const float hi = fmaxf(fmaxf(smx[0][a], smx[1][a]), fmaxf(smx[2][a], smx[3][a]));
-    atomicMin(&d->bbox[a], enc_float(lo));
-    atomicMax(&d->bbox[3 + a], enc_float(hi));
+    float lo = smn[0][a], hi = smx[0][a];
+    for (int w = 1; w < kW; w++)
+    {
+      lo = fminf(lo, smn[w][a]);
+      hi = fmaxf(hi, smx[w][a]);
+    }
+    __hip_atomic_store(&part[blockIdx.x * 6 + a], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[blockIdx.x * 6 + 3 + a], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();  // this group's slot is written before its arrival is counted
   }
   __syncthreads();
   if (threadIdx.x == 0)
-  {
-    __threadfence();  // this group's atomics are performed before its arrival is counted
     last = atomicAdd(&d->done, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
   __syncthreads();
-  if (last && threadIdx.x == 0)
+  if (last && threadIdx.x < 64)
   {
     __threadfence();
-    unsigned bb[6];
-    for (int a = 0; a < 6; a++)
-      bb[a] = atomicExch(&d->bbox[a], a < 3 ? 0xffffffffu : 0u);  // read the result and leave the reset state behind
-    d->done = 0u;
-    desc_finish(d, base_cell, n, bb);
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int b = threadIdx.x; b < (int) gridDim.x; b += 64)
+      for (int a = 0; a < 3; a++)
+      {
+        lo[a] = fminf(lo[a], __hip_atomic_load(&part[b * 6 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        hi[a] = fmaxf(hi[a], __hip_atomic_load(&part[b * 6 + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    for (int a = 0; a < 3; a++)
+      for (int o = 32; o > 0; o >>= 1)
+      {
+        lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+      }
+    if (threadIdx.x == 0)
+    {
+      d->done = 0u;  // the reset state for the next build
+      desc_finish(d, base_cell, n, lo, hi);
+    }
   }
 }
 
@@ -314,8 +334,8 @@ int grid_build(Ctx* c, hipStream_t st)
   }
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
-  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, 128)), C), dim3(256), 0, st, c->d_xyz, c->stride_floats,
-    (const int*) c->d_cloud_off, c->d_desc, base_cell);
+  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, kBboxBlocks)), C), dim3(kBboxThreads), 0, st, c->d_xyz, c->stride_floats,
+    (const int*) c->d_cloud_off, c->d_desc, base_cell, c->d_bbox_part);
   if (nmax > 0)
     hipLaunchKernelGGL(k_cell_count, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
       c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count);

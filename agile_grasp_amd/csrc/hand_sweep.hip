@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned lowmask(int n)
 template <int MODE, int PX, int PY>
 __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
-  int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell, int32_t* __restrict__ nh,
+  int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
   const int* __restrict__ order, uint8_t* __restrict__ vmask, double2* __restrict__ spill_all, int spill_cap,
   uint32_t* __restrict__ images_cam)
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
   __shared__ unsigned img[kImgPlanes][kImageWords + 2];
-  __shared__ int cnt_ball, cnt_crop, any_hand, pending, tile_end;
+  __shared__ int cnt_crop, any_hand, pending, tile_end;
 
   const int s = order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +142,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     }
     if (tid == 0)
     {
-      nh[s] = 0;
       status[s] = kStatusDegenerate;
       vmask[s] = 0;
     }
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     ((unsigned*) &G)[k] = ((const unsigned*) geom_p)[k];
   if (tid == 0)
   {
-    cnt_ball = 0;
     cnt_crop = 0;
     any_hand = 0;
     pending = 0;
@@ -165,7 +163,8 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     (&img[0][0])[k] = 0u;
   const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
   gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));  // the sample's cloud of the batch
-  build_rows(gv, sx, sy, sz, rpad, rt);  // ends with barriers: G and counters are visible afterwards
+  // only the rows (and the parts of rows) that can hold a point of the hand's slab |axis . (p - sample)| < hand_height
+  build_rows<true>(gv, sx, sy, sz, rpad, rt, F.axis, geom_p->hand_height);  // ends with barriers: G and counters are visible afterwards
   if (tid < 64)
     thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
   if (tid < 24)
@@ -175,7 +174,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     if (tid == 0)
     {
       status[s] = kStatusRows;
-      nh[s] = 0;
       vmask[s] = 0;
     }
     return;
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // and the survivors are appended to the LDS tile: one LDS atomic per wave-instruction reserves their slots; if the
   // reservation does not fit, the tile is closed and the wave pauses AT that instruction, so a neighbourhood that does
   // not fit one tile streams through it in several rounds.  The cursor (row, offset) says where to resume.
-  int cur_r = wave, cur_i = 0, nball = 0;
+  int cur_r = wave, cur_i = 0;
   const int nrows = rt.nrows;
   auto gather_reset = [&]() {
     cur_r = wave;
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
     ty = (fr[0][1] * cx + fr[1][1] * cy) + fr[2][1] * cz;
   };
-  auto consume2 = [&](const float4& p0, bool h0, const float4& p1, bool h1, bool count_ball) -> bool {
+  auto consume2 = [&](const float4& p0, bool h0, const float4& p1, bool h1) -> bool {
     bool in0, in1, k0, k1;
     double tx0, ty0, tx1, ty1;
     classify1(p0, h0, in0, k0, tx0, ty0);
@@ -294,7 +292,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
           pid[k] = __float_as_uint(p1.w);
       }
     }
-    nball += count_ball ? ((in0 ? 1 : 0) + (in1 ? 1 : 0)) : 0;
     return true;
   };
   // Fills the tile from the cursors on; returns the tile's point count and whether every wave reached the end.
@@ -326,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     p0 = gv.sorted[h0 ? rb + i + lane : 0];
     p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
   };
-  auto gather_tile = [&](bool count_ball, bool& all_done) -> int {
+  auto gather_tile = [&](bool& all_done) -> int {
     bool full = false;
     int rb = 0, len = 0;
     seg_normalize(cur_r, cur_i, rb, len);
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       float4 q0, q1;
       bool g0, g1;
       seg_load(nr, ni, nrb, nlen, q0, q1, g0, g1);  // in flight while the current segment is consumed
-      if (!consume2(p0, h0, p1, h1, count_ball))
+      if (!consume2(p0, h0, p1, h1))
         full = true;
       else
       {
@@ -457,12 +454,12 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // scratch (dead since K1c; 16 bytes per point, spill_cap points) while pass A streams through them, and pass B reads
   // them back with plain coalesced loads.  Only if they do not fit does pass B gather again.
   double2* spill = spill_all + (int64_t) s * spill_cap;
-  int ntiles = 0, nc = 0, nspill = 0;
+  int ntiles = 0, nc = 0, nspill = 0, ncrop_all = 0;
   bool spill_ok = !NORMALS;  // (the normals variant also needs the point ids: it keeps the second gather)
   for (;;)
   {
     bool all_done = false;
-    nc = gather_tile(true, all_done);
+    nc = gather_tile(all_done);
     if (ntiles == 0)
       AGH_STAMP(2);
     if (debug_stop == 2)
@@ -480,13 +477,11 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     }
     classify(nc);
     ntiles++;
+    ncrop_all += nc;
     if (all_done)
       break;
     next_tile();
   }
-  nball = wave_sum_i32(nball);
-  if (lane == 0 && nball)
-    atomicAdd(&cnt_ball, nball);
   __syncthreads();
   AGH_STAMP(3);
   if (debug_stop == 3)
@@ -617,7 +612,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
         __syncthreads();
       }
       else if (refill)
-        nc = gather_tile(false, all_done);
+        nc = gather_tile(all_done);
       for (int oo = 0; oo < 2; oo++)
       {
         const int o = wave + 4 * oo;
@@ -761,7 +756,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     return;
   if (tid == 0)
   {
-    nh[s] = cnt_ball;
     status[s] = kStatusOk;
     unsigned m = 0;  // orientations that produced a hypothesis: what the concatenation kernel scans
     for (int o = 0; o < 8; o++)
@@ -770,7 +764,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     if (dbg)
     {
       dbg[(int64_t) s * 8 + 6] = wall_clock64();
-      dbg[(int64_t) s * 8 + 7] = ((long long) cnt_ball << 32) | (unsigned) (ntiles << 24) | (unsigned) (total & 0xffffff);
+      dbg[(int64_t) s * 8 + 7] = ((long long) ncrop_all << 32) | (unsigned) (ntiles << 24) | (unsigned) (total & 0xffffff);
     }
   }
 #undef AGH_STAMP
@@ -936,6 +930,52 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
     slot_of_hyp[pos] = slot;
 }
 
+// The number of points radiusSearch(sample, nn_radius_hands) returns (hand_search.cpp:147), for agh_get_neighbor_counts: a
+// lazy getter.  The sweep itself only visits the slab of the ball the hand can occupy, so it never sees this number.
+__global__ __launch_bounds__(256) void k_ball_count(GridView gv, const agh_frame* __restrict__ frames,
+  const int32_t* __restrict__ scloud, int S, float r2f, double rpad, int32_t* __restrict__ nh)
+{
+  __shared__ RowTable rt;
+  __shared__ int cnt;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const agh_frame F = frames[s];
+  if (!F.valid)
+  {
+    if (tid == 0)
+      nh[s] = 0;
+    return;
+  }
+  if (tid == 0)
+    cnt = 0;
+  const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];
+  gv = grid_of_cloud(gv, scloud[s]);
+  build_rows(gv, sx, sy, sz, rpad, rt);
+  int n = 0;
+  if (!rt.bad)
+    for (int j = tid; j < rt.total; j += 256)
+    {
+      const float4 p = gv.sorted[row_lookup(rt, j)];
+      n += flann_d2(sx, sy, sz, p.x, p.y, p.z) < r2f ? 1 : 0;
+    }
+  n = wave_sum_i32(n);
+  if ((tid & 63) == 0 && n)
+    atomicAdd(&cnt, n);
+  __syncthreads();
+  if (tid == 0)
+    nh[s] = cnt;
+}
+
+int ball_counts(Ctx* c, int64_t S, hipStream_t st)
+{
+  if (S == 0)
+    return AGH_OK;
+  GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted, c->d_cloud_off, c->n_clouds };
+  const double radius = c->p.nn_radius_hands;
+  hipLaunchKernelGGL(k_ball_count, dim3((int) S), dim3(256), 0, st, gv, (const agh_frame*) c->d_frames,
+    (const int32_t*) c->d_scloud, (int) S, static_cast<float>(radius * radius), radius * 1.0001 + 1e-6, c->d_nh);
+  return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st)
 {
   if (S == 0)
@@ -952,7 +992,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const bool few = c->geom.x_probes <= 2 && c->geom.y_probes <= 1;
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
   hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
-    r2f, rpad, nrm, img_cell, c->d_nh, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
+    r2f, rpad, nrm, img_cell, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
     (const int*) c->d_order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
   const bool train = nrm && c->training_images && c->d_images_cam;
   if (train)

@@ -899,111 +899,6 @@ __device__ __forceinline__ double wave_max_f64_(double v)
   return v;
 }
 
-// jacobi3_serial (agh_internal.h; oracle jacobi_sym<3>) as a resumable computation: the same operations in the same order,
-// `budget` pair visits per call, state in LDS between calls.  k_taubin_frame's wave 0 runs it in slices BETWEEN the barriers
-// of the estimate phase that the other three waves execute, so the 3x3 eigen solve -- a chain of dependent divisions and
-// square roots on a single lane, ~7 us -- no longer sits on the work-group's critical path behind that phase.
-struct J3State
-{
-  double A[9], V[9];
-  int sweep, k;  // next pair to visit: k = 0: (0,1), 1: (0,2), 2: (1,2); sweep >= 30: finished
-};
-template <int P, int Q>
-__device__ __forceinline__ void j3_pair(double (&A)[3][3], double (&V)[3][3], int sweep)
-{
-  constexpr int R = 3 - P - Q;
-  const double apq = A[P][Q];
-  if (apq == 0.0)
-    return;
-  const double app = A[P][P], aqq = A[Q][Q];
-  const double aabs = fabs(apq);
-  if (sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq)))
-  {
-    A[P][Q] = 0.0;
-    A[Q][P] = 0.0;
-    return;
-  }
-  const double theta = (aqq - app) / (2.0 * apq);
-  double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-  if (theta < 0.0)
-    t = -t;
-  const double c = 1.0 / sqrt(t * t + 1.0);
-  const double sn = t * c;
-  A[P][P] = app - t * apq;
-  A[Q][Q] = aqq + t * apq;
-  A[P][Q] = 0.0;
-  A[Q][P] = 0.0;
-  {
-    const double akp = A[R][P], akq = A[R][Q];
-    const double np_ = c * akp - sn * akq;
-    const double nq_ = sn * akp + c * akq;
-    A[R][P] = np_;
-    A[P][R] = np_;
-    A[R][Q] = nq_;
-    A[Q][R] = nq_;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++)
-  {
-    const double vkp = V[k][P], vkq = V[k][Q];
-    V[k][P] = c * vkp - sn * vkq;
-    V[k][Q] = sn * vkp + c * vkq;
-  }
-}
-// one lane; returns with st->sweep >= 30 once the iteration has ended (off == 0 or 30 sweeps)
-__device__ inline void j3_run(J3State* st, int budget)
-{
-  int sweep = st->sweep, k = st->k;
-  if (sweep >= 30)
-    return;
-  double A[3][3], V[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-    {
-      A[i][j] = st->A[3 * i + j];
-      V[i][j] = st->V[3 * i + j];
-    }
-  while (budget > 0 && sweep < 30)
-  {
-    if (k == 0)
-    {
-      double off = 0.0;
-      off += A[0][1] * A[0][1];
-      off += A[0][2] * A[0][2];
-      off += A[1][2] * A[1][2];
-      if (off == 0.0)
-      {
-        sweep = 30;
-        break;
-      }
-    }
-    if (k == 0)
-      j3_pair<0, 1>(A, V, sweep);
-    else if (k == 1)
-      j3_pair<0, 2>(A, V, sweep);
-    else
-      j3_pair<1, 2>(A, V, sweep);
-    budget--;
-    if (++k == 3)
-    {
-      k = 0;
-      sweep++;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-    {
-      st->A[3 * i + j] = A[i][j];
-      st->V[3 * i + j] = V[i][j];
-    }
-  st->sweep = sweep;
-  st->k = k;
-}
-
 // THREADS = 256 (one work-group of four waves per sample) or 64 (one wave per sample: the class for at most 128 normals
 // of the r = 0.01 all-points pass).
 template <int CAP, int THREADS>
@@ -1017,7 +912,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   __shared__ double nx[CAP], ny[CAP], nz[CAP];
   __shared__ int camcnt[2];
   __shared__ int next_col;
-  __shared__ J3State sJ;
+  __shared__ double sM3[6];
   __shared__ double sAxis[3];
   constexpr int NW = THREADS / 64;
   __shared__ double wbest[NW];
@@ -1105,47 +1000,6 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   // With at most 64 normals (always in the reference's production mode, which subsamples 50) a column's exact sum is
   // one term per lane plus the butterfly: evaluating all columns exactly is cheaper than estimating them first
   // (measured; with up to 128 it is not).
-  // Division of labour in the four-wave variant: the estimate phase below is run by waves 1..3 (192 threads) while wave 0
-  // accumulates M3 = normals * normals^T (quadric.cpp:266) and runs its 3 x 3 eigen solve in slices between that phase's
-  // four barriers (j3_run) -- every wave executes the same barriers, the slices are sized to the windows between them.
-  constexpr bool kSplit = NW == 4;
-  constexpr int ET = kSplit ? THREADS - 64 : THREADS;  // threads of the estimate phase
-  constexpr int ENW = kSplit ? NW - 1 : NW;
-  const int et = kSplit ? tid - 64 : tid, ew = kSplit ? wave - 1 : wave;
-  const bool jwave = kSplit && wave == 0;
-  auto m3_init = [&]() {  // one wave: M3 in the oracle's LaneSum64 order (lane l owns the terms l, l + 64, ...; butterfly tree)
-    double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-    if (!(debug_stop == 5 || debug_stop == 7))
-      for (int t = lane; t < ks; t += 64)
-      {
-        const double x = nx[t], y = ny[t], z = nz[t];
-        m[0] += x * x;
-        m[1] += x * y;
-        m[2] += x * z;
-        m[3] += y * y;
-        m[4] += y * z;
-        m[5] += z * z;
-      }
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-      for (int o = 32; o > 0; o >>= 1)
-        m[k] = m[k] + __shfl_xor(m[k], o);
-    if (lane == 0)
-    {
-      const double A[9] = { m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5] };
-      for (int k = 0; k < 9; k++)
-      {
-        sJ.A[k] = A[k];
-        sJ.V[k] = (k % 4 == 0) ? 1.0 : 0.0;
-      }
-      sJ.sweep = (debug_stop == 6 || debug_stop == 7) ? 30 : 0;
-      sJ.k = 0;
-    }
-  };
-  auto j3_slice = [&](int budget) {
-    if (lane == 0)
-      j3_run(&sJ, budget);
-  };
   if (ks <= 64)
   {
     for (int j = tid; j < ks; j += THREADS)
@@ -1155,18 +1009,12 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   }
   else
   {
-    if (jwave)
-    {
-      m3_init();
-      j3_slice(4);
-    }
-    else
     {
       double T[28];
   #pragma unroll
       for (int k = 0; k < 28; k++)
         T[k] = 0.0;
-      for (int t = et; t < ks; t += ET)
+      for (int t = tid; t < ks; t += THREADS)
       {
         const double x = nx[t], y = ny[t], z = nz[t];
         double px[7], py[7], pz[7];
@@ -1206,46 +1054,40 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
       }
       R[0] = R[0] + __shfl_xor(R[0], 1);
       if ((lane & 1) == 0 && (lane >> 1) < 28)
-        sT[ew][lane >> 1] = R[0];
+        sT[wave][lane >> 1] = R[0];
     }
     __syncthreads();
-    if (jwave)
-      j3_slice(1);
-    else if (et < 28)  // multinomial-weighted moments, once per block
+    if (tid < 28)  // multinomial-weighted moments, once per block
     {
       const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
       int k = 0, ea = 0, eb = 0;
       for (int a = 6; a >= 0; a--)
         for (int b = 6 - a; b >= 0; b--)
         {
-          if (k == et)
+          if (k == tid)
           {
             ea = a;
             eb = b;
           }
           k++;
         }
-      double tsum = sT[0][et];
-      for (int w = 1; w < ENW; w++)
-        tsum = tsum + sT[w][et];
-      sW[et] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
+      double tsum = sT[0][tid];
+      for (int w = 1; w < NW; w++)
+        tsum = tsum + sT[w][tid];
+      sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
     }
     __syncthreads();
-    constexpr int EST = (CAP + ET - 1) / ET;
-    double est[EST];
+    double est[(CAP + THREADS - 1) / THREADS];
     double est_max = -1.0;
-    if (jwave)
-      j3_slice(8);
-    else
     {
       double W[28];
   #pragma unroll
       for (int k = 0; k < 28; k++)
         W[k] = sW[k];
   #pragma unroll
-      for (int m = 0; m < EST; m++)
+      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
       {
-        const int j = et + ET * m;
+        const int j = tid + THREADS * m;
         double e_ = -2.0;
         if (j < ks)
         {
@@ -1269,23 +1111,20 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
         est[m] = e_;
         est_max = fmax(est_max, e_);
       }
-      est_max = wave_max_f64_(est_max);
-      if (lane == 0)
-        wmax_s[ew] = est_max;
     }
+    est_max = wave_max_f64_(est_max);
+    if (lane == 0)
+      wmax_s[wave] = est_max;
     __syncthreads();
-    if (jwave)
-      j3_slice(1);
-    else
+    est_max = wmax_s[0];
+    for (int w = 1; w < NW; w++)
+      est_max = fmax(est_max, wmax_s[w]);
     {
-      est_max = wmax_s[0];
-      for (int w = 1; w < ENW; w++)
-        est_max = fmax(est_max, wmax_s[w]);
       const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
   #pragma unroll
-      for (int m = 0; m < EST; m++)
+      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
       {
-        const int j = et + ET * m;
+        const int j = tid + THREADS * m;
         const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
         const unsigned long long mk = __ballot(is_c);
         int base = 0;
@@ -1301,47 +1140,52 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   const int ncnd = ncand;
   if (debug_stop == 2)
     return;
-  // ---- wave 0 finishes the eigen solve (the other waves go straight to the exact column sums below) ----
+  // ---- wave 0 (the other waves go straight to the exact column sums below): M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
   if (wave == 0)
   {
-    if (!(kSplit && ks > 64))
-      m3_init();
+    // M3 in the oracle's LaneSum64 order: lane l owns partial l (terms l, l + 64, ...), butterfly tree at the end
+    double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    if (!(debug_stop == 5 || debug_stop == 7))
+      for (int t = lane; t < ks; t += 64)
+      {
+        const double x = nx[t], y = ny[t], z = nz[t];
+        m[0] += x * x;
+        m[1] += x * y;
+        m[2] += x * z;
+        m[3] += y * y;
+        m[4] += y * z;
+        m[5] += z * z;
+      }
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+    {
+      for (int o = 32; o > 0; o >>= 1)
+        m[k] = m[k] + __shfl_xor(m[k], o);
+      if (lane == 0)
+        sM3[k] = m[k];
+    }
     __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     if (lane == 0)
     {
-      double dd[3], Vm[3][3];
-      if (kSplit)
+      double A[3][3] = { { sM3[0], sM3[1], sM3[2] }, { sM3[1], sM3[3], sM3[4] }, { sM3[2], sM3[4], sM3[5] } };
+      double V[3][3], dd[3];
+      if (debug_stop == 6 || debug_stop == 7)
       {
-        j3_run(&sJ, 1 << 20);
         for (int r = 0; r < 3; r++)
-        {
-          dd[r] = sJ.A[4 * r];
           for (int q = 0; q < 3; q++)
-            Vm[r][q] = sJ.V[3 * r + q];
-        }
+            V[r][q] = (r == q) ? 1.0 : 0.0;
+        dd[0] = dd[1] = dd[2] = 0.0;
       }
-      else  // one wave does everything in turn: the solve runs in registers (jacobi3_serial), nothing to overlap it with
-      {
-        double A[3][3] = { { sJ.A[0], sJ.A[1], sJ.A[2] }, { sJ.A[3], sJ.A[4], sJ.A[5] }, { sJ.A[6], sJ.A[7], sJ.A[8] } };
-        if (sJ.sweep >= 30)
-        {
-          for (int r = 0; r < 3; r++)
-          {
-            dd[r] = A[r][r];
-            for (int q = 0; q < 3; q++)
-              Vm[r][q] = (r == q) ? 1.0 : 0.0;
-          }
-        }
-        else
-          jacobi3_serial(A, Vm, dd);
-      }
+      else
+        jacobi3_serial(A, V, dd);
       int mi = 0;
       for (int r = 1; r < 3; r++)
         if (dd[r] < dd[mi])
           mi = r;
-      sAxis[0] = Vm[0][mi];
-      sAxis[1] = Vm[1][mi];
-      sAxis[2] = Vm[2][mi];
+      sAxis[0] = V[0][mi];
+      sAxis[1] = V[1][mi];
+      sAxis[2] = V[2][mi];
     }
   }
   if (debug_stop == 3)
