@@ -142,6 +142,9 @@ def save_svm_file(path: str, w: np.ndarray, rho: float, kernel: int = SVM_LINEAR
         raise AghError(rc, f"cannot write {path}")
 
 
+AGH_ERR_RETRY = -9  # the context adapted its configuration to the input (include/agh.h): repeat the call
+
+
 class AghError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"agh error {code}: {msg}")

@@ -216,6 +216,8 @@ struct Ctx
   agh_hypothesis* d_out_last = nullptr;  // where the last call's compacted records live
   int64_t* d_nout_last = nullptr;
   int32_t* d_flags = nullptr;  // [0] any overflow, [1] ...
+  bool big_classes = false;  // launch the larger capacity classes of K1a / K1c too (sticky; set by the first call that
+                             // met a neighbourhood beyond the first class, see AGH_ERR_RETRY)
   bool zero_flags_pending = false;  // the next k_taubin_moments launch clears d_flags first
 
   // normals for the antipodal test (cloud_normals_, hand_search.cpp:13-14)

@@ -958,6 +958,16 @@ static int check_flags(Ctx* c, hipStream_t st)
 
 static int flags_to_status(Ctx* c, const int32_t* flags)
 {
+  if ((flags[0] & 1) && !c->big_classes)
+  {
+    // the launches of the larger capacity classes are skipped until a cloud needs them (~5 us each, and class membership
+    // is only known on the device): this call met such a neighbourhood, so its samples beyond the first class have no
+    // frame yet.  From now on the context launches every class.
+    c->big_classes = true;
+    c->err = "a Taubin neighbourhood exceeds the first capacity class; the context now launches the larger classes as "
+             "well: repeat the call";
+    return AGH_ERR_RETRY;
+  }
   if (flags[0] & 1)
   {
     c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
@@ -980,7 +990,7 @@ static int flags_to_status(Ctx* c, const int32_t* flags)
     c->shard_full_exchange = true;
     c->err = "a rank found more hypotheses than its exchange segment holds; the context now exchanges full-size segments: "
              "repeat the call";
-    return AGH_ERR_CAPACITY;
+    return AGH_ERR_RETRY;
   }
   return AGH_OK;
 }
@@ -1023,19 +1033,24 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
   int32_t* d_idx = c->d_idx_own;
   if (n_samples > 0)
     HIPCHK(c, hipMemcpyAsync(d_idx, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
-  rc = agh_find_hands_device(ctx, d_idx, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
-    c->stream);
   int64_t n = 0;
-  if (rc == AGH_OK)
+  for (int attempt = 0; attempt < 2; attempt++)  // (AGH_ERR_RETRY: the context has enabled the larger classes)
   {
-    int32_t flags[8];  // error flags and the count come back with one synchronisation
-    HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    rc = flags_to_status(c, flags);
+    rc = agh_find_hands_device(ctx, d_idx, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
+      c->stream);
+    if (rc == AGH_OK)
+    {
+      int32_t flags[8];  // error flags and the count come back with one synchronisation
+      HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      rc = flags_to_status(c, flags);
+    }
+    else
+      (void) hipStreamSynchronize(c->stream);
+    if (rc != AGH_ERR_RETRY)
+      break;
   }
-  else
-    (void) hipStreamSynchronize(c->stream);
   if (rc != AGH_OK)
     return rc;
   c->last_nout = n;

@@ -371,6 +371,7 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
     c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
     return AGH_ERR_HIP;
   }
+  c->big_classes = true;  // (no per-rank speculation about capacity classes: the ranks must run the same schedule)
   c->comm = new Comm();
   c->comm->rank = rank;
   c->comm->n_ranks = n_ranks;
@@ -395,6 +396,7 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
     cm->n_ranks = n_ranks;
     cm->local = g;
     ctxs[q]->c.comm = cm;
+    ctxs[q]->c.big_classes = true;
   }
   return AGH_OK;
 }
@@ -711,7 +713,7 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
       break;
     // a rank found more than its segment holds: every rank sees the same headers, so every rank repeats with 8 per sample
     c->shard_full_exchange = true;
-    rc = AGH_ERR_CAPACITY;
+    rc = AGH_ERR_RETRY;
     c->err = "a rank found more hypotheses than its exchange segment holds";
   }
   if (rc != AGH_OK)

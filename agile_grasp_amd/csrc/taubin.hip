@@ -1365,12 +1365,17 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
     zf = nullptr;
     first = false;
   }
-  hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
-    zf, c->d_scloud);
-  hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-    r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
-    (int32_t*) nullptr, c->d_scloud);
+  // The classes after the first only do work for samples the first one flagged, which the host cannot know: their
+  // launches (~5 us each, empty for voxelised clouds) are skipped until a call reports such a sample (AGH_ERR_RETRY, then
+  // c->big_classes stays set).  Skipped classes leave kStatusOverflow behind, which k_taubin_eigen turns into the flag.
+  if (first || c->big_classes)
+    hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+      r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      zf, c->d_scloud);
+  if (c->big_classes)
+    hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+      r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      (int32_t*) nullptr, c->d_scloud);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
@@ -1408,7 +1413,8 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
     AGH_LAUNCH_FRAME(1152, 256, 128);
   else
     AGH_LAUNCH_FRAME(1152, 256, 0);
-  AGH_LAUNCH_FRAME(4096, 256, 1152);
+  if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
+    AGH_LAUNCH_FRAME(4096, 256, 1152);
 #undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;

@@ -105,6 +105,7 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
         if classify:
             ctx.classify_torch(keep_t, stream=stream)
 
+    settle(ctx, step, torch.cuda.synchronize)
     for _ in range(max(args.warmup, 3)):
         step()
     torch.cuda.synchronize()
@@ -132,6 +133,23 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sweep_bytes / sweep_s / 1e9 / HBM_PEAK_GBS) if sweep_s > 0 else 0.0,
                          "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
                          "note": "HIP events of an untimed pass of the same steps"}}
+
+
+def settle(ctx, step, fence):
+    """Two untimed steps on every rank before anything is measured.  A context starts with the launches of the larger
+    capacity classes switched off (they are empty for voxelised clouds); the first step of a cloud that needs them reports
+    AGH_ERR_RETRY and switches them on for good, so the steps that follow -- warm-up and timed -- run the context's final
+    configuration.  (Always two steps, so that every rank executes the same collectives.)"""
+    from agile_grasp_amd import binding
+
+    for _ in range(2):
+        step()
+        fence()
+        try:
+            ctx.synchronize()
+        except binding.AghError as e:
+            if e.code != binding.AGH_ERR_RETRY:
+                raise
 
 
 def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
@@ -179,7 +197,7 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
             ctx.synchronize()
             break
         except binding.AghError as e:  # a segment overflowed: the context now exchanges full segments, measure again
-            if e.code != -4 or attempt == 1:
+            if e.code != binding.AGH_ERR_RETRY or attempt == 1:
                 raise
     tv = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tv, op=dist.ReduceOp.MAX)
@@ -325,6 +343,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle(ctx, step, fence)
     # Clocks: a cold GPU runs the first milliseconds below its sustained clock and these kernels are issue bound, so the
     # same step runs untimed for a moment first (the W warm-up steps and the K timed steps follow unchanged).
     t_spin = time.perf_counter()
@@ -350,7 +369,7 @@ def main():
                 ctx.synchronize()  # raises AGH_ERR_CAPACITY if a rank overflowed its segment; the context then uses full ones
                 break
             except binding.AghError as e:
-                if e.code != -4:
+                if e.code != binding.AGH_ERR_RETRY:
                     raise
                 continue
         nb = sharding.segment_bytes(seg[0])

@@ -40,7 +40,13 @@ typedef enum agh_status
   AGH_ERR_NO_CLOUD = -5,
   AGH_ERR_NO_SVM = -6,
   AGH_ERR_IO = -7,
-  AGH_ERR_STATE = -8
+  AGH_ERR_STATE = -8,
+  AGH_ERR_RETRY = -9            /* the call's result is incomplete because the context ran in a cheaper configuration than
+                                 * this input needs; it has switched itself (for good): repeat the call.  Two cases: a Taubin
+                                 * neighbourhood beyond the first capacity class of the kernels (the launches of the larger
+                                 * classes are skipped until a cloud needs them), and a rank that overflowed its exchange
+                                 * segment in a sharded search.  Host-buffer entry points repeat by themselves; the
+                                 * asynchronous device variants report it at the next agh_synchronize. */
 } agh_status;
 
 #define AGH_NORMALS_DETERMINISTIC 0 /* Quadric(is_deterministic = true): all neighbours (quadric.cpp:194-212) */
@@ -177,7 +183,8 @@ int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
 int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* out, int64_t cap, int64_t* n_out);
 /* Same, everything device-resident and asynchronous on hip_stream (NULL = the context's stream):
- * d_out has room for cap records, *d_n_out (device int64) receives the count. */
+ * d_out has room for cap records, *d_n_out (device int64) receives the count.  Device-side errors (capacity, a sample
+ * index outside the cloud, AGH_ERR_RETRY) are reported by the next agh_synchronize. */
 int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
 
@@ -276,8 +283,8 @@ void agh_shard_slice(int64_t n, int32_t rank, int32_t n_ranks, int64_t* lo, int6
  * agh_find_hands_device; on return (asynchronously on hip_stream) every rank's d_out holds the complete list and
  * *d_n_out its length.  Each rank contributes a segment of max(2 ceil(S/G), 1024) records (never more than 8 ceil(S/G)): scenes
  * yield well under one hypothesis per sample, and xGMI all-gathers of this size are latency bound.  If a rank found more,
- * the call reports AGH_ERR_CAPACITY at the next agh_synchronize / in the host variant and switches the context to
- * full-size segments (8 per sample) for the following calls; the host variant retries by itself. */
+ * the call reports AGH_ERR_RETRY at the next agh_synchronize and switches the context to full-size segments (8 per
+ * sample) for the following calls; the host variant retries by itself. */
 int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
 int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
