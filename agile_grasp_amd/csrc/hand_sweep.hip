@@ -123,6 +123,14 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   __shared__ unsigned regmask[8][44];
   __shared__ unsigned pre_s[4][88], suf_s[4][88];
   __shared__ unsigned img[kImgPlanes][kImageWords + 2];
+  // Pass A sets its (region, depth) bits in kRmCopies copies of the table, one per lane & 3, and the finger phase ORs them
+  // together: neighbouring lanes hold neighbouring points, which mostly fall into the same table word, and an LDS atomic
+  // serialises the lanes of a wave that hit one word (or one bank) -- with a single table the atomic was 45 % of pass A.
+  // The copies live in the image planes, which nothing touches before pass B (the finger phase leaves them zeroed again);
+  // copy c starts 8 banks after copy c - 1.
+  constexpr int kRmCopies = 4, kRmOriStride = 48, kRmCopyStride = 8 * kRmOriStride + 8;
+  static_assert(kRmCopies * kRmCopyStride <= kImgPlanes * (kImageWords + 2), "the table copies must fit the image planes");
+  unsigned* const rmc = &img[0][0];
   __shared__ int cnt_crop, any_hand, pending, tile_end;
 
   const int s = order[blockIdx.x];
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
           }
           const int key = 2 * c + e;
           if (act[u] & (yk < K) AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
-            atomicOr(&regmask[o][key >> 1], 1u << ((key & 1) * 16 + yk));
+            atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + yk));
         }
       }
       ymin_w[oo] = ymin;
@@ -497,6 +505,18 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       continue;
     const double ymin = wave_min_f64(ymin_w[oo]);
     const double ymax = wave_max_f64(ymax_w[oo]);
+    if (lane < 44)  // this orientation's table: the OR of its copies (only this wave wrote them), which are zeroed again
+    {
+      unsigned m = 0;
+      for (int c = 0; c < kRmCopies; c++)
+      {
+        m |= rmc[c * kRmCopyStride + o * kRmOriStride + lane];
+        rmc[c * kRmCopyStride + o * kRmOriStride + lane] = 0u;
+      }
+      regmask[o][lane] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     auto half = [&](int key) -> unsigned { return (regmask[o][key >> 1] >> ((key & 1) * 16)) & 0xffffu; };
     const unsigned v0 = lane < R ? half(lane) : 0u;
     const unsigned v1 = (64 + lane) < R ? half(64 + lane) : 0u;

@@ -14,6 +14,11 @@ for _ in range(3):
     h = ctx.find_hands(sc.samples)
 ctx.synchronize()
 d = np.fromfile("/tmp/agh_clocks.bin", np.int64).reshape(-1, 8)
+fr = ctx.frames()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "sweep_clocks.npz"), clocks=d, axis=fr["axis"], normal=fr["normal"],
+                    sample=fr["sample"], valid=fr["valid"], hyp_sample=h["sample"], hyp_orientation=h["orientation"],
+                    cam_origins=sc.cam_origins)
 t = d[:, :7].astype(np.float64)
 ph = np.diff(t, axis=1)  # wall_clock64 ticks: 100 MHz on MI300-class
 names = ["setup", "gather", "passA", "finger", "passB", "write"]
@@ -24,7 +29,7 @@ tot = t[:, 6] - t[:, 0]
 print("total per WG median", np.median(tot), "p90", np.percentile(tot, 90), "max", tot.max())
 print("kernel span", t[:, 6].max() - t[:, 0].min(), "first start spread", np.percentile(t[:, 0] - t[:, 0].min(), [50, 90, 100]))
 print('guard trips', (d[:, 7] < 0).sum(), d[d[:, 7] < 0][:5])
-cand = (d[:, 7] & 0xffffffff); ball = d[:, 7] >> 32
+cand = (d[:, 7] & 0xffffff); ball = d[:, 7] >> 32  # (since the slab clip: "ball" = cropped points, cand = slab candidates)
 print("candidates mean", cand.mean(), "ball mean", ball.mean())
 pa = ph[:, 2]
 order = np.argsort(ball)
@@ -35,7 +40,8 @@ big = ball > 7000
 print("ball>7000:", big.sum(), "passA mean", pa[big].mean() if big.any() else 0, "; ball<5000 passA mean", pa[ball < 5000].mean())
 print("corr(ball, passA)", np.corrcoef(ball, pa)[0, 1])
 slow = pa > 5000
-print("slow passA count", slow.sum(), "their ball mean", ball[slow].mean(), "min", ball[slow].min())
+if slow.any():
+    print("slow passA count", slow.sum(), "their ball mean", ball[slow].mean(), "min", ball[slow].min())
 # schedule view: when do work-groups start and end relative to the kernel (ticks of 10 ns)
 t0 = t[:, 0].min()
 start, end = t[:, 0] - t0, t[:, 6] - t0

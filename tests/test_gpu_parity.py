@@ -473,7 +473,7 @@ def test_points_for_learning_on_demand(tiny_scene):
         assert np.array_equal(R.convert_to_image(pts, hyps["binormal"][k], s2c).reshape(-1), images[k])
 
 
-@pytest.mark.parametrize("name,expect_retry", [("small", True), ("C1", False)])
+@pytest.mark.parametrize("name,expect_retry", [("small", True), ("C2", False)])
 def test_larger_capacity_classes_are_switched_on_by_the_first_cloud_that_needs_them(name, expect_retry):
     """The launches of the capacity classes beyond the first are skipped until a cloud needs them (they are empty for
     voxelised clouds, ~5 us each).  Asynchronous calls report the switch once as AGH_ERR_RETRY at agh_synchronize; the repeated
