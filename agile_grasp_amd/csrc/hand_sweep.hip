@@ -82,6 +82,15 @@ __device__ __forceinline__ unsigned wave_prefix_or(unsigned v)
   v |= (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);
   return v;
 }
+// (int) v for any v: truncation, saturation at the int range, NaN -> 0 -- what the instruction does, where the C++ cast of
+// an out-of-range value is undefined
+__device__ __forceinline__ int cvt_i32_f64_sat(double v)
+{
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
   for (int o = 32; o > 0; o >>= 1)
@@ -407,19 +416,22 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
           yr[u] = sn * p.x + cs * p.y;
         }
+        // (a lane past the end of the tile holds point 0 once more: min, max and the table bits are idempotent, so nothing
+        // below needs to know -- no selects, no predicate besides the depth test)
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
-          ymin = min_f64_raw(ymin, act[u] ? yr[u] : INFINITY);
-          ymax = max_f64_raw(ymax, act[u] ? yr[u] : -INFINITY);
+          ymin = min_f64_raw(ymin, yr[u]);
+          ymax = max_f64_raw(ymax, yr[u]);
         }
         // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
         int ly[4], lx[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
-          const int cy = (int) fmin(fmax((yr[u] - ylo) * ysc, 0.0), 63.0);
-          const int cx = (int) fmin(fmax((xr[u] - xlo) * xsc, 0.0), 1023.0);
+          // v_cvt_i32_f64 truncates and saturates (NaN -> 0), so the clamp can follow the conversion as one integer med3
+          const int cy = min(max(cvt_i32_f64_sat((yr[u] - ylo) * ysc), 0), 63);
+          const int cx = min(max(cvt_i32_f64_sat((xr[u] - xlo) * xsc), 0), 1023);
           ly[u] = G.ylut[cy];
           lx[u] = G.xlut[cx];
         }
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
             e |= (tv[u][j] == xr[u]) ? 1 : 0;
           }
           const int key = 2 * c + e;
-          if (act[u] & (yk < K) AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
+          if ((yk < K) AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
             atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + yk));
         }
       }
