@@ -14,6 +14,7 @@ namespace agh
 
 constexpr int kBboxBlocks = 128;   // work-groups of k_bbox per cloud (one slot of six extrema each)
 constexpr int kCellCap = 1 << 21;  // cells in the uniform grid table (8 MiB of int32)
+constexpr int kCellStride = kCellCap + 4;  // entries of one cloud's cell table (kCellCap + 1 used; 16-byte aligned tables)
 constexpr int kMaxRows = 128;      // (y,z) cell rows one ball query may touch
 constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (quadric.cpp:40-131)
 constexpr int kSumStride = 40;     // doubles per sample in the sums buffer
@@ -36,13 +37,13 @@ struct GridDesc
 // Everything a search kernel needs to walk the grid.
 // A context holds a BATCH of n_clouds >= 1 clouds laid end to end in one point array (cloud k = points [cloud_off[k],
 // cloud_off[k + 1])); point and sample indices are positions in that array.  Every cloud has its own grid descriptor and
-// its own cell table (kCellCap + 1 entries each, holding positions in the common cell-sorted array), so a ball query only
+// its own cell table (kCellStride entries each, holding positions in the common cell-sorted array), so a ball query only
 // sees its own cloud.  n_clouds == 1 is the plain HandSearch::findHands case.
 constexpr int kMaxClouds = 64;
 struct GridView
 {
   const GridDesc* desc;    // n_clouds descriptors (or, after grid_of_*, the one of the query's cloud)
-  const int* cell_start;   // n_clouds x (kCellCap + 1)
+  const int* cell_start;   // n_clouds x kCellStride
   const float4* sorted;    // x, y, z, bits((idx << 1) | cam), cloud-major, then cell-major
   const int* cloud_off;    // n_clouds + 1
   int n_clouds;
@@ -169,7 +170,7 @@ struct Ctx
   int32_t* d_scloud = nullptr;      // s_cap: cloud of every sample of the last call (written by k_taubin_moments)
   GridDesc* d_desc = nullptr;       // clouds_cap
   float* d_bbox_part = nullptr;     // clouds_cap x kBboxBlocks x 6 partial extrema of k_bbox
-  int* d_cell_start = nullptr;      // clouds_cap x (kCellCap + 1)
+  int* d_cell_start = nullptr;      // clouds_cap x kCellStride
   int* d_cell_count = nullptr;      // clouds_cap x kCellCap
   int* d_block_sums = nullptr;
   unsigned long long* d_tile_state = nullptr;  // clouds_cap x kCellCap / 1024 look-back descriptors of k_cell_scan, tagged with the build number
@@ -334,7 +335,7 @@ __device__ __forceinline__ int cell_coord(const GridDesc& g, double v, int a)
 __device__ __forceinline__ GridView grid_of_cloud(GridView gv, int k)
 {
   gv.desc += k;
-  gv.cell_start += (int64_t) k * (kCellCap + 1);
+  gv.cell_start += (int64_t) k * kCellStride;
   return gv;
 }
 __device__ __forceinline__ int cloud_of_point(const GridView& gv, int p)

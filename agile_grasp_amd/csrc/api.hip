@@ -247,7 +247,7 @@ int ensure_clouds(Ctx* c, int C)
   if (C <= c->clouds_cap)
     return AGH_OK;
   int rc;
-  if ((rc = dev_alloc(c, &c->d_desc, (size_t) C)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) C * ((size_t) kCellCap + 1))) ||
+  if ((rc = dev_alloc(c, &c->d_desc, (size_t) C)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t) C * (size_t) kCellStride)) ||
       (rc = dev_alloc(c, &c->d_cell_count, (size_t) C * kCellCap)) || (rc = dev_alloc(c, &c->d_bbox_part, (size_t) C * kBboxBlocks * 6)) ||
       (rc = dev_alloc(c, &c->d_tile_state, (size_t) C * (kCellCap / 1024))))
     return rc;

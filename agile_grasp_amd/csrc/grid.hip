@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xy
 // publishes (build number, flag, value) in one 64-bit word: flag 1 = the tile's own total, 2 = its inclusive prefix;
 // the build number makes stale words from earlier builds invisible, so the descriptors never need clearing.  The kernel
 // also zeroes the histogram it has read: the next build starts from a clean one without a memset.
-constexpr int kScanBlock = 1024;
+constexpr int kScanBlock = 4096;  // cells per tile: 16 per thread, four 16-byte accesses each way
 
 __device__ __forceinline__ int block_scan_excl(int v, int* total)
 {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, Grid
   const int p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
   count += (int64_t) blockIdx.y * kCellCap;
   tile_state += (int64_t) blockIdx.y * (kCellCap / kScanBlock);
-  cell_start += (int64_t) blockIdx.y * (kCellCap + 1);
+  cell_start += (int64_t) blockIdx.y * kCellStride;
   d += blockIdx.y;
   const int ncell = d->ncell;
   // 256 resident work-groups walk the tiles round-robin: tile t only ever waits for tiles < t, which belong to the
@@ -228,12 +228,13 @@ __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, Grid
   for (int tile = blockIdx.x; tile * kScanBlock < ncell; tile += gridDim.x)
   {
   const int b0 = tile * kScanBlock;
-  int v[4], sum = 0;
+  // thread t owns the cells b0 + 16 t .. + 15 (the table is padded to whole tiles, and cells past ncell hold zero counts)
+  int4 v[4];
+  int sum = 0;
   for (int k = 0; k < 4; k++)
   {
-    const int i = b0 + threadIdx.x * 4 + k;
-    v[k] = i < ncell ? count[i] : 0;
-    sum += v[k];
+    v[k] = reinterpret_cast<const int4*>(count + b0)[threadIdx.x * 4 + k];
+    sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   int total;
   int ex = block_scan_excl(sum, &total);
@@ -282,13 +283,15 @@ __global__ __launch_bounds__(256) void k_cell_scan(int* __restrict__ count, Grid
   ex += s_prefix + p0;
   for (int k = 0; k < 4; k++)
   {
-    const int i = b0 + threadIdx.x * 4 + k;
-    if (i < ncell)
-    {
-      cell_start[i] = ex;
-      count[i] = 0;
-    }
-    ex += v[k];
+    int4 o;
+    o.x = ex;
+    o.y = o.x + v[k].x;
+    o.z = o.y + v[k].y;
+    o.w = o.z + v[k].z;
+    ex = o.w + v[k].w;
+    // (entries past ncell are scratch of the padded table; the one AT ncell is written below, after everybody's stores)
+    reinterpret_cast<int4*>(cell_start + b0)[threadIdx.x * 4 + k] = o;
+    reinterpret_cast<int4*>(count + b0)[threadIdx.x * 4 + k] = make_int4(0, 0, 0, 0);
   }
   if (tile == 0 && threadIdx.x == 0)
     cell_start[ncell] = p0 + n;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ xyz, 
   const int* __restrict__ rank_of, const int* __restrict__ cell_start, float4* __restrict__ sorted)
 {
   const int64_t p0 = cloud_off[blockIdx.y], p1 = cloud_off[blockIdx.y + 1];
-  cell_start += (int64_t) blockIdx.y * (kCellCap + 1);
+  cell_start += (int64_t) blockIdx.y * kCellStride;
   for (int64_t i = p0 + blockIdx.x * (int64_t) blockDim.x + threadIdx.x; i < p1; i += (int64_t) gridDim.x * blockDim.x)
   {
     const int pos = cell_start[cell_of[i]] + rank_of[i];
