@@ -570,17 +570,25 @@ __device__ __forceinline__ void csolve_step(const double (&yrow)[9], const doubl
   crow[J] = t / bcast16<J>(lrow[J]);
 }
 
+// One sample's LDS.  M and N are read once, into registers, before anything writes A, L, Y or V (a work-group is one
+// wave: program order is enough), so the two sets share their bytes: 2.6 KB per sample, 10.4 KB per work-group.
 struct EigSmem
 {
-  double M[10][10];
-  double N[10][10];
-  double A[9][9];  // S, then C, then the Jacobi iterate
-  double L[9][9];
-  double Y[9][9];
-  double V[9][9];
-  double cs[4][2];  // (c, s) of the four rotations of a Jacobi round
-  int flag[4];
-  double off;
+  union
+  {
+    struct
+    {
+      double M[10][10];
+      double N[10][10];
+    };
+    struct
+    {
+      double A[9][9];  // C, then the eigenvalues on its diagonal
+      double L[9][9];
+      double Y[9][9];
+      double V[9][9];
+    };
+  };
   int fail;
 };
 
@@ -595,12 +603,28 @@ __device__ __forceinline__ int order_bin(int w) { return kOrderBins - 1 - min(w 
 
 __device__ void sample_order_block(const int* __restrict__ weight, int S, int* __restrict__ order, int* hist)
 {
+  // One wave walks the S weights twice.  Every step of the walk is a global-load round trip, so a lane takes kPer weights
+  // per step with all its loads in flight together (one weight per step took 2 x S / 64 round trips: 140 us at S = 8000,
+  // twice what the eigen solves beside it need -- the sorter WAS k_taubin_eigen's duration at C4 and in the batch).
+  constexpr int kPer = 16;
   const int lane = threadIdx.x;  // 64 threads
   for (int b = lane; b < kOrderBins; b += 64)
     hist[b] = 0;
   __syncthreads();
-  for (int s = lane; s < S; s += 64)
-    atomicAdd(&hist[order_bin(weight[s])], 1);
+  for (int base = 0; base < S; base += 64 * kPer)
+  {
+    int bin[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      const int s = base + u * 64 + lane;
+      bin[u] = s < S ? order_bin(weight[s]) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (bin[u] >= 0)
+        atomicAdd(&hist[bin[u]], 1);
+  }
   __syncthreads();
   constexpr int per = kOrderBins / 64;  // consecutive bins per lane
   int loc = 0;
@@ -621,19 +645,36 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
     run += c;
   }
   __syncthreads();
-  for (int s = lane; s < S; s += 64)
-    order[atomicAdd(&hist[order_bin(weight[s])], 1)] = s;
+  for (int base = 0; base < S; base += 64 * kPer)
+  {
+    int bin[kPer], pos[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      const int s = base + u * 64 + lane;
+      bin[u] = s < S ? order_bin(weight[s]) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      pos[u] = bin[u] >= 0 ? atomicAdd(&hist[bin[u]], 1) : 0;
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (bin[u] >= 0)
+        order[pos[u]] = base + u * 64 + lane;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
   const int* __restrict__ weight, int* __restrict__ order)
 {
+  // (the sorter's histogram shares the solver's LDS: a work-group is one or the other.  With both side by side a
+  // work-group took 24.8 KB, six of these one-wave groups filled a CU's LDS and the 2000 waves of C4 ran in two rounds.)
   __shared__ EigSmem sm[4];
-  __shared__ int order_hist[kOrderBins];
+  static_assert(sizeof(EigSmem) * 4 >= sizeof(int) * kOrderBins, "the sorter's histogram lives in the solver's LDS");
   if (blockIdx.x == gridDim.x - 1)  // the extra work-group: scheduling order of the following kernels
   {
-    sample_order_block(weight, S, order, order_hist);
+    sample_order_block(weight, S, order, reinterpret_cast<int*>(&sm[0]));
     return;
   }
   const int lane = threadIdx.x, gl = lane & 15, grp = lane >> 4;
