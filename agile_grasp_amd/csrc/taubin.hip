@@ -589,6 +589,7 @@ struct EigSmem
       double V[9][9];
     };
   };
+  double m[9];  // M[k][9], k < 9: needed once more at the very end (the eliminated 10th unknown)
   int fail;
 };
 
@@ -771,6 +772,8 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
         E.M[j][i] = E.M[i][j];
         E.N[j][i] = E.N[i][j];
       }
+    for (int k = 0; k < 9; k++)
+      E.m[k] = E.M[k][9];
   }
   __syncthreads();
   const bool row = gl < 9;
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
       }
       double bv = 0.0;
       for (int k = 0; k < 9; k++)
-        bv += E.M[k][9] * v[k];
+        bv += E.m[k] * v[k];
       v[9] = -bv / n;
       for (int k = 3; k < 6; k++)
         v[k] *= 0.5;  // quadric.cpp:153
