@@ -392,6 +392,35 @@ __device__ __forceinline__ double shfl16(double v, int src_in_group, int gbase)
   return __shfl(v, gbase + src_in_group);
 }
 
+// The row exchange of a Jacobi round as DPP moves.  In round R lane i (row i of its 16-lane group) needs the value of lane
+// (C - i) mod 9, C = 2 R mod 9: a reflection of the lanes [0, C] and a reflection of the lanes [C + 1, 8].  With
+// t = row_mirror(x) (t[i] = x[15 - i]), row_shl:(15 - C) of t is the first reflection (exactly the lanes i <= C have an
+// in-row source, the others keep `old`), and row_shl:(6 - C) / row_shr:(C - 6) of t is the second, which goes in as `old`.
+// C = 7 is row_half_mirror on the lanes 0..7.  One to three DPP moves per 32-bit half instead of a ds_bpermute and its
+// wait: the 18 permutes per round were where the wave stood waiting for LDS, 28 % of its cycles.  (64-bit DPP exists for
+// row_newbcast only.)  Lanes 9..15 receive don't-care values, as they hold don't-care rows.
+template <int C>
+__device__ __forceinline__ int mate16_half(int x)
+{
+  constexpr int kMirror = 0x140, kHalfMirror = 0x141, kShl = 0x100, kShr = 0x110;
+  if (C == 7)
+    return __builtin_amdgcn_update_dpp(x, x, kHalfMirror, 0xf, 0x3, false);  // banks 0, 1 = lanes 0..7; lane 8 keeps x
+  const int t = __builtin_amdgcn_update_dpp(0, x, kMirror, 0xf, 0xf, true);
+  if (C == 8)
+    return __builtin_amdgcn_update_dpp(0, t, kShl + 7, 0xf, 0xf, true);
+  constexpr int k2 = 6 - C;
+  int u2 = t;
+  if (k2 > 0)
+    u2 = __builtin_amdgcn_update_dpp(0, t, kShl + (k2 > 0 ? k2 : 1), 0xf, 0xf, true);
+  // (k2 < 0 cannot happen here: C = 7 and C = 8 returned above)
+  return __builtin_amdgcn_update_dpp(u2, t, kShl + (15 - C), 0xf, 0xf, false);
+}
+template <int C>
+__device__ __forceinline__ double mate16(double v)
+{
+  return __hiloint2double(mate16_half<C>(__double2hiint(v)), mate16_half<C>(__double2loint(v)));
+}
+
 // Lane N of every 16-lane row to all lanes of that row: one DPP move per 32-bit half (row_newbcast, gfx90a+), no LDS
 // crossbar and no wait.  The 16-lane groups of k_taubin_eigen are exactly the DPP rows.
 template <int N>
@@ -469,7 +498,11 @@ __device__ __forceinline__ bool rr_needs_rotation(const double (&ar)[9], int gl,
   return row && J > gl && v != 0.0 && !negl;
 }
 
-template <int R>
+// LAT: the build for launches of at most one wave per SIMD, where the kernel's duration is one wave's latency chain --
+// branch-free predicates (a short-circuit is a branch at the end of every round, and the basic-block boundary keeps the
+// compiler from starting the next round's parameter chain under this round's row phase) and the row exchange as DPP moves
+// (no LDS wait).  It issues a fifth more instructions, so the plain build stays for launches with two waves per SIMD.
+template <int R, bool LAT>
 __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], int gl, int gbase, bool row, bool active,
   int sweep)
 {
@@ -487,16 +520,26 @@ __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], i
   // (2) rotation parameters (both lanes of a pair compute the same values); lanes without a rotation get the
   //     identity and never use it
   const double aabs = fabs(apq);
-  const bool cand = active && kk != 0 && apq != 0.0;
-  const bool negligible = sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq));
+  bool cand, negligible;
+  if (LAT)
+  {
+    cand = active & (kk != 0) & (apq != 0.0);
+    negligible = (sweep > 3) & (fabs(app) + aabs == fabs(app)) & (fabs(aqq) + aabs == fabs(aqq));
+  }
+  else
+  {
+    cand = active && kk != 0 && apq != 0.0;
+    negligible = sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq));
+  }
   // oracle jacobi_rr9: h = sqrt(alpha^2 + beta^2), d = |alpha| + h, r = sqrt(d^2 + beta^2), c = d / r,
   // s = sgn |beta| / r
   const double alpha = aqq - app, beta = 2.0 * apq;
   const double h = sqrt(alpha * alpha + beta * beta);
   const double dsum = fabs(alpha) + h;
   const double rr = sqrt(dsum * dsum + beta * beta);
-  const bool rot = cand && !negligible && rr > 0.0;
-  const bool neg = (alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0);
+  const bool rot = LAT ? (cand & !negligible & (rr > 0.0)) : (cand && !negligible && rr > 0.0);
+  const bool neg = LAT ? (((alpha < 0.0) & (beta > 0.0)) | ((alpha > 0.0) & (beta < 0.0)))
+                       : ((alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0));
   const double rsafe = rot ? rr : 1.0;
   const double sb = fabs(beta) / rsafe;
   const double c = rot ? dsum / rsafe : 1.0;
@@ -514,7 +557,7 @@ __device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], i
   for (int j = 0; j < 9; j++)
   {
     const double own = ar[j];
-    const double other = shfl16(own, mate, gbase);
+    const double other = LAT ? mate16<(2 * R) % 9>(own) : shfl16(own, mate, gbase);
     ar[j] = c * own - se * other;  // (identity for a lane whose pair does not rotate, see rr_columns)
   }
   // (5) the rotated entries are exactly zero (both triangles)
@@ -665,6 +708,7 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
   }
 }
 
+template <bool LAT>
 __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
   const int* __restrict__ weight, int* __restrict__ order)
@@ -876,15 +920,15 @@ __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ 
     const bool active = ((nzb >> gbase) & 0xffffull) != 0 && ((needb >> gbase) & 0xffffull) != 0;
     if (__ballot(active) == 0ull)
       break;
-    jacobi_round<0>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<1>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<2>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<3>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<4>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<5>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<6>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<7>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<8>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<0, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<1, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<2, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<3, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<4, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<5, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<6, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<7, LAT>(ar, vr, gl, gbase, row, active, sweep);
+    jacobi_round<8, LAT>(ar, vr, gl, gbase, row, active, sweep);
   }
   if (row)
   {
@@ -1423,8 +1467,16 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
-  hipLaunchKernelGGL(k_taubin_eigen, dim3((Si + 3) / 4 + 1), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-    c->d_flags, (const int*) c->d_weight, c->d_order);
+  // Two builds of the solver (see jacobi_round): LAT when every wave has a SIMD to itself, and again when the launch
+  // needs three waves per SIMD anyway (only LAT's 167 VGPRs allow that); the plain one for two per SIMD.  Measured, us:
+  // 500 waves 61 (plain 66), 2000 waves 95 (LAT 119), 4000 waves 197 (plain 213).
+  const int eig_groups = (Si + 3) / 4 + 1;
+  if (eig_groups <= 1024 || eig_groups > 2048)
+    hipLaunchKernelGGL(k_taubin_eigen<true>, dim3(eig_groups), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) c->d_weight, c->d_order);
+  else
+    hipLaunchKernelGGL(k_taubin_eigen<false>, dim3(eig_groups), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) c->d_weight, c->d_order);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
