@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   __shared__ double wmax_s[NW];
   __shared__ unsigned short cand[CAP];
   __shared__ int ncand;
+  __shared__ int bar3cnt;  // arrivals at the barriers of the estimate phase (waves 1..3 of the four-wave variant)
 
   const int s = order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1057,6 +1058,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   {
     next_col = 0;
     ncand = 0;
+    bar3cnt = 0;
   }
   __syncthreads();
   const float4* nb = nbr + (int64_t) s * nbr_stride;
@@ -1077,160 +1079,36 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   __syncthreads();
   if (debug_stop == 1)
     return;
-  // ---- argmax_j sum_i (n_i . n_j)^6 (quadric.cpp:283-284) by filter-and-refine ----
-  // The reference needs only the ARGMAX of the n column sums.  (1) A cheap estimate of every column sum:
-  //   sum_i (n_i . n_j)^6 = sum_{a+b+c=6} 6!/(a!b!c!) T_abc jx^a jy^b jz^c,   T_abc = sum_i nx_i^a ny_i^b nz_i^c,
-  // i.e. 28 moments of the normals (O(n)) instead of n^2 dot products; its rounding error is < 3e-12 n.
-  // (2) Every column whose estimate is within delta = 1e-9 n + 1e-7 max of the best estimate -- hundreds of times
-  // the error bound, so the true (sequentially rounded) maximum and all its exact ties are among them -- gets the
-  // reference's exact sequential sum; the argmax (first index on ties) is taken over those.  The result is the
-  // same index the exhaustive n^2 evaluation yields (asserted against the exhaustive oracle by the parity tests).
-  // With at most 64 normals (always in the reference's production mode, which subsamples 50) a column's exact sum is
-  // one term per lane plus the butterfly: evaluating all columns exactly is cheaper than estimating them first
-  // (measured; with up to 128 it is not).
-  if (ks <= 64)
-  {
-    for (int j = tid; j < ks; j += THREADS)
-      cand[j] = (unsigned short) j;
-    if (tid == 0)
-      ncand = ks;
-  }
-  else
-  {
+  // Division of labour in the four-wave variant when the columns are estimated first (more than 64 normals): waves 1..3 run
+  // the estimate phase and synchronise among themselves through an LDS counter, while wave 0 accumulates M3 and runs its
+  // 3 x 3 eigen solve -- a chain of dependent divisions and square roots on ONE lane, ~10 us -- at the same time; the four
+  // waves meet again at the work queue of the exact column sums.  (A round-2 attempt ran the solve in slices between
+  // work-group barriers shared by all four waves; its timing depended on the box.  Here wave 0 meets no barrier at all.)
+  constexpr bool kSplit = NW == 4;
+  const bool use3 = kSplit && ks > 64;  // uniform over the work-group
+  constexpr int ET = kSplit ? THREADS - 64 : THREADS;  // threads of the estimate phase
+  constexpr int ENW = kSplit ? NW - 1 : NW;
+  const int et = kSplit ? tid - 64 : tid, ew = kSplit ? wave - 1 : wave;
+  int bar_phase = 0;
+  auto wait3 = [&](int target) {
+    while (__hip_atomic_load(&bar3cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(1);
+    __threadfence_block();
+  };
+  auto ebar = [&]() {  // barrier of the estimate phase: waves 1..3 only in the split variant
+    if (kSplit)
     {
-      double T[28];
-  #pragma unroll
-      for (int k = 0; k < 28; k++)
-        T[k] = 0.0;
-      for (int t = tid; t < ks; t += THREADS)
-      {
-        const double x = nx[t], y = ny[t], z = nz[t];
-        double px[7], py[7], pz[7];
-        px[0] = py[0] = pz[0] = 1.0;
-  #pragma unroll
-        for (int k = 1; k < 7; k++)
-        {
-          px[k] = px[k - 1] * x;
-          py[k] = py[k - 1] * y;
-          pz[k] = pz[k - 1] * z;
-        }
-        int k = 0;
-  #pragma unroll
-        for (int a = 6; a >= 0; a--)
-  #pragma unroll
-          for (int b = 6 - a; b >= 0; b--)
-            T[k++] += (px[a] * py[b]) * pz[6 - a - b];
-      }
-      // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
-      // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
-      // full butterflies (168 exchanges) would; lane l ends with the total of moment l >> 1.
-      double R[32];
-  #pragma unroll
-      for (int k = 0; k < 32; k++)
-        R[k] = k < 28 ? T[k] : 0.0;
-  #pragma unroll
-      for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1)
-      {
-        const bool upper = (lane & o) != 0;
-  #pragma unroll
-        for (int k = 0; k < half; k++)
-        {
-          const double send = upper ? R[k] : R[k + half];
-          const double keep = upper ? R[k + half] : R[k];
-          R[k] = keep + __shfl_xor(send, o);
-        }
-      }
-      R[0] = R[0] + __shfl_xor(R[0], 1);
-      if ((lane & 1) == 0 && (lane >> 1) < 28)
-        sT[wave][lane >> 1] = R[0];
+      bar_phase++;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0)
+        __hip_atomic_fetch_add(&bar3cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      wait3(3 * bar_phase);
     }
-    __syncthreads();
-    if (tid < 28)  // multinomial-weighted moments, once per block
-    {
-      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
-      int k = 0, ea = 0, eb = 0;
-      for (int a = 6; a >= 0; a--)
-        for (int b = 6 - a; b >= 0; b--)
-        {
-          if (k == tid)
-          {
-            ea = a;
-            eb = b;
-          }
-          k++;
-        }
-      double tsum = sT[0][tid];
-      for (int w = 1; w < NW; w++)
-        tsum = tsum + sT[w][tid];
-      sW[tid] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
-    }
-    __syncthreads();
-    double est[(CAP + THREADS - 1) / THREADS];
-    double est_max = -1.0;
-    {
-      double W[28];
-  #pragma unroll
-      for (int k = 0; k < 28; k++)
-        W[k] = sW[k];
-  #pragma unroll
-      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
-      {
-        const int j = tid + THREADS * m;
-        double e_ = -2.0;
-        if (j < ks)
-        {
-          const double x = nx[j], y = ny[j], z = nz[j];
-          double px[7], py[7], pz[7];
-          px[0] = py[0] = pz[0] = 1.0;
-          for (int k = 1; k < 7; k++)
-          {
-            px[k] = px[k - 1] * x;
-            py[k] = py[k - 1] * y;
-            pz[k] = pz[k - 1] * z;
-          }
-          e_ = 0.0;
-          int k = 0;
-          for (int a = 6; a >= 0; a--)
-            for (int b = 6 - a; b >= 0; b--)
-              e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
-          if (!(e_ == e_))
-            e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
-        }
-        est[m] = e_;
-        est_max = fmax(est_max, e_);
-      }
-    }
-    est_max = wave_max_f64_(est_max);
-    if (lane == 0)
-      wmax_s[wave] = est_max;
-    __syncthreads();
-    est_max = wmax_s[0];
-    for (int w = 1; w < NW; w++)
-      est_max = fmax(est_max, wmax_s[w]);
-    {
-      const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
-  #pragma unroll
-      for (int m = 0; m < (CAP + THREADS - 1) / THREADS; m++)
-      {
-        const int j = tid + THREADS * m;
-        const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
-        const unsigned long long mk = __ballot(is_c);
-        int base = 0;
-        if (lane == 0 && mk)
-          base = atomicAdd(&ncand, __popcll(mk));
-        base = __shfl(base, 0);
-        if (is_c)
-          cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
-      }
-    }
-  }
-  __syncthreads();
-  const int ncnd = ncand;
-  if (debug_stop == 2)
-    return;
-  // ---- wave 0 (the other waves go straight to the exact column sums below): M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors ----
-  if (wave == 0)
-  {
+    else
+      __syncthreads();
+  };
+  auto m3_and_axis = [&]() {  // one wave: M3 = normals * normals^T by sequential sums (quadric.cpp:266), then its eigenvectors
     // M3 in the oracle's LaneSum64 order: lane l owns partial l (terms l, l + 64, ...), butterfly tree at the end
     double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
     if (!(debug_stop == 5 || debug_stop == 7))
@@ -1275,7 +1153,172 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
       sAxis[1] = V[1][mi];
       sAxis[2] = V[2][mi];
     }
+  };
+  // ---- argmax_j sum_i (n_i . n_j)^6 (quadric.cpp:283-284) by filter-and-refine ----
+  // The reference needs only the ARGMAX of the n column sums.  (1) A cheap estimate of every column sum:
+  //   sum_i (n_i . n_j)^6 = sum_{a+b+c=6} 6!/(a!b!c!) T_abc jx^a jy^b jz^c,   T_abc = sum_i nx_i^a ny_i^b nz_i^c,
+  // i.e. 28 moments of the normals (O(n)) instead of n^2 dot products; its rounding error is < 3e-12 n.
+  // (2) Every column whose estimate is within delta = 1e-9 n + 1e-7 max of the best estimate -- hundreds of times
+  // the error bound, so the true (sequentially rounded) maximum and all its exact ties are among them -- gets the
+  // reference's exact sequential sum; the argmax (first index on ties) is taken over those.  The result is the
+  // same index the exhaustive n^2 evaluation yields (asserted against the exhaustive oracle by the parity tests).
+  // With at most 64 normals (always in the reference's production mode, which subsamples 50) a column's exact sum is
+  // one term per lane plus the butterfly: evaluating all columns exactly is cheaper than estimating them first
+  // (measured; with up to 128 it is not).
+  if (ks <= 64)
+  {
+    for (int j = tid; j < ks; j += THREADS)
+      cand[j] = (unsigned short) j;
+    if (tid == 0)
+      ncand = ks;
   }
+  else if (kSplit && wave == 0)
+    m3_and_axis();
+  else
+  {
+    {
+      double T[28];
+  #pragma unroll
+      for (int k = 0; k < 28; k++)
+        T[k] = 0.0;
+      for (int t = et; t < ks; t += ET)
+      {
+        const double x = nx[t], y = ny[t], z = nz[t];
+        double px[7], py[7], pz[7];
+        px[0] = py[0] = pz[0] = 1.0;
+  #pragma unroll
+        for (int k = 1; k < 7; k++)
+        {
+          px[k] = px[k - 1] * x;
+          py[k] = py[k - 1] * y;
+          pz[k] = pz[k - 1] * z;
+        }
+        int k = 0;
+  #pragma unroll
+        for (int a = 6; a >= 0; a--)
+  #pragma unroll
+          for (int b = 6 - a; b >= 0; b--)
+            T[k++] += (px[a] * py[b]) * pz[6 - a - b];
+      }
+      // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
+      // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
+      // full butterflies (168 exchanges) would; lane l ends with the total of moment l >> 1.
+      double R[32];
+  #pragma unroll
+      for (int k = 0; k < 32; k++)
+        R[k] = k < 28 ? T[k] : 0.0;
+  #pragma unroll
+      for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1)
+      {
+        const bool upper = (lane & o) != 0;
+  #pragma unroll
+        for (int k = 0; k < half; k++)
+        {
+          const double send = upper ? R[k] : R[k + half];
+          const double keep = upper ? R[k + half] : R[k];
+          R[k] = keep + __shfl_xor(send, o);
+        }
+      }
+      R[0] = R[0] + __shfl_xor(R[0], 1);
+      if ((lane & 1) == 0 && (lane >> 1) < 28)
+        sT[ew][lane >> 1] = R[0];
+    }
+    ebar();
+    if (et < 28)  // multinomial-weighted moments, once per block
+    {
+      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
+      int k = 0, ea = 0, eb = 0;
+      for (int a = 6; a >= 0; a--)
+        for (int b = 6 - a; b >= 0; b--)
+        {
+          if (k == et)
+          {
+            ea = a;
+            eb = b;
+          }
+          k++;
+        }
+      double tsum = sT[0][et];
+      for (int w = 1; w < ENW; w++)
+        tsum = tsum + sT[w][et];
+      sW[et] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
+    }
+    ebar();
+    constexpr int EST = (CAP + ET - 1) / ET;
+    double est[EST];
+    double est_max = -1.0;
+    {
+      double W[28];
+  #pragma unroll
+      for (int k = 0; k < 28; k++)
+        W[k] = sW[k];
+  #pragma unroll
+      for (int m = 0; m < EST; m++)
+      {
+        const int j = et + ET * m;
+        double e_ = -2.0;
+        if (j < ks)
+        {
+          const double x = nx[j], y = ny[j], z = nz[j];
+          double px[7], py[7], pz[7];
+          px[0] = py[0] = pz[0] = 1.0;
+          for (int k = 1; k < 7; k++)
+          {
+            px[k] = px[k - 1] * x;
+            py[k] = py[k - 1] * y;
+            pz[k] = pz[k - 1] * z;
+          }
+          e_ = 0.0;
+          int k = 0;
+          for (int a = 6; a >= 0; a--)
+            for (int b = 6 - a; b >= 0; b--)
+              e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
+          if (!(e_ == e_))
+            e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
+        }
+        est[m] = e_;
+        est_max = fmax(est_max, e_);
+      }
+    }
+    est_max = wave_max_f64_(est_max);
+    if (lane == 0)
+      wmax_s[ew] = est_max;
+    ebar();
+    est_max = wmax_s[0];
+    for (int w = 1; w < ENW; w++)
+      est_max = fmax(est_max, wmax_s[w]);
+    {
+      const double delta = 1e-9 * (double) ks + 1e-7 * fabs(est_max);
+  #pragma unroll
+      for (int m = 0; m < EST; m++)
+      {
+        const int j = et + ET * m;
+        const bool is_c = j < ks && (est[m] >= est_max - delta || est_max >= 1e299);
+        const unsigned long long mk = __ballot(is_c);
+        int base = 0;
+        if (lane == 0 && mk)
+          base = atomicAdd(&ncand, __popcll(mk));
+        base = __shfl(base, 0);
+        if (is_c)
+          cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
+      }
+    }
+  }
+  if (use3)
+  {
+    if (wave == 0)
+      wait3(3 * 4);  // the candidate list is complete when waves 1..3 have passed their fourth barrier
+    else
+      ebar();
+  }
+  else
+    __syncthreads();
+  const int ncnd = ncand;
+  if (debug_stop == 2)
+    return;
+  // ---- without the split: wave 0 (the other waves go straight to the exact column sums below) ----
+  if (wave == 0 && !use3)
+    m3_and_axis();
   if (debug_stop == 3)
     return;
   // exact sums of the candidate columns in the oracle's LaneSum64 order, one candidate per wave at a time: lane l adds
