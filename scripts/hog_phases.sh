@@ -1,0 +1,9 @@
+#!/bin/bash
+# Cumulative phase times of k_hog_svm (AGH_DEBUG_STOP_HOG = 1..5; debug build): bash scripts/hog_phases.sh
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+AGH_DEBUG_BUILD=1 python -c "from agile_grasp_amd import build; build.build(force=True)" > /dev/null 2>&1
+for k in 1 2 3 4 5 0; do
+  AGH_DEBUG_STOP_HOG=$k timeout 200 python bench.py --config C3 --steps 30 --warmup 5 --no-cpu-baseline --batch-clouds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1]); print('stop $k hog_svm us', round(d['kernel_ms_per_step']['hog_svm']*1000,1))"
+done
