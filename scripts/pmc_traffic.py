@@ -34,8 +34,10 @@ for k in sorted(set(fetch) | set(write)):
     short = k.split("agh")[1].lstrip("0123456789").split("E")[0] if "_ZN3agh" in k else k
     short = k[k.index("agh") + 3:]
     short = short.lstrip("0123456789")
-    name = short.split("ILi")[0].split("EP")[0].split("ENS")[0]
+    name = short.split("ILi")[0].split("ILb")[0].split("EP")[0].split("ENS")[0]
     cap = ("<" + short.split("ILi")[1].split("E")[0] + ">") if "ILi" in short else ""
+    if "ILb" in short:  # bool template argument (k_taubin_eigen<latency build?>)
+        cap = "<latency>" if short.split("ILb")[1].startswith("1") else "<plain>"
     f = fetch.get(k, (1, 0.0))
     w = write.get(k, (1, 0.0))
     entry["kernels"][name + cap] = {"fetch_kib_per_launch": f[1] / f[0], "write_kib_per_launch": w[1] / w[0],
