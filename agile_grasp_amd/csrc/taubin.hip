@@ -990,7 +990,7 @@ __device__ __forceinline__ double wave_max_f64_(double v)
 // THREADS = 256 (one work-group of four waves per sample) or 64 (one wave per sample: the class for at most 128 normals
 // of the r = 0.01 all-points pass).
 template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
+__global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CAP == 64 && THREADS == 256) ? 8 : 1)) void k_taubin_frame(const float4* __restrict__ nbr, int64_t nbr_stride,
   const int32_t* __restrict__ nt, const double* __restrict__ eig, const int32_t* __restrict__ status,
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
   }
   __syncthreads();
   const float4* nb = nbr + (int64_t) s * nbr_stride;
+  int cam1 = 0;  // this thread's neighbours seen by camera 1 (quadric.cpp:215-226)
   for (int t = tid; t < ks; t += THREADS)
   {
     const int pick = sub ? (draws[draw_ofs[s] + t] % n) : t;
@@ -1074,8 +1075,13 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
     nx[t] = fx / mag;
     ny[t] = fy / mag;
     nz[t] = fz / mag;
-    atomicAdd(&camcnt[__float_as_uint(p.w) & 1u], 1);  // quadric.cpp:215-226
+    cam1 += (int) (__float_as_uint(p.w) & 1u);
   }
+  // one LDS atomic per wave (one per neighbour put up to 64 lanes on two addresses, and an LDS atomic serialises them)
+  for (int o = 32; o > 0; o >>= 1)
+    cam1 += __shfl_xor(cam1, o);
+  if (lane == 0 && cam1)
+    atomicAdd(&camcnt[1], cam1);
   __syncthreads();
   if (debug_stop == 1)
     return;
@@ -1172,6 +1178,8 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
     if (tid == 0)
       ncand = ks;
   }
+  else if (CAP <= 64)
+    ;  // (this instantiation never estimates: the branch below would only cost it registers)
   else if (kSplit && wave == 0)
     m3_and_axis();
   else
@@ -1399,7 +1407,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : 1) v
     double normal[3] = { np_[0] / nn, np_[1] / nn, np_[2] / nn };
     double binormal[3] = { axis[1] * normal[2] - axis[2] * normal[1], axis[2] * normal[0] - axis[0] * normal[2],
       axis[0] * normal[1] - axis[1] * normal[0] };  // quadric.cpp:291
-    const int maj = (camcnt[1] > camcnt[0]) ? 1 : 0;
+    const int maj = (camcnt[1] > ks - camcnt[1]) ? 1 : 0;  // camera 1's count against camera 0's
     const double sample[3] = { (double) qp[0], (double) qp[1], (double) qp[2] };
     const double s2s[3] = { sample[0] - (maj ? cam1x : cam0x), sample[1] - (maj ? cam1y : cam0y),
       sample[2] - (maj ? cam1z : cam0z) };
@@ -1548,12 +1556,23 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
     (const int*) c->d_order)
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
-  if (small_class)
-    AGH_LAUNCH_FRAME(1152, 256, 128);
+  if (rand_mode && !small_class)
+  {
+    // the reference's production mode: a sample needs room for min(n, 50) normals whatever its neighbourhood holds, so one
+    // class serves every sample -- 1.5 KB of LDS and no estimate phase (<= 64 VGPRs): eight work-groups per CU, all 2000
+    // work-groups of C2 resident in one round (49 -> 29 us; the 1152 class ran them five per CU in two rounds, each
+    // mostly waiting for its one lane in the 3 x 3 eigen solve)
+    AGH_LAUNCH_FRAME(64, 256, 0);
+  }
   else
-    AGH_LAUNCH_FRAME(1152, 256, 0);
-  if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
-    AGH_LAUNCH_FRAME(4096, 256, 1152);
+  {
+    if (small_class)
+      AGH_LAUNCH_FRAME(1152, 256, 128);
+    else
+      AGH_LAUNCH_FRAME(1152, 256, 0);
+    if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
+      AGH_LAUNCH_FRAME(4096, 256, 1152);
+  }
 #undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;

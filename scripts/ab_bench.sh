@@ -17,6 +17,10 @@ for L in ab/lib*.so; do
   echo "== $L round $round"
   timeout 300 python bench.py --config C2 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$show"
   timeout 300 python bench.py --config C4 --steps 20 --warmup 5 --no-cpu-baseline --batch-clouds 0 2>/dev/null | python -c "$show"
+  if [ "${AB_RAND:-0}" = 1 ]; then
+    timeout 300 python bench.py --config C2 --normals rand50 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$show"
+    timeout 300 python bench.py --config C4 --normals rand50 --steps 20 --warmup 5 --no-cpu-baseline --batch-clouds 0 2>/dev/null | python -c "$show"
+  fi
   if [ "${AB_C3:-0}" = 1 ]; then
     timeout 300 python bench.py --config C3 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$show"
   fi
