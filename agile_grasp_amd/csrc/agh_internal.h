@@ -287,9 +287,10 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);
-int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st);
+int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st,
+  bool with_draw_offsets = false);
 int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
-  bool write_normals, hipStream_t st);
+  bool write_normals, hipStream_t st, bool draw_offsets_done = false);
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
 int ball_counts(Ctx* c, int64_t S, hipStream_t st);  // d_nh of the last call's samples (agh_get_neighbor_counts)
 int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);

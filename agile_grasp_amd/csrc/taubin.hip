@@ -708,18 +708,65 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
   }
 }
 
+// RAND50: sample i consumes 50 draws iff its neighbourhood has more than 50 points, in sample order (one wave: chunked
+// inclusive scan; *total_io carries the draws consumed by earlier passes of this call).
+__device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
+  int32_t* __restrict__ total_io)
+{
+  // sixteen consecutive samples per lane and step (one wave scan per 1024 samples: with one sample per lane the 16 000
+  // samples of a batch were 250 dependent scans, 100 us on the critical path of k_taubin_eigen's sorter work-group)
+  constexpr int kPer = 16;
+  const int lane = threadIdx.x;
+  int carry = *total_io;
+  for (int c0 = 0; c0 < S; c0 += 64 * kPer)
+  {
+    const int i0 = c0 + lane * kPer;
+    int v[kPer], sum = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      v[u] = (i0 + u < S && nt[i0 + u] > 50) ? 50 : 0;
+      sum += v[u];
+    }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+    int run = carry + inc - sum;
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      if (i0 + u < S)
+        draw_ofs[i0 + u] = run;
+      run += v[u];
+    }
+    carry += __shfl(inc, 63);
+  }
+  if (lane == 0)
+    *total_io = carry;
+}
+
 template <bool LAT>
 __global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
-  const int* __restrict__ weight, int* __restrict__ order)
+  const int* __restrict__ weight, int* __restrict__ order, int32_t* __restrict__ draw_ofs, int32_t* __restrict__ draw_total_io)
 {
   // (the sorter's histogram shares the solver's LDS: a work-group is one or the other.  With both side by side a
   // work-group took 24.8 KB, six of these one-wave groups filled a CU's LDS and the 2000 waves of C4 ran in two rounds.)
   __shared__ EigSmem sm[4];
   static_assert(sizeof(EigSmem) * 4 >= sizeof(int) * kOrderBins, "the sorter's histogram lives in the solver's LDS");
-  if (blockIdx.x == gridDim.x - 1)  // the extra work-group: scheduling order of the following kernels
+  const int n_solver_groups = (S + 3) / 4;
+  if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling order of the following kernels
   {
     sample_order_block(weight, S, order, reinterpret_cast<int*>(&sm[0]));
+    return;
+  }
+  if ((int) blockIdx.x > n_solver_groups)  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
+  {                                        // instead of in a launch of their own (12 us at C2: a launch for one wave)
+    draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
     return;
   }
   const int lane = threadIdx.x, gl = lane & 15, grp = lane >> 4;
@@ -1446,43 +1493,24 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   }
 }
 
-// RAND50: sample i consumes 50 draws iff its neighbourhood has more than 50 points, in sample order.
 __global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
   int32_t* __restrict__ total_io)
 {
-  // single wave: chunked inclusive scan; *total_io carries the draws consumed by earlier passes of this call
-  const int lane = threadIdx.x;
-  int carry = *total_io;
-  for (int c0 = 0; c0 < S; c0 += 64)
-  {
-    const int i = c0 + lane;
-    const int v = (i < S && nt[i] > 50) ? 50 : 0;
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1)
-    {
-      const int t = __shfl_up(inc, o);
-      if (lane >= o)
-        inc += t;
-    }
-    if (i < S)
-      draw_ofs[i] = carry + inc - v;
-    carry += __shfl(inc, 63);
-  }
-  if (lane == 0)
-    *total_io = carry;
+  draw_offsets_wave(nt, S, draw_ofs, total_io);
 }
 
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st)
 {
-  const int rc = taubin_moments_eigen(c, d_samples, S, radius, d_nt, st);
+  const int rc = taubin_moments_eigen(c, d_samples, S, radius, d_nt, st, true);
   if (rc != AGH_OK || c->debug_stop_moments)
     return rc;
-  return taubin_frame_stage(c, d_samples, S, radius, d_frames, d_nt, write_normals, st);
+  return taubin_frame_stage(c, d_samples, S, radius, d_frames, d_nt, write_normals, st, true);
 }
 
 // K1a + K1b for S samples (the sharded search exchanges the RAND50 draw counts between this stage and the next)
-int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st)
+int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double radius, int32_t* d_nt, hipStream_t st,
+  bool with_draw_offsets)
 {
   if (S == 0)
     return AGH_OK;
@@ -1522,25 +1550,29 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   // needs three waves per SIMD anyway (only LAT's 167 VGPRs allow that); the plain one for two per SIMD.  Measured, us:
   // 500 waves 61 (plain 66), 2000 waves 95 (LAT 119), 4000 waves 197 (plain 213).
   const int eig_groups = (Si + 3) / 4 + 1;
+  // (production mode: the sorter work-group also computes the RAND50 draw offsets, unless the caller exchanges the counts
+  // between the ranks first -- the sharded search)
+  int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
+  const int eig_grid = eig_groups + (dofs ? 1 : 0);
   if (eig_groups <= 1024 || eig_groups > 2048)
-    hipLaunchKernelGGL(k_taubin_eigen<true>, dim3(eig_groups), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) c->d_weight, c->d_order);
+    hipLaunchKernelGGL(k_taubin_eigen<true>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) c->d_weight, c->d_order, dofs, c->d_flags + 2);
   else
-    hipLaunchKernelGGL(k_taubin_eigen<false>, dim3(eig_groups), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) c->d_weight, c->d_order);
+    hipLaunchKernelGGL(k_taubin_eigen<false>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) c->d_weight, c->d_order, dofs, c->d_flags + 2);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
 // K1c (and the RAND50 draw offsets, continuing from the count in d_flags[2]) for the same S samples
 int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
-  bool write_normals, hipStream_t st)
+  bool write_normals, hipStream_t st, bool draw_offsets_done)
 {
   if (S == 0)
     return AGH_OK;
   const int Si = (int) S;
   const int rand_mode = c->p.normals_mode == AGH_NORMALS_RAND50 ? 1 : 0;
-  if (rand_mode)
+  if (rand_mode && !draw_offsets_done)
     hipLaunchKernelGGL(k_draw_offsets, dim3(1), dim3(64), 0, st, d_nt, Si, c->d_draw_ofs, c->d_flags + 2);
   const double* co = &c->p.cam_origin[0][0];
   // capacity classes (LDS = 24 B per normal) by the number of normals a sample needs: at most 128 (typical of the
@@ -1560,8 +1592,8 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
   {
     // the reference's production mode: a sample needs room for min(n, 50) normals whatever its neighbourhood holds, so one
     // class serves every sample -- 1.5 KB of LDS and no estimate phase (<= 64 VGPRs): eight work-groups per CU, all 2000
-    // work-groups of C2 resident in one round (49 -> 29 us; the 1152 class ran them five per CU in two rounds, each
-    // mostly waiting for its one lane in the 3 x 3 eigen solve)
+    // work-groups of C2 resident in one round (C2 49 -> 47 us, the batch of eight 333 -> 277; the 1152 class ran them five
+    // per CU, each mostly waiting for its one lane in the 3 x 3 eigen solve)
     AGH_LAUNCH_FRAME(64, 256, 0);
   }
   else

@@ -16,7 +16,8 @@ def run(env):
     for k in ("AGH_DEBUG_STOP_SWEEP", "AGH_DEBUG_STOP_MOMENTS", "AGH_DEBUG_STOP_FRAME"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    ctx = binding.Context(sc.cam_origins, profile=True)
+    ctx = binding.Context(sc.cam_origins, profile=True,
+                          normals_mode=binding.NORMALS_RAND50 if "rand50" in sys.argv else binding.NORMALS_DETERMINISTIC)
     for i in range(13):
         if i == 3:
             torch.cuda.synchronize(); ctx.timing()
