@@ -216,7 +216,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_nh, cap)) || (rc = dev_alloc(c, &c->d_scloud, cap)))
     return rc;
-  if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)) || (rc = dev_alloc(c, &c->d_vmask, cap)))
+  if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)) || (rc = dev_alloc(c, &c->d_vmask, cap + 16)))
     return rc;
   c->nbr_stride = 4096;
   if ((rc = dev_alloc(c, &c->d_nbr, cap * c->nbr_stride)))
