@@ -315,6 +315,11 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // Must be entered with cnt_crop == 0 made visible by a barrier.
   // The walk is software-pipelined: the loads of the NEXT 128 candidates are issued before the current 128 are
   // filtered, so a wave always has two row segments in flight (the gather is bound by L2 latency, not by bandwidth).
+  // (the wave's rows wave, wave + 4, ... live in lane registers -- lane k: start and length of row wave + 4 k -- and the
+  // walk reads them with v_readlane: no LDS round trip between a row's end and the next row's first load)
+  const int my_row = wave + 4 * lane;
+  const int row_begin_v = my_row < nrows ? rt.begin[my_row] : 0;
+  const int row_len_v = my_row < nrows ? rt.prefix[my_row + 1] - rt.prefix[my_row] : 0;
   auto seg_normalize = [&](int& r, int& i, int& rb, int& len) {  // skip exhausted / empty rows
     for (;;)
     {
@@ -324,8 +329,9 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
         rb = 0;
         return;
       }
-      rb = rt.begin[r];
-      len = rt.prefix[r + 1] - rt.prefix[r];
+      const int k = __builtin_amdgcn_readfirstlane((r - wave) >> 2);
+      rb = __builtin_amdgcn_readlane(row_begin_v, k);
+      len = __builtin_amdgcn_readlane(row_len_v, k);
       if (i < len)
         return;
       r += 4;
