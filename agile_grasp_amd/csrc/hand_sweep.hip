@@ -58,17 +58,40 @@ struct OriState
   int last;
 };
 
+// Wave-wide minimum / maximum of a double, the same on every lane: row_shr 1, 2, 4, 8 inside each 16-lane row, row_bcast:15
+// into rows 1 and 3, row_bcast:31 into rows 2 and 3 (a lane without a source keeps its own value: min and max are
+// idempotent), then lane 63 holds the result.  Two 32-bit DPP moves and one v_min_f64 per step instead of the two
+// ds_bpermute round trips of a __shfl_xor butterfly (the finger phase's longest chain).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_self_f64(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63_f64(double v)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-  for (int o = 32; o > 0; o >>= 1)
-    v = fmin(v, __shfl_xor(v, o));
-  return v;
+  v = min_f64_raw(v, dpp_or_self_f64<0x111, 0xf>(v));
+  v = min_f64_raw(v, dpp_or_self_f64<0x112, 0xf>(v));
+  v = min_f64_raw(v, dpp_or_self_f64<0x114, 0xf>(v));
+  v = min_f64_raw(v, dpp_or_self_f64<0x118, 0xf>(v));
+  v = min_f64_raw(v, dpp_or_self_f64<0x142, 0xa>(v));
+  v = min_f64_raw(v, dpp_or_self_f64<0x143, 0xc>(v));
+  return lane63_f64(v);
 }
 __device__ __forceinline__ double wave_max_f64(double v)
 {
-  for (int o = 32; o > 0; o >>= 1)
-    v = fmax(v, __shfl_xor(v, o));
-  return v;
+  v = max_f64_raw(v, dpp_or_self_f64<0x111, 0xf>(v));
+  v = max_f64_raw(v, dpp_or_self_f64<0x112, 0xf>(v));
+  v = max_f64_raw(v, dpp_or_self_f64<0x114, 0xf>(v));
+  v = max_f64_raw(v, dpp_or_self_f64<0x118, 0xf>(v));
+  v = max_f64_raw(v, dpp_or_self_f64<0x142, 0xa>(v));
+  v = max_f64_raw(v, dpp_or_self_f64<0x143, 0xc>(v));
+  return lane63_f64(v);
 }
 // Inclusive OR scan over the 64 lanes: row_shr 1, 2, 4, 8 inside each 16-lane row, then row_bcast:15 into rows 1 and 3
 // and row_bcast:31 into rows 2 and 3 (the compiler fuses each step into one v_or_b32_dpp).
