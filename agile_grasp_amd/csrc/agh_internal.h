@@ -293,7 +293,8 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
   bool write_normals, hipStream_t st, bool draw_offsets_done = false);
 int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hipStream_t st);
 int ball_counts(Ctx* c, int64_t S, hipStream_t st);  // d_nh of the last call's samples (agh_get_neighbor_counts)
-int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st);
+int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st,
+  int64_t* d_hdr_flags = nullptr);  // d_hdr_flags: sharded search, slices of at most 65536 samples (see shard.hip)
 int hog_svm(Ctx* c, int64_t n_hyp_cap, uint8_t* d_keep, hipStream_t st);
 int hog_images(Ctx* c, const uint32_t* d_images, const int32_t* d_order, int64_t n, float* d_desc, hipStream_t st);
 int svm_predict_general(Ctx* c, const float* d_desc, int64_t cap, uint8_t* d_keep, hipStream_t st);

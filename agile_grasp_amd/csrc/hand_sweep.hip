@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
 // one work-group scans the S popcounts (output offset of every sample, total count), then 10 threads copy each record
 // (16 bytes per thread, coalesced).
 __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restrict__ vmask, int S, int* __restrict__ offs,
-  int64_t* __restrict__ n_out)
+  int64_t* __restrict__ n_out, const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out)
 {
   // thread t owns the samples [t per, (t + 1) per), per a multiple of 16: its masks arrive as 16-byte loads, all in flight
   // together (one byte per load and iteration made this kernel 15 us for the 16 000 samples of a batch; the buffer is
@@ -972,7 +972,11 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restr
     total += ws[k];
   }
   if (tid == 0)
+  {
     *n_out = total;
+    if (hdr_flags_out)  // sharded search: this rank's "a neighbourhood beyond the launched capacity classes" travels in its
+      *hdr_flags_out = flags_in[0] & 1;  // segment header, so that every rank learns it from the same all-gather
+  }
 #pragma unroll
   for (int c = 0; c < 4; c++)
   {
@@ -1100,7 +1104,8 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
-int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st)
+int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, int64_t* d_nout, hipStream_t st,
+  int64_t* d_hdr_flags)
 {
   const int n = (int) (S * 8);
   const int nb = (n + 1023) / 1024;
@@ -1112,7 +1117,7 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
   if (S <= 65536)
   {
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
-      d_nout);
+      d_nout, (const int32_t*) c->d_flags, d_hdr_flags);
     hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
       (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch);
   }

@@ -230,10 +230,11 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
   if (threadIdx.x == 0)
   {
     int64_t o = 0;
-    int ov = 0;
+    int ov = 0, need = 0;
     for (int q = 0; q < G; q++)
     {
       int64_t cnt = *reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes);
+      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 1);
       if (cnt > seg_records)
       {
         ov = 1;
@@ -249,6 +250,8 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
       *n_out = o;
       if (ov)
         atomicOr(&flags[0], 16);
+      if (need)  // some rank met a neighbourhood beyond the capacity classes it launched: every rank reports it
+        atomicOr(&flags[0], 1);
       if (o > cap)
         atomicOr(&flags[0], 2);
     }
@@ -371,7 +374,6 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
     c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
     return AGH_ERR_HIP;
   }
-  c->big_classes = true;  // (no per-rank speculation about capacity classes: the ranks must run the same schedule)
   c->comm = new Comm();
   c->comm->rank = rank;
   c->comm->n_ranks = n_ranks;
@@ -396,7 +398,6 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
     cm->n_ranks = n_ranks;
     cm->local = g;
     ctxs[q]->c.comm = cm;
-    ctxs[q]->c.big_classes = true;
   }
   return AGH_OK;
 }
@@ -476,6 +477,8 @@ int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int
   const int64_t S = n_samples;
   const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = hi - lo;
   const int64_t Smax = (S + G - 1) / G;
+  if (Smax > 65536)  // the same on every rank: slices this long launch every capacity class from the start
+    c->big_classes = true;
   int64_t seg_records = std::min<int64_t>(8 * Smax, std::max<int64_t>(2 * Smax, 1024));
   if (c->shard_seg_override > 0)
     seg_records = std::min<int64_t>(8 * Smax, c->shard_seg_override);
@@ -593,15 +596,17 @@ int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int
       c->err = "hand sweep launch failed";
       return rc;
     }
+    if (Sr > 65536)  // (the compaction for long lists does not write the header flags: no speculation there, see below)
+      HIPCHK(c, hipMemsetAsync(my_count + 1, 0, sizeof(int64_t), st));
     // K4 straight into my segment of the exchange buffer; an overflow of the segment shows as count > seg_records
-    if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st)) != AGH_OK)
+    if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st, my_count + 1)) != AGH_OK)
     {
       c->err = "compaction launch failed";
       return rc;
     }
   }
   else
-    HIPCHK(c, hipMemsetAsync(my_count, 0, sizeof(int64_t), st));
+    HIPCHK(c, hipMemsetAsync(my_count, 0, 2 * sizeof(int64_t), st));  // count and header flags
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
     return rc;
   timing_mark(c, "shard_exchange", st);
@@ -641,6 +646,14 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
   HIPCHK(c, hipStreamSynchronize(st));
   if (flags[0] & 16)
     return 16;
+  if ((flags[0] & 1) && !c->big_classes)
+  {
+    // (every rank reads the same segment headers, so every rank lands here and switches together)
+    c->big_classes = true;
+    c->err = "a Taubin neighbourhood exceeds the first capacity class; the contexts of the communicator now launch the "
+             "larger classes as well: repeat the call";
+    return AGH_ERR_RETRY;
+  }
   if (flags[0] & 1)
   {
     c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity";
@@ -698,7 +711,7 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
   if (n_samples > 0)
     HIPCHK(c, hipMemcpyAsync(c->d_idx_own, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
   int64_t n = 0;
-  for (int attempt = 0; attempt < 2; attempt++)
+  for (int attempt = 0; attempt < 3; attempt++)  // (at most one repeat for the capacity classes, one for the segment size)
   {
     // (s_cap >= n_samples, so d_out_own holds the complete list: 8 slots per sample)
     rc = agh_find_hands_sharded_device(ctx, c->d_idx_own, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
@@ -709,6 +722,8 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
       return rc;
     }
     rc = shard_flags(c, c->stream, &n);
+    if (rc == AGH_ERR_RETRY)
+      continue;  // the larger capacity classes are on now, on every rank
     if (rc != 16)
       break;
     // a rank found more than its segment holds: every rank sees the same headers, so every rank repeats with 8 per sample

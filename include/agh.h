@@ -45,7 +45,8 @@ typedef enum agh_status
                                  * this input needs; it has switched itself (for good): repeat the call.  Two cases: a Taubin
                                  * neighbourhood beyond the first capacity class of the kernels (the launches of the larger
                                  * classes are skipped until a cloud needs them), and a rank that overflowed its exchange
-                                 * segment in a sharded search.  Host-buffer entry points repeat by themselves; the
+                                 * segment in a sharded search (both conditions reach every rank through the segment
+                                 * headers, so all ranks repeat together).  Host-buffer entry points repeat by themselves; the
                                  * asynchronous device variants report it at the next agh_synchronize. */
 } agh_status;
 
