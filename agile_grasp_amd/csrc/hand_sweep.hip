@@ -1023,6 +1023,81 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
     slot_of_hyp[pos] = slot;
 }
 
+// K4 in ONE launch for S <= 4096: every copy work-group (25 slots, i.e. at most five samples) sums the masks in front of its
+// first sample itself -- at most 4 KB out of L2, one 16-byte load per thread -- instead of waiting for an offsets kernel
+// (a launch costs ~4 us on this part, the redundant sums ~1).  The last work-group also knows the total.
+__global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __restrict__ slots,
+  const uint8_t* __restrict__ vmask, int S, int n_slots, agh_hypothesis* __restrict__ out, int64_t cap,
+  int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch, int64_t* __restrict__ n_out,
+  int64_t* __restrict__ hdr_flags_out)
+{
+  __shared__ int wsum[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s_first = (blockIdx.x * 25) >> 3;
+  const bool last_group = blockIdx.x == gridDim.x - 1;
+  auto popc_below = [&](const uint4& m, int base, int limit) -> int {  // masks of the samples base .. base + 15 below `limit`
+    const unsigned q[4] = { m.x, m.y, m.z, m.w };
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const int left = limit - (base + 4 * k);
+      const unsigned keep = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : (0xffffffffu >> (8 * (4 - left))));
+      c += __popc(q[k] & keep);
+    }
+    return c;
+  };
+  int before = 0, all = 0;
+  const int s_scan = last_group ? S : s_first;
+  for (int b = tid * 16; b < s_scan; b += 256 * 16)
+  {
+    const uint4 m = *reinterpret_cast<const uint4*>(vmask + b);  // (the buffer is 16 bytes longer than its samples)
+    before += popc_below(m, b, s_first);
+    if (last_group)
+      all += popc_below(m, b, S);
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    before += __shfl_xor(before, o);
+    all += __shfl_xor(all, o);
+  }
+  if (lane == 0)
+  {
+    wsum[0][w] = before;
+    wsum[1][w] = all;
+  }
+  __syncthreads();
+  before = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]);
+  if (last_group && tid == 0)
+  {
+    *n_out = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
+    if (hdr_flags_out)  // sharded search: see k_compact_offsets
+      *hdr_flags_out = flags[0] & 1;
+  }
+  const int slot = blockIdx.x * 25 + tid / 10, part = tid % 10;
+  if (tid >= 250 || slot >= n_slots)
+    return;
+  const int sm = slot >> 3, o = slot & 7;
+  const unsigned m = vmask[sm];
+  if (!((m >> o) & 1u))
+    return;
+  int64_t pos = before + __popc(m & ((1u << o) - 1u));
+  for (int q = s_first; q < sm; q++)  // (at most four samples)
+    pos += __popc((unsigned) vmask[q]);
+  if (pos >= cap)
+  {
+    if (part == 0)
+      atomicOr(&flags[0], 2);
+    return;
+  }
+  uint4 v = reinterpret_cast<const uint4*>(slots + slot)[part];
+  if (part == 9)
+    v.w = (unsigned) epoch;
+  reinterpret_cast<uint4*>(out + pos)[part] = v;
+  if (part == 0)
+    slot_of_hyp[pos] = slot;
+}
+
 // The number of points radiusSearch(sample, nn_radius_hands) returns (hand_search.cpp:147), for agh_get_neighbor_counts: a
 // lazy getter.  The sweep itself only visits the slab of the ball the hand can occupy, so it never sees this number.
 __global__ __launch_bounds__(256) void k_ball_count(GridView gv, const agh_frame* __restrict__ frames,
@@ -1114,7 +1189,10 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
     hipMemsetAsync(d_nout, 0, sizeof(int64_t), st);
     return AGH_OK;
   }
-  if (S <= 65536)
+  if (S <= 4096)
+    hipLaunchKernelGGL(k_compact_fused, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
+      (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags);
+  else if (S <= 65536)
   {
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
       d_nout, (const int32_t*) c->d_flags, d_hdr_flags);
