@@ -184,7 +184,8 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
         dist.barrier()
         torch.cuda.synchronize()
 
-    for attempt in range(2):
+    settle(ctx, step, fence)  # (capacity classes / segment size: every rank learns both from the segment headers)
+    for attempt in range(3):
         for _ in range(max(args.warmup, 3)):
             step()
         fence()
@@ -197,7 +198,7 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
             ctx.synchronize()
             break
         except binding.AghError as e:  # a segment overflowed: the context now exchanges full segments, measure again
-            if e.code != binding.AGH_ERR_RETRY or attempt == 1:
+            if e.code != binding.AGH_ERR_RETRY or attempt == 2:
                 raise
     tv = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tv, op=dist.ReduceOp.MAX)
