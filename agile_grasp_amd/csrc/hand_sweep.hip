@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   unsigned* const rmc = &img[0][0];
   __shared__ int cnt_crop, any_hand, pending, tile_end;
 
-  const int s = order[blockIdx.x];
+  // (work-groups in sample order: the caller's samples are spatially sorted, neighbouring work-groups share grid rows in L2,
+  // and since the gather only walks the hand's slab no weight known before the launch predicts a work-group's duration well
+  // enough to beat that -- longest-first by ball candidates: 104 us, by Taubin neighbours: 109, sample order: 102)
+  const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
   AGH_STAMP(0);

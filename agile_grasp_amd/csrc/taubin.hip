@@ -11,8 +11,7 @@
 //                          search's (d2, index) order, then the 37 distinct sums behind M and N accumulated
 //                          SEQUENTIALLY in that order (56-neighbour chunks: all four waves form the products, 37 lanes
 //                          run the 37 dependent add chains) -- the same fp64 operation order as the reference loop, so
-//                          the sums are bit-identical to the CPU path.  One wave also computes the sample's
-//                          scheduling weight for the kernels that follow.
+//                          the sums are bit-identical to the CPU path.
 //   k_taubin_eigen         four samples per wave, 9 lanes each: builds M, N, reduces the 10x10 pencil to the 9x9
 //                          symmetric-definite problem, Cholesky in LDS, round-robin Jacobi in registers without a
 //                          divergent branch (same rotation order and arithmetic as the CPU path), smallest eigenpair
@@ -42,7 +41,7 @@ template <int CAP>
 __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points, double rpad_w, int* __restrict__ weight, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud)
+  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud)
 {
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
@@ -73,8 +72,6 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     {
       status[s] = kStatusBadIndex;
       nt[s] = 0;
-      if (first_class)
-        weight[s] = 0;
     }
     return;
   }
@@ -85,36 +82,6 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     gv = grid_of_cloud(gv, cloud);
     if (first_class && tid == 0)
       scloud[s] = cloud;
-  }
-  // Scheduling weight of the sample for the kernels that follow (see k_taubin_eigen's sorter block): the candidate
-  // count of its hand-search ball, i.e. the row total k_hand_sweep's gather will walk.  One wave, <= 128 rows.
-  if (first_class && wave == 3)
-  {
-    const GridDesc& g = *gv.desc;
-    const int lx = cell_coord(g, (double) qx - rpad_w, 0), hx = cell_coord(g, (double) qx + rpad_w, 0);
-    const int ly = cell_coord(g, (double) qy - rpad_w, 1), hy = cell_coord(g, (double) qy + rpad_w, 1);
-    const int lz = cell_coord(g, (double) qz - rpad_w, 2), hz = cell_coord(g, (double) qz + rpad_w, 2);
-    const int ny = hy - ly + 1, nrw = ny * (hz - lz + 1);
-    int w = 0;
-    for (int t = lane; t < nrw && t < kMaxRows; t += 64)
-    {
-      const int cy = ly + t % ny, cz = lz + t / ny;
-      const double y0 = g.mn[1] + cy * g.cell, z0 = g.mn[2] + cz * g.cell;  // the row's chord, as build_rows clips it
-      const double dy = fmax(fmax(y0 - (double) qy, (double) qy - (y0 + g.cell)), 0.0);
-      const double dz = fmax(fmax(z0 - (double) qz, (double) qz - (z0 + g.cell)), 0.0);
-      const double rem = rpad_w * rpad_w - (dy * dy + dz * dz);
-      if (rem >= 0.0)
-      {
-        const double xr = sqrt(rem);
-        const int lxr = max(lx, cell_coord(g, (double) qx - xr, 0)), hxr = min(hx, cell_coord(g, (double) qx + xr, 0));
-        const int base = (cz * g.dim[1] + cy) * g.dim[0];
-        w += gv.cell_start[base + hxr + 1] - gv.cell_start[base + lxr];
-      }
-    }
-    for (int o = 32; o > 0; o >>= 1)
-      w += __shfl_xor(w, o);
-    if (lane == 0)
-      weight[s] = w;
   }
   if (tid == 0)
     count = 0;
@@ -636,12 +603,14 @@ struct EigSmem
   int fail;
 };
 
-// Longest-first scheduling of k_taubin_frame and k_hand_sweep: a sample's cost grows with its neighbourhood and the
+// Longest-first scheduling of k_taubin_frame: a sample's cost there grows with its Taubin neighbourhood n_t, and the
 // samples arrive sorted by index, i.e. spatially coherent, so dense regions form runs of slow work-groups and a run
 // that starts late is a long tail.  Work-groups are dispatched in blockIdx order; `order` maps blockIdx -> sample by
-// descending weight (counting sort, 2048 bins of 16 candidates).  It is computed by ONE EXTRA work-group of this
-// kernel: k_taubin_eigen leaves half the SIMDs idle, so the sort costs no time and no launch.  Results go to per-sample
-// slots, so the processing order (and the arbitrary order inside a bin) is invisible in the output.
+// descending n_t (counting sort, bins of 16 neighbours).  It is computed by ONE EXTRA work-group of this kernel:
+// k_taubin_eigen leaves half the SIMDs idle, so the sort costs no time and no launch.  Results go to per-sample slots, so
+// the processing order (and the arbitrary order inside a bin) is invisible in the output.  (k_hand_sweep used the same
+// scheme with the candidate count of the hand-search ball as weight until its gather was clipped to the hand's slab; it
+// now runs in sample order, see there.)
 constexpr int kOrderBins = 2048;
 __device__ __forceinline__ int order_bin(int w) { return kOrderBins - 1 - min(w >> 4, kOrderBins - 1); }  // 0 = heaviest
 
@@ -1517,7 +1486,6 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   GridView gv{ c->d_desc, c->d_cell_start, c->d_sorted, c->d_cloud_off, c->n_clouds };
   const float r2f = static_cast<float>(radius * radius);  // pcl::KdTreeFLANN::radiusSearch squares in double, casts
   const double rpad = radius * 1.0001 + 1e-6;
-  const double rpad_w = c->p.nn_radius_hands * 1.0001 + 1e-6;  // scheduling weight = candidates of the hand-search ball
   const int Si = (int) S;
   // capacity classes: smallest first; later classes only touch samples flagged kStatusOverflow
   const bool small_first = radius <= 0.015;
@@ -1527,7 +1495,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
       zf, c->d_scloud);
     zf = nullptr;
     first = false;
@@ -1537,11 +1505,11 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   // c->big_classes stays set).  Skipped classes leave kStatusOverflow behind, which k_taubin_eigen turns into the flag.
   if (first || c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
       zf, c->d_scloud);
   if (c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n, rpad_w, c->d_weight,
+      r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
       (int32_t*) nullptr, c->d_scloud);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
@@ -1556,10 +1524,10 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   const int eig_grid = eig_groups + (dofs ? 1 : 0);
   if (eig_groups <= 1024 || eig_groups > 2048)
     hipLaunchKernelGGL(k_taubin_eigen<true>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) c->d_weight, c->d_order, dofs, c->d_flags + 2);
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
   else
     hipLaunchKernelGGL(k_taubin_eigen<false>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) c->d_weight, c->d_order, dofs, c->d_flags + 2);
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
