@@ -298,6 +298,10 @@ int agh_classify_sharded(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64
 
 /* Introspection for parity tests / plotting (host buffers). */
 int agh_get_frames(agh_ctx* ctx, agh_frame* out, int64_t cap);
+/* Neighbour counts of the samples of the last call: n_taubin = points in the Taubin ball (hand_search.cpp:85), n_hands =
+ * points radiusSearch(sample, nn_radius_hands) returns (hand_search.cpp:147).  Either may be NULL.  n_hands is counted
+ * on demand (one extra kernel per call of this getter; the cloud of the search must still be set): the hand sweep itself
+ * only visits the slab of that ball the hand can occupy. */
 int agh_get_neighbor_counts(agh_ctx* ctx, int32_t* n_taubin, int32_t* n_hands, int64_t cap);
 int agh_get_images(agh_ctx* ctx, uint8_t* images, int64_t cap_hyp); /* cap_hyp x 8000 bytes, 80 rows x 100 cols */
 int agh_get_hog(agh_ctx* ctx, float* desc, double* sums, int64_t cap_hyp); /* cap_hyp x 3528 floats (+ SVM sums) */
