@@ -28,6 +28,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(binding.EXPORTS) == set(names)
 
 
+def test_status_codes_match_the_header():
+    """The Python side names two codes (callers of the asynchronous entry points repeat on AGH_ERR_RETRY): they must be the
+    header's, and the header's codes must be distinct."""
+    from agile_grasp_amd import binding
+
+    hdr = open(os.path.join(ROOT, "include", "agh.h")).read()
+    codes = dict((k, int(v)) for k, v in re.findall(r"\b(AGH_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", hdr))
+    assert codes["AGH_OK"] == 0 and len(set(codes.values())) == len(codes) >= 10
+    assert binding.AGH_ERR_RETRY == codes["AGH_ERR_RETRY"]
+
+
 def test_struct_layouts_match_the_header():
     from agile_grasp_amd import binding
 
