@@ -4,7 +4,9 @@ bench.py and for the CPU (gloo) tests.  The data path itself is C++ + RCCL: agh_
 Rank g of G takes the contiguous slice [g*S/G, (g+1)*S/G) of the sample list (agh_shard_slice) -- the reference's OpenMP
 loops run over independent samples (hand_search.cpp:77-80, 135-138), so the ranks' lists concatenated in rank order ARE
 the reference's sample-major list.  Each rank contributes one fixed-size segment
-``[160-byte header: int64 count | seg_records records of 160 B]`` to ONE in-place all-gather.
+``[160-byte header: int64 count, int64 flags | seg_records records of 160 B]`` to ONE in-place all-gather (flags bit 0: the
+rank met a Taubin neighbourhood beyond the capacity classes it had launched -- every rank then reports AGH_ERR_RETRY
+together; this host-side mirror leaves it zero).
 """
 from __future__ import annotations
 
