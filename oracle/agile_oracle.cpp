@@ -300,185 +300,290 @@ void jacobi_sym(double A[NN][NN], double V[NN][NN], double d[NN])
 }
 
 /* ---------------------------------------------------------------------------------------------------
- * Round-robin ("parallel order", Brent-Luk) Jacobi for the symmetric 9x9 matrix of the reduced Taubin problem.
- * Same rotations as jacobi_sym, but each sweep is organised in 9 rounds of 4 disjoint pairs
- * {(r+k) mod 9, (r-k) mod 9 : k = 1..4} (index r sits out); the four rotations of a round are computed from the
- * matrix at the start of the round and applied together: all column rotations (A <- A J), then all row rotations
- * (A <- J^T A), and the rotated off-diagonal entries (both triangles) are set to exactly 0.  Rotation parameters and
- * the convergence test read the upper triangle; the two triangles stay equal up to rounding.  Disjoint pairs touch disjoint columns / rows, so the order inside a phase is immaterial -- which is
- * what lets the GPU run a round with one lane per row.  Stands in for LAPACK dggev's QZ (quadric.cpp:330-363).
- * ------------------------------------------------------------------------------------------------- */
-void jacobi_rr9(double A[9][9], double V[9][9], double d[9])
-{
-  for (int i = 0; i < 9; i++)
-    for (int j = 0; j < 9; j++)
-      V[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 30; sweep++)
-  {
-    double off = 0.0;
-    for (int p = 0; p < 8; p++)
-      for (int q = p + 1; q < 9; q++)
-        off += A[p][q] * A[p][q];
-    if (off == 0.0)
-      break;
-    for (int r = 0; r < 9; r++)
-    {
-      int P[4], Q[4];
-      double C[4], S[4];
-      bool rot[4], zero[4];
-      for (int k = 1; k <= 4; k++)
-      {
-        const int a = (r + k) % 9, b = (r + 9 - k) % 9;
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        P[k - 1] = p;
-        Q[k - 1] = q;
-        const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
-        const double aabs = std::fabs(apq);
-        rot[k - 1] = false;
-        zero[k - 1] = false;
-        C[k - 1] = 1.0;
-        S[k - 1] = 0.0;
-        if (apq == 0.0)
-          continue;
-        if (sweep > 3 && (std::fabs(app) + aabs == std::fabs(app)) && (std::fabs(aqq) + aabs == std::fabs(aqq)))
-        {
-          zero[k - 1] = true;
-          continue;
-        }
-        /* The classical parameters theta = alpha / beta, t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)),
-         * c = 1 / sqrt(t^2 + 1), s = t c, written without the three chained divisions (same values in exact
-         * arithmetic, no cancellation: every sum is a sum of non-negative terms):
-         *   h = sqrt(alpha^2 + beta^2), d = |alpha| + h, r = sqrt(d^2 + beta^2), c = d / r, s = sgn |beta| / r.
-         * The dependent chain is sqrt, sqrt, div instead of div, sqrt, div, sqrt, div -- it is the critical path of
-         * the GPU kernel (one 16-lane group per sample). */
-        const double alpha = aqq - app, beta = 2.0 * apq;
-        const double h = std::sqrt(alpha * alpha + beta * beta);
-        const double dd = std::fabs(alpha) + h;
-        const double rr = std::sqrt(dd * dd + beta * beta);
-        if (!(rr > 0.0))  /* alpha^2 and beta^2 both underflowed: treat the entry as negligible */
-        {
-          zero[k - 1] = true;
-          continue;
-        }
-        const bool neg = (alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0);  /* theta < 0 */
-        const double sb = std::fabs(beta) / rr;
-        C[k - 1] = dd / rr;
-        S[k - 1] = neg ? -sb : sb;
-        rot[k - 1] = true;
-      }
-      for (int m = 0; m < 4; m++)  /* columns: A <- A J, V <- V J */
-        if (rot[m])
-          for (int k = 0; k < 9; k++)
-          {
-            const double akp = A[k][P[m]], akq = A[k][Q[m]];
-            A[k][P[m]] = C[m] * akp - S[m] * akq;
-            A[k][Q[m]] = S[m] * akp + C[m] * akq;
-            const double vkp = V[k][P[m]], vkq = V[k][Q[m]];
-            V[k][P[m]] = C[m] * vkp - S[m] * vkq;
-            V[k][Q[m]] = S[m] * vkp + C[m] * vkq;
-          }
-      for (int m = 0; m < 4; m++)  /* rows: A <- J^T A */
-        if (rot[m])
-          for (int k = 0; k < 9; k++)
-          {
-            const double apk = A[P[m]][k], aqk = A[Q[m]][k];
-            A[P[m]][k] = C[m] * apk - S[m] * aqk;
-            A[Q[m]][k] = S[m] * apk + C[m] * aqk;
-          }
-      for (int m = 0; m < 4; m++)
-        if (rot[m] || zero[m])
-        {
-          A[P[m]][Q[m]] = 0.0;
-          A[Q[m]][P[m]] = 0.0;
-        }
-    }
-  }
-  for (int i = 0; i < 9; i++)
-    d[i] = A[i][i];
-}
-
-/* ---------------------------------------------------------------------------------------------------
  * Quadric::solveGeneralizedEigenProblem + the eigenvalue selection of fitQuadric
  * (quadric.cpp:143-153, 330-363) -- dggev is THIRD PARTY.
- * N's 10th row/column is identically zero, so the pencil (M,N) has exactly one infinite eigenvalue and
- * the reference takes the smallest of "the first 9" = the smallest finite one (scipy/LAPACK places the
- * infinite one at index 9, see tests/golden).  Eliminating the 10th unknown (v10 = -b.v9/n) gives the
- * symmetric-definite 9x9 problem (A - b b^T/n) v = lambda N9 v, solved by Cholesky(N9) + round-robin Jacobi.
- * The eigenvector's sign and scale are arbitrary in both solvers and cancel downstream
- * (quadric.cpp:246-247 normalises, 294-301 re-orients).
- * Returns false if N9 is not positive definite (degenerate neighbourhood) -- the reference would carry
- * on with whatever dggev returned; here the sample is marked invalid and yields no hypotheses.
+ *
+ * What the reference asks of LAPACK: the eigenvector of M v = lambda N v that belongs to the smallest of "the first
+ * nine" eigenvalues.  N's 10th row/column is identically zero, so the pencil has one infinite eigenvalue, which
+ * LAPACK returns last (tests/golden); eliminating the 10th unknown (v10 = -b.v9/n) leaves the symmetric 9x9 problem
+ * S v = lambda N9 v with S = A - b b^T/n positive semi-definite and N9 = sum of gradient outer products.
+ *
+ * Only ONE eigenpair is used (quadric.cpp:150-153), so only one is computed:
+ *   1. Cholesky N9 = L L^T WITH DEFLATION (below);
+ *   2. C = L^-1 S L^-T;
+ *   3. Householder tridiagonalisation C = Q T Q^T;
+ *   4. the smallest eigenvalue of T by bisection on the Sturm sequence of T - x I (polynomial form, a fixed
+ *      number of halvings of the Gershgorin bracket; sigma = the lower end, so that T - sigma I stays positive);
+ *   5. its eigenvector from the twisted factorisation of T - sigma I (Fernando; Parlett & Dhillon): forward and
+ *      backward pivots, gamma_k = D+_k + D-_k - (d_k - sigma), z_k = 1 at the k with the smallest |gamma_k|;
+ *   6. v9 = L^-T Q z, v10 = -(b . v9)/n.
+ * Pinned against scipy's LAPACK dggev by tests/golden (taubin_dggev.npz, e2e_lapack.npz): direction within
+ * 4e-6 rad on regular pencils, which is dggev's own distance from itself when one input bit flips.
+ *
+ * RANK-DEFICIENT PENCILS.  A neighbourhood that lies exactly in one plane n.p = c -- the normal case for a table top
+ * or a box face voxelised on an axis-aligned 3 mm lattice (localization.cpp:247-355, launch/baxter_grasps.launch:4) --
+ * makes BOTH S and N9 annihilate w = (n.p - c)^2: the pencil is singular.  dggev does not notice; it returns three
+ * eigenvalues of size 1e-14 (the quadrics (n.p - c) * {1, x, y}-ish, which vanish on the plane) and an eigenvector
+ * from their span plus a multiple of w, the reference takes it (quadric.cpp:146-153, no validity test), and its
+ * gradients are +-n: a correct surface normal (measured: tests/golden/make_e2e_goldens.py).  Here: a Cholesky pivot
+ * that is not above 2^-40 of its diagonal entry (measured pivots: <= 4e-15 in magnitude on exactly planar patches,
+ * >= 7e-6 on everything else) DEFLATES its coordinate -- the row and column are dropped from both matrices, i.e.
+ * v_j = 0; since w_j != 0 at the failing pivot, every vector is (one with v_j = 0) + alpha w, and w contributes
+ * neither value nor gradient on the points, so the reduced problem has the reference's eigenvectors modulo w.  Its
+ * smallest eigenvalue is the (triple) zero, the vector some (n.p - c) * (linear form), the normals +-n.
+ * The in-plane direction of the curvature axis that follows (quadric.cpp:268-280: sum n n^T then has a double zero
+ * eigenvalue) is decided by rounding noise in the reference and is decided by rounding noise here: it is defined by
+ * this file's arithmetic and solver-dependent in the reference.
+ * Implementation of the deflation: row j of L := 0 and rinv_j = 0 instead of 1/L_jj -- every later use of index j
+ * is a product with one of them, so the coordinate drops out without a branch -- and C_jj = BIG keeps it out of the
+ * spectrum's low end.
+ * Returns false only for an empty neighbourhood (n = 0).
  * ------------------------------------------------------------------------------------------------- */
+static const double kDeflateTol = 0x1p-40; /* relative Cholesky pivot below which a coordinate is deflated */
+static const double kPivMin = 0x1p-500;    /* floor of |pivot| in the twisted factorisation */
+static const int kBisectSteps = 56;
+
+/* number of eigenvalues of the tridiagonal (d, e) below x: sign changes of the Sturm sequence
+ * p_0 = 1, p_1 = d_0 - x, p_i+1 = (d_i - x) p_i - e_i-1^2 p_i-1; a zero takes the sign opposite to its predecessor */
+static inline int sturm_count9(const double d[9], const double e2[8], double x)
+{
+  double pm2 = 1.0, pm1 = d[0] - x;
+  bool neg = (pm1 < 0.0) || (pm1 == 0.0);
+  int c = neg ? 1 : 0;
+  for (int i = 1; i < 9; i++)
+  {
+    const double pi = (d[i] - x) * pm1 - e2[i - 1] * pm2;
+    const bool ng = (pi < 0.0) || (pi == 0.0 && !neg);
+    if (ng != neg)
+      c++;
+    neg = ng;
+    pm2 = pm1;
+    pm1 = pi;
+  }
+  return c;
+}
+
+static inline double pivot_floor(double x)
+{
+  return (std::fabs(x) >= kPivMin) ? x : kPivMin;
+}
+
 bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], double* lambda)
 {
   const double n = M[9][9];
-  double S[9][9], L[9][9], Y[9][9], C[9][9];
   if (!(n > 0.0))
     return false;
+  double b[9], A[9][9], L[9][9], rinv[9];
+  bool defl[9];
   for (int i = 0; i < 9; i++)
-    for (int j = 0; j < 9; j++)
-      S[i][j] = M[i][j] - (M[i][9] * M[j][9]) / n;
-  /* Cholesky N9 = L L^T */
+    b[i] = M[i][9];
+  for (int i = 0; i < 9; i++)
+  {
+    const double ti = b[i] / n;
+    for (int j = 0; j <= i; j++)
+    {
+      A[i][j] = M[i][j] - ti * b[j];
+      A[j][i] = A[i][j];
+    }
+  }
+  /* 1. Cholesky with deflation */
   for (int i = 0; i < 9; i++)
     for (int j = 0; j < 9; j++)
       L[i][j] = 0.0;
   for (int j = 0; j < 9; j++)
   {
-    double sum = N[j][j];
+    double s = N[j][j];
     for (int k = 0; k < j; k++)
-      sum -= L[j][k] * L[j][k];
-    if (!(sum > 0.0))
-      return false;
-    const double ljj = std::sqrt(sum);
-    L[j][j] = ljj;
+      s -= L[j][k] * L[j][k];
+    if (s > kDeflateTol * N[j][j])
+    {
+      const double ljj = std::sqrt(s);
+      L[j][j] = ljj;
+      rinv[j] = 1.0 / ljj;
+      defl[j] = false;
+    }
+    else
+    {
+      for (int k = 0; k <= j; k++)
+        L[j][k] = 0.0;
+      rinv[j] = 0.0;
+      defl[j] = true;
+    }
     for (int i = j + 1; i < 9; i++)
     {
       double s2 = N[i][j];
       for (int k = 0; k < j; k++)
         s2 -= L[i][k] * L[j][k];
-      L[i][j] = s2 / ljj;
+      L[i][j] = s2 * rinv[j];
     }
   }
-  /* Y = L^-1 S */
-  for (int j = 0; j < 9; j++)
-    for (int i = 0; i < 9; i++)
-    {
-      double s2 = S[i][j];
-      for (int k = 0; k < i; k++)
-        s2 -= L[i][k] * Y[k][j];
-      Y[i][j] = s2 / L[i][i];
-    }
-  /* C = Y L^-T, lower triangle mirrored so that C is exactly symmetric */
+  /* 2. C = L^-1 A L^-T in place on the lower triangle (the unblocked LAPACK dsygs2 scheme, itype 1, lower), mirrored */
+  double C[9][9];
   for (int i = 0; i < 9; i++)
     for (int j = 0; j < 9; j++)
+      C[i][j] = A[i][j];
+  for (int k = 0; k < 9; k++)
+  {
+    const double akk = (C[k][k] * rinv[k]) * rinv[k];
+    C[k][k] = akk;
+    const double ct = -0.5 * akk;
+    for (int i = k + 1; i < 9; i++)
+      C[i][k] = C[i][k] * rinv[k] + ct * L[i][k];
+    for (int i = k + 1; i < 9; i++)
+      for (int j = k + 1; j <= i; j++)
+        C[i][j] = (C[i][j] - C[i][k] * L[j][k]) - L[i][k] * C[j][k];
+    for (int i = k + 1; i < 9; i++)
+      C[i][k] = C[i][k] + ct * L[i][k];
+    for (int i = k + 1; i < 9; i++)
     {
-      double s2 = Y[i][j];
-      for (int k = 0; k < j; k++)
-        s2 -= C[i][k] * L[j][k];
-      C[i][j] = s2 / L[j][j];
+      double s2 = C[i][k];
+      for (int m = k + 1; m < i; m++)
+        s2 -= L[i][m] * C[m][k];
+      C[i][k] = s2 * rinv[i];
     }
+  }
   for (int i = 0; i < 9; i++)
     for (int j = i + 1; j < 9; j++)
       C[i][j] = C[j][i];
-  double V[9][9], d[9];
-  jacobi_rr9(C, V, d);
-  int mi = 0;
-  for (int i = 1; i < 9; i++)
-    if (d[i] < d[mi])
-      mi = i;
-  /* v9 = L^-T y */
+  double tr = 0.0;
+  for (int i = 0; i < 9; i++)
+    tr += std::fabs(C[i][i]);
+  const double big = 2.0 * tr + 1.0;
+  for (int j = 0; j < 9; j++)
+    if (defl[j])
+      C[j][j] = big;
+  /* 3. Householder tridiagonalisation (reflector k zeroes column k below the sub-diagonal; H_k = I - u u^T / h) */
+  double U[7][9], RH[7], e[8], d[9], e2[8];
+  for (int k = 0; k < 7; k++)
+  {
+    double sg = 0.0;
+    for (int i = k + 1; i < 9; i++)
+      sg += C[i][k] * C[i][k];
+    const double x0 = C[k + 1][k];
+    const double rt = std::sqrt(sg);
+    const double g = (x0 >= 0.0) ? -rt : rt;
+    const double h = sg - x0 * g;
+    const bool live = h > 0.0;
+    const double rh = live ? 1.0 / h : 0.0;
+    double u[9], p[9], q[9];
+    for (int i = 0; i < 9; i++)
+      u[i] = 0.0;
+    if (live)
+    {
+      for (int i = k + 1; i < 9; i++)
+        u[i] = C[i][k];
+      u[k + 1] = x0 - g;
+    }
+    for (int i = 0; i < 9; i++)
+      U[k][i] = u[i];
+    RH[k] = rh;
+    e[k] = live ? g : x0;
+    for (int i = k + 1; i < 9; i++)
+    {
+      double s2 = 0.0;
+      for (int j = k + 1; j < 9; j++)
+        s2 += C[i][j] * u[j];
+      p[i] = s2 * rh;
+    }
+    double kk = 0.0;
+    for (int i = k + 1; i < 9; i++)
+      kk += u[i] * p[i];
+    kk = (kk * rh) * 0.5;
+    for (int i = k + 1; i < 9; i++)
+      q[i] = p[i] - kk * u[i];
+    for (int i = k + 1; i < 9; i++)
+      for (int j = k + 1; j <= i; j++)
+      {
+        C[i][j] = (C[i][j] - u[i] * q[j]) - q[i] * u[j];
+        C[j][i] = C[i][j];
+      }
+  }
+  e[7] = C[8][7];
+  for (int i = 0; i < 9; i++)
+    d[i] = C[i][i];
+  for (int i = 0; i < 8; i++)
+    e2[i] = e[i] * e[i];
+  /* 4. bisection: lambda_min lies in [min_i (d_i - |e_i-1| - |e_i|), min_i d_i] (deflated coordinates excluded) */
+  double lo = 0.0, hi = 0.0;
+  bool first = true;
+  for (int i = 0; i < 9; i++)
+  {
+    if (defl[i])
+      continue;
+    const double r = ((i > 0) ? std::fabs(e[i - 1]) : 0.0) + ((i < 8) ? std::fabs(e[i]) : 0.0);
+    const double g0 = d[i] - r;
+    if (first || g0 < lo)
+      lo = g0;
+    if (first || d[i] < hi)
+      hi = d[i];
+    first = false;
+  }
+  for (int it = 0; it < kBisectSteps; it++)
+  {
+    const double mid = lo + (hi - lo) * 0.5;
+    if (sturm_count9(d, e2, mid) >= 1)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  const double sigma = lo;
+  /* 5. twisted factorisation of T - sigma I */
+  double Dp[9], Dm[9], lf[8], ub[8];
+  Dp[0] = pivot_floor(d[0] - sigma);
+  for (int i = 0; i < 8; i++)
+  {
+    lf[i] = e[i] / Dp[i];
+    Dp[i + 1] = pivot_floor((d[i + 1] - sigma) - lf[i] * e[i]);
+  }
+  Dm[8] = pivot_floor(d[8] - sigma);
+  for (int i = 7; i >= 0; i--)
+  {
+    ub[i] = e[i] / Dm[i + 1];
+    Dm[i] = pivot_floor((d[i] - sigma) - ub[i] * e[i]);
+  }
+  int ks = -1;
+  double gmin = 0.0;
+  for (int k = 0; k < 9; k++)
+  {
+    if (defl[k])
+      continue;
+    const double gk = std::fabs((Dp[k] + Dm[k]) - (d[k] - sigma));
+    if (ks < 0 || gk < gmin)
+    {
+      ks = k;
+      gmin = gk;
+    }
+  }
+  double z[9];
+  for (int i = 0; i < 9; i++)
+    z[i] = 0.0;
+  z[ks] = 1.0;
+  for (int i = ks - 1; i >= 0; i--)
+    z[i] = -(lf[i] * z[i + 1]);
+  for (int i = ks; i < 8; i++)
+    z[i + 1] = -(ub[i] * z[i]);
+  /* 6. y = H_0 ... H_6 z, v9 = L^-T y, v10 */
+  for (int k = 6; k >= 0; k--)
+  {
+    double s2 = 0.0;
+    for (int i = k + 1; i < 9; i++)
+      s2 += U[k][i] * z[i];
+    s2 = s2 * RH[k];
+    for (int i = k + 1; i < 9; i++)
+      z[i] = z[i] - s2 * U[k][i];
+  }
   for (int i = 8; i >= 0; i--)
   {
-    double s2 = V[i][mi];
+    double s2 = z[i];
     for (int k = i + 1; k < 9; k++)
       s2 -= L[k][i] * v[k];
-    v[i] = s2 / L[i][i];
+    v[i] = s2 * rinv[i];
   }
   double bv = 0.0;
   for (int k = 0; k < 9; k++)
-    bv += M[k][9] * v[k];
-  v[9] = -bv / n;
-  *lambda = d[mi];
+    bv += b[k] * v[k];
+  v[9] = -(bv / n);
+  *lambda = sigma;
   return true;
 }
 

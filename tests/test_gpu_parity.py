@@ -207,7 +207,7 @@ def test_edge_cases(tiny_scene):
     ctx.set_cloud(np.array([[0.5, 0.0, 0.0], [2.0, 2.0, 2.0]], np.float32), np.zeros(2, np.int32))
     assert len(ctx.find_hands(np.array([0, 1], np.int32))) == 0
     fr = ctx.frames()
-    assert (fr["valid"] == 0).all() and list(fr["n_nb"]) == [1, 1]
+    assert (fr["valid"] == 1).all() and list(fr["n_nb"]) == [1, 1]  # under-determined fits still yield a frame
     # duplicate samples are independent work items
     ctx.set_cloud(sc.xyz, sc.cam)
     s = np.array([sc.samples[3]] * 3, np.int32)
@@ -231,7 +231,7 @@ def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
     elif kind == "lattice_plane":
         g = np.arange(-0.06, 0.06, 0.003)
         u, v = np.meshgrid(g, g, indexing="ij")
-        xyz = c0 + np.stack([u.ravel(), v.ravel(), np.zeros(u.size)], 1)  # exactly planar: N9 singular -> invalid frames
+        xyz = c0 + np.stack([u.ravel(), v.ravel(), np.zeros(u.size)], 1)  # exactly planar: singular pencil, deflated -> frames with the plane's normal
     elif kind == "collinear":
         t = np.linspace(-0.08, 0.08, 300)
         xyz = np.concatenate([c0 + np.stack([t, 0 * t, 0 * t], 1), c0 + rng.uniform(-0.02, 0.02, (40, 3))])
