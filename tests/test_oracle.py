@@ -83,8 +83,10 @@ def test_underdetermined_neighbourhood_still_yields_a_frame():
     fr = O.fit_frames(p, xyz, cam, np.array([0], np.int32), 0.03)
     assert fr["valid"][0] == 1 and fr["n_nb"][0] == 1
     assert np.isfinite(fr["normal"][0]).all() and abs(np.linalg.norm(fr["normal"][0]) - 1) < 1e-12
+    # (with a finite frame the sweep then "grasps" the lone point -- finger_hand.cpp only asks for one point between the
+    # fingers; what dggev returns for such a pencil, finite or NaN, is solver noise in the reference)
     r = O.find_hands(p, xyz, cam, np.array([0], np.int32))
-    assert len(r["hyps"]) == 0
+    assert (r["hyps"]["sample"] == 0).all()
 
 
 def test_pow6_libm_switch_keeps_argmax(tiny_scene):
