@@ -19,7 +19,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, "csrc", f) for f in SRC + ["agh_internal.h"]] + [os.path.join(ROOT, "include", "agh.h")]
+    deps = [os.path.join(HERE, "csrc", f) for f in SRC + ["agh_internal.h", "taubin_eigen.h"]] + [os.path.join(ROOT, "include", "agh.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -25,6 +25,8 @@
 
 #include <utility>
 
+#include "taubin_eigen.h"
+
 namespace agh
 {
 
@@ -350,259 +352,19 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1b: quadric.cpp:134-153 + solveGeneralizedEigenProblem (330-363) as a 9x9 symmetric-definite reduction.
-// 4 samples per 64-thread workgroup, 16 lanes per sample (9 active).  Mirrors oracle solve_taubin()/jacobi_sym<9>.
+// K1b: quadric.cpp:134-153 + solveGeneralizedEigenProblem (330-363): the ONE eigenpair the reference uses of
+// M v = lambda N v (the smallest of "the first nine"), by the scheme the oracle states (solve_taubin): elimination of
+// the 10th unknown, Cholesky of N9 with deflation of rank-deficient coordinates, in-place reduction C = L^-1 S L^-T,
+// Householder tridiagonalisation, bisection on the Sturm sequence, twisted factorisation, back-transformation.
+//
+// ONE SAMPLE PER LANE.  The solve is a chain of ~4000 dependent-ish fp64 operations on a 9 x 9 matrix; spreading one
+// matrix over lanes (round 2: nine lanes per sample, DPP broadcasts) bought a 4x shorter chain at 16x the instruction
+// count, and left 63 of 64 lanes idle in the scalar phases.  With a sample per lane every instruction does 64 samples'
+// work, every index is a compile-time constant (the matrices live in registers: <= 256 VGPRs), there is no LDS and no
+// cross-lane traffic, and the arithmetic is the oracle's loop nest verbatim -- the same roundings by construction.
+// 2000 samples are 32 waves; the kernel's time is one lane's chain, whatever the sample count (until the waves outnumber
+// the SIMDs several times over: the 300 000 samples of the all-points pass are 4688 waves).
 // ---------------------------------------------------------------------------------------------------------------
-// One round of the round-robin Jacobi: the four disjoint pairs {(R+k) mod 9, (R-k) mod 9}, k = 1..4 (index R sits out).
-__device__ __forceinline__ double shfl16(double v, int src_in_group, int gbase)
-{
-  return __shfl(v, gbase + src_in_group);
-}
-
-// The row exchange of a Jacobi round as DPP moves.  In round R lane i (row i of its 16-lane group) needs the value of lane
-// (C - i) mod 9, C = 2 R mod 9: a reflection of the lanes [0, C] and a reflection of the lanes [C + 1, 8].  With
-// t = row_mirror(x) (t[i] = x[15 - i]), row_shl:(15 - C) of t is the first reflection (exactly the lanes i <= C have an
-// in-row source, the others keep `old`), and row_shl:(6 - C) / row_shr:(C - 6) of t is the second, which goes in as `old`.
-// C = 7 is row_half_mirror on the lanes 0..7.  One to three DPP moves per 32-bit half instead of a ds_bpermute and its
-// wait: the 18 permutes per round were where the wave stood waiting for LDS, 28 % of its cycles.  (64-bit DPP exists for
-// row_newbcast only.)  Lanes 9..15 receive don't-care values, as they hold don't-care rows.
-template <int C>
-__device__ __forceinline__ int mate16_half(int x)
-{
-  constexpr int kMirror = 0x140, kHalfMirror = 0x141, kShl = 0x100, kShr = 0x110;
-  if (C == 7)
-    return __builtin_amdgcn_update_dpp(x, x, kHalfMirror, 0xf, 0x3, false);  // banks 0, 1 = lanes 0..7; lane 8 keeps x
-  const int t = __builtin_amdgcn_update_dpp(0, x, kMirror, 0xf, 0xf, true);
-  if (C == 8)
-    return __builtin_amdgcn_update_dpp(0, t, kShl + 7, 0xf, 0xf, true);
-  constexpr int k2 = 6 - C;
-  int u2 = t;
-  if (k2 > 0)
-    u2 = __builtin_amdgcn_update_dpp(0, t, kShl + (k2 > 0 ? k2 : 1), 0xf, 0xf, true);
-  // (k2 < 0 cannot happen here: C = 7 and C = 8 returned above)
-  return __builtin_amdgcn_update_dpp(u2, t, kShl + (15 - C), 0xf, 0xf, false);
-}
-template <int C>
-__device__ __forceinline__ double mate16(double v)
-{
-  return __hiloint2double(mate16_half<C>(__double2hiint(v)), mate16_half<C>(__double2loint(v)));
-}
-
-// Lane N of every 16-lane row to all lanes of that row: one DPP move per 32-bit half (row_newbcast, gfx90a+), no LDS
-// crossbar and no wait.  The 16-lane groups of k_taubin_eigen are exactly the DPP rows.
-template <int N>
-__device__ __forceinline__ double bcast16(double v)
-{
-  // one v_mov_b64_dpp: gfx90a+ carries 64-bit operands through DPP for row_newbcast (two 32-bit moves otherwise)
-#if defined(__HIP_DEVICE_COMPILE__)
-  const long long x = __builtin_bit_cast(long long, v);
-  const long long y = __builtin_amdgcn_update_dpp((long long) 0, x, 0x150 + N, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, y);
-#else
-  return v;  // (host pass of the single-source compile: the 64-bit form of the builtin only exists for the device)
-#endif
-}
-template <int N>
-__device__ __forceinline__ int bcast16(int v)
-{
-  return __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xf, 0xf, true);
-}
-
-// One round of the round-robin Jacobi sweep (oracle jacobi_rr9).  The wave runs it with all lanes enabled and without
-// a single divergent branch: the kernel is bound by the instructions one wave issues (one wave per SIMD, four samples
-// per wave), so conditional updates are selects and the broadcasts inside a group are DPP moves.
-template <int R, int K>
-struct RrPair  // pair K (1..4) of round R: rows (R + K) mod 9 and (R - K) mod 9, p < q
-{
-  static constexpr int a = (R + K) % 9, b = (R + 9 - K) % 9;
-  static constexpr int p = a < b ? a : b, q = a < b ? b : a;
-};
-
-template <int R, int K>
-__device__ __forceinline__ void rr_gather(const double (&ar)[9], int kk, double& apq, double& app, double& aqq)
-{
-  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
-  const double x_pq = bcast16<p>(ar[q]), x_pp = bcast16<p>(ar[p]), x_qq = bcast16<q>(ar[q]);
-  const bool mine = kk == K;
-  apq = mine ? x_pq : apq;
-  app = mine ? x_pp : app;
-  aqq = mine ? x_qq : aqq;
-}
-
-// A pair that is not rotated carries the identity (c = 1, s = 0), and applying it is exact: 1 * x - 0 * y = x bit for bit
-// for every finite x, y except x = -0 with y < 0 -- and these matrices never hold a negative zero (they are built from
-// sums that start at +0, quotients by positive pivots, and entries that are cleared to +0).  So the column and row phases
-// carry no selects: a fifth of the sweep's instructions were v_cndmask pairs guarding updates that are no-ops anyway.
-template <int R, int K>
-__device__ __forceinline__ void rr_columns(double (&ar)[9], double (&vr)[9], double c, double sn)
-{
-  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
-  const double ck = bcast16<p>(c), sk = bcast16<p>(sn);
-  const double akp = ar[p], akq = ar[q];
-  ar[p] = ck * akp - sk * akq;
-  ar[q] = sk * akp + ck * akq;
-  const double vkp = vr[p], vkq = vr[q];
-  vr[p] = ck * vkp - sk * vkq;
-  vr[q] = sk * vkp + ck * vkq;
-}
-
-template <int R, int K>
-__device__ __forceinline__ void rr_zero(double (&ar)[9], int kk, int gl, bool zero_it)
-{
-  constexpr int p = RrPair<R, K>::p, q = RrPair<R, K>::q;
-  const bool mine = zero_it && kk == K;
-  ar[q] = (mine && gl == p) ? 0.0 : ar[q];
-  ar[p] = (mine && gl == q) ? 0.0 : ar[p];
-}
-
-// Would the sweep ROTATE the pair (gl, J) of this lane's row (upper triangle)?  Mirrors the per-pair tests of jacobi_rr9.
-template <int J>
-__device__ __forceinline__ bool rr_needs_rotation(const double (&ar)[9], int gl, bool row, int sweep, double dg)
-{
-  const double ajj = bcast16<J>(ar[J]);  // a_JJ lives in lane J
-  const double v = ar[J], av = fabs(v);
-  const bool negl = sweep > 3 && (fabs(dg) + av == fabs(dg)) && (fabs(ajj) + av == fabs(ajj));
-  return row && J > gl && v != 0.0 && !negl;
-}
-
-// LAT: the build for launches of at most one wave per SIMD, where the kernel's duration is one wave's latency chain --
-// branch-free predicates (a short-circuit is a branch at the end of every round, and the basic-block boundary keeps the
-// compiler from starting the next round's parameter chain under this round's row phase) and the row exchange as DPP moves
-// (no LDS wait).  It issues a fifth more instructions, so the plain build stays for launches with two waves per SIMD.
-template <int R, bool LAT>
-__device__ __forceinline__ void jacobi_round(double (&ar)[9], double (&vr)[9], int gl, int gbase, bool row, bool active,
-  int sweep)
-{
-  // lane roles in round R: pair id kk (1..4, 0: sits out / idle lane), the pair's other row, and which of the two
-  const int dd = row ? (gl - R + 9) % 9 : 0;
-  const int kk = dd <= 4 ? dd : 9 - dd;
-  const int mate = (kk != 0) ? (2 * R - gl + 18) % 9 : gl;
-  const bool is_p = gl < mate;
-  // (1) (a_pq, a_pp, a_qq) of this lane's pair, read from the lane that owns row p (upper triangle) / row q
-  double apq = 0.0, app = 0.0, aqq = 0.0;
-  rr_gather<R, 1>(ar, kk, apq, app, aqq);
-  rr_gather<R, 2>(ar, kk, apq, app, aqq);
-  rr_gather<R, 3>(ar, kk, apq, app, aqq);
-  rr_gather<R, 4>(ar, kk, apq, app, aqq);
-  // (2) rotation parameters (both lanes of a pair compute the same values); lanes without a rotation get the
-  //     identity and never use it
-  const double aabs = fabs(apq);
-  bool cand, negligible;
-  if (LAT)
-  {
-    cand = active & (kk != 0) & (apq != 0.0);
-    negligible = (sweep > 3) & (fabs(app) + aabs == fabs(app)) & (fabs(aqq) + aabs == fabs(aqq));
-  }
-  else
-  {
-    cand = active && kk != 0 && apq != 0.0;
-    negligible = sweep > 3 && (fabs(app) + aabs == fabs(app)) && (fabs(aqq) + aabs == fabs(aqq));
-  }
-  // oracle jacobi_rr9: h = sqrt(alpha^2 + beta^2), d = |alpha| + h, r = sqrt(d^2 + beta^2), c = d / r,
-  // s = sgn |beta| / r
-  const double alpha = aqq - app, beta = 2.0 * apq;
-  const double h = sqrt(alpha * alpha + beta * beta);
-  const double dsum = fabs(alpha) + h;
-  const double rr = sqrt(dsum * dsum + beta * beta);
-  const bool rot = LAT ? (cand & !negligible & (rr > 0.0)) : (cand && !negligible && rr > 0.0);
-  const bool neg = LAT ? (((alpha < 0.0) & (beta > 0.0)) | ((alpha > 0.0) & (beta < 0.0)))
-                       : ((alpha < 0.0 && beta > 0.0) || (alpha > 0.0 && beta < 0.0));
-  const double rsafe = rot ? rr : 1.0;
-  const double sb = fabs(beta) / rsafe;
-  const double c = rot ? dsum / rsafe : 1.0;
-  const double sn = rot ? (neg ? -sb : sb) : 0.0;
-  const int flag = rot ? 1 : (cand ? 2 : 0);  // 1 rotate, 2 zero only
-  // (3) column phase A <- A J, V <- V J: this lane's row, all four pairs (parameters from the pair's first lane)
-  rr_columns<R, 1>(ar, vr, c, sn);
-  rr_columns<R, 2>(ar, vr, c, sn);
-  rr_columns<R, 3>(ar, vr, c, sn);
-  rr_columns<R, 4>(ar, vr, c, sn);
-  // (4) row phase A <- J^T A: rows p and q of a pair are the two lanes of the pair; each fetches its mate's row.
-  //     Row p: c a_p - s a_q; row q: s a_p + c a_q = c a_q - (-s) a_p (IEEE addition commutes).
-  const double se = is_p ? sn : -sn;
-#pragma unroll
-  for (int j = 0; j < 9; j++)
-  {
-    const double own = ar[j];
-    const double other = LAT ? mate16<(2 * R) % 9>(own) : shfl16(own, mate, gbase);
-    ar[j] = c * own - se * other;  // (identity for a lane whose pair does not rotate, see rr_columns)
-  }
-  // (5) the rotated entries are exactly zero (both triangles)
-  const bool zero_it = flag != 0;
-  rr_zero<R, 1>(ar, kk, gl, zero_it);
-  rr_zero<R, 2>(ar, kk, gl, zero_it);
-  rr_zero<R, 3>(ar, kk, gl, zero_it);
-  rr_zero<R, 4>(ar, kk, gl, zero_it);
-}
-
-// ---- the reduction M v = lambda N v -> C y = lambda y (Cholesky N9 = L L^T, Y = L^-1 S, C = Y L^-T) with the matrices in
-// registers: lane gl of a 16-lane group holds row gl of N9, of L and of C, and column gl of S (= row gl: S is symmetric
-// bit for bit) and of Y.  Every dot product runs in the index order of the oracle's loops; an operand that belongs to
-// another row arrives by a DPP row broadcast, so the chains carry no LDS round trips.
-template <int J, int... K>
-__device__ __forceinline__ double chol_dot(double t, const double (&lrow)[9], std::integer_sequence<int, K...>)
-{
-  ((t -= lrow[K] * bcast16<J>(lrow[K])), ...);  // t -= L[i][k] * L[J][k], k = 0 .. J-1 in order
-  return t;
-}
-template <int J>
-__device__ __forceinline__ void chol_step(const double (&nrow)[9], double (&lrow)[9], int gl, int& fail)
-{
-  const double t = chol_dot<J>(nrow[J], lrow, std::make_integer_sequence<int, J>{});
-  const bool mine = gl == J;
-  const bool bad = mine && !(t > 0.0);  // N9 not positive definite: no frame (the sample is dropped loudly downstream)
-  fail |= bcast16<J>(bad ? 1 : 0);
-  const double ljj = bcast16<J>(sqrt((mine && !bad) ? t : 1.0));
-  lrow[J] = mine ? ljj : (gl > J ? t / ljj : 0.0);
-}
-template <int R, int... K>
-__device__ __forceinline__ double ysolve_dot(double t, const double (&lrow)[9], const double (&ycol)[9], std::integer_sequence<int, K...>)
-{
-  ((t -= bcast16<R>(lrow[K]) * ycol[K]), ...);  // t -= L[R][k] * Y[k][j]
-  return t;
-}
-template <int R>
-__device__ __forceinline__ void ysolve_step(const double (&srow)[9], const double (&lrow)[9], double (&ycol)[9])
-{
-  const double t = ysolve_dot<R>(srow[R], lrow, ycol, std::make_integer_sequence<int, R>{});
-  ycol[R] = t / bcast16<R>(lrow[R]);
-}
-template <int J, int... K>
-__device__ __forceinline__ double csolve_dot(double t, const double (&lrow)[9], const double (&crow)[9], std::integer_sequence<int, K...>)
-{
-  ((t -= crow[K] * bcast16<J>(lrow[K])), ...);  // t -= C[i][k] * L[J][k]
-  return t;
-}
-template <int J>
-__device__ __forceinline__ void csolve_step(const double (&yrow)[9], const double (&lrow)[9], double (&crow)[9])
-{
-  const double t = csolve_dot<J>(yrow[J], lrow, crow, std::make_integer_sequence<int, J>{});
-  crow[J] = t / bcast16<J>(lrow[J]);
-}
-
-// One sample's LDS.  M and N are read once, into registers, before anything writes A, L, Y or V (a work-group is one
-// wave: program order is enough), so the two sets share their bytes: 2.6 KB per sample, 10.4 KB per work-group.
-struct EigSmem
-{
-  union
-  {
-    struct
-    {
-      double M[10][10];
-      double N[10][10];
-    };
-    struct
-    {
-      double A[9][9];  // C, then the eigenvalues on its diagonal
-      double L[9][9];
-      double Y[9][9];
-      double V[9][9];
-    };
-  };
-  double m[9];  // M[k][9], k < 9: needed once more at the very end (the eliminated 10th unknown)
-  int fail;
-};
-
 // Longest-first scheduling of k_taubin_frame: a sample's cost there grows with its Taubin neighbourhood n_t, and the
 // samples arrive sorted by index, i.e. spatially coherent, so dense regions form runs of slow work-groups and a run
 // that starts late is a long tail.  Work-groups are dispatched in blockIdx order; `order` maps blockIdx -> sample by
@@ -614,23 +376,24 @@ struct EigSmem
 constexpr int kOrderBins = 2048;
 __device__ __forceinline__ int order_bin(int w) { return kOrderBins - 1 - min(w >> 4, kOrderBins - 1); }  // 0 = heaviest
 
-__device__ void sample_order_block(const int* __restrict__ weight, int S, int* __restrict__ order, int* hist)
+__device__ void sample_order_block(const int* __restrict__ weight, int S, int* __restrict__ order, int* hist, int* wave_tot)
 {
-  // One wave walks the S weights twice.  Every step of the walk is a global-load round trip, so a lane takes kPer weights
-  // per step with all its loads in flight together (one weight per step took 2 x S / 64 round trips: 140 us at S = 8000,
-  // twice what the eigen solves beside it need -- the sorter WAS k_taubin_eigen's duration at C4 and in the batch).
-  constexpr int kPer = 16;
-  const int lane = threadIdx.x;  // 64 threads
-  for (int b = lane; b < kOrderBins; b += 64)
+  // One work-group of 256 threads walks the S weights twice.  Every step of the walk is a global-load round trip, so a
+  // thread takes kPer weights per step with all its loads in flight together (one weight per step and one wave took
+  // 2 x S / 64 round trips: 140 us at S = 8000 -- the sorter WAS k_taubin_eigen's duration at C4 and in the batch; with
+  // the solver at 10 us it was again, at 61 us, until the walk got four waves).
+  constexpr int kPer = 16, kT = 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < kOrderBins; b += kT)
     hist[b] = 0;
   __syncthreads();
-  for (int base = 0; base < S; base += 64 * kPer)
+  for (int base = 0; base < S; base += kT * kPer)
   {
     int bin[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; u++)
     {
-      const int s = base + u * 64 + lane;
+      const int s = base + u * kT + tid;
       bin[u] = s < S ? order_bin(weight[s]) : -1;
     }
 #pragma unroll
@@ -639,10 +402,10 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
         atomicAdd(&hist[bin[u]], 1);
   }
   __syncthreads();
-  constexpr int per = kOrderBins / 64;  // consecutive bins per lane
+  constexpr int per = kOrderBins / kT;  // consecutive bins per thread
   int loc = 0;
   for (int k = 0; k < per; k++)
-    loc += hist[lane * per + k];
+    loc += hist[tid * per + k];
   int incl = loc;
   for (int o = 1; o < 64; o <<= 1)
   {
@@ -650,21 +413,26 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
     if (lane >= o)
       incl += y;
   }
+  if (lane == 63)
+    wave_tot[wave] = incl;
+  __syncthreads();
   int run = incl - loc;
+  for (int w = 0; w < wave; w++)
+    run += wave_tot[w];
   for (int k = 0; k < per; k++)
   {
-    const int c = hist[lane * per + k];
-    hist[lane * per + k] = run;
+    const int c = hist[tid * per + k];
+    hist[tid * per + k] = run;
     run += c;
   }
   __syncthreads();
-  for (int base = 0; base < S; base += 64 * kPer)
+  for (int base = 0; base < S; base += kT * kPer)
   {
     int bin[kPer], pos[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; u++)
     {
-      const int s = base + u * 64 + lane;
+      const int s = base + u * kT + tid;
       bin[u] = s < S ? order_bin(weight[s]) : -1;
     }
 #pragma unroll
@@ -673,7 +441,7 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
 #pragma unroll
     for (int u = 0; u < kPer; u++)
       if (bin[u] >= 0)
-        order[pos[u]] = base + u * 64 + lane;
+        order[pos[u]] = base + u * kT + tid;
   }
 }
 
@@ -718,279 +486,46 @@ __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t
     *total_io = carry;
 }
 
-template <bool LAT>
-__global__ __launch_bounds__(64) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
+__global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
   const int* __restrict__ weight, int* __restrict__ order, int32_t* __restrict__ draw_ofs, int32_t* __restrict__ draw_total_io)
 {
-  // (the sorter's histogram shares the solver's LDS: a work-group is one or the other.  With both side by side a
-  // work-group took 24.8 KB, six of these one-wave groups filled a CU's LDS and the 2000 waves of C4 ran in two rounds.)
-  __shared__ EigSmem sm[4];
-  static_assert(sizeof(EigSmem) * 4 >= sizeof(int) * kOrderBins, "the sorter's histogram lives in the solver's LDS");
-  const int n_solver_groups = (S + 3) / 4;
+  __shared__ int hist[kOrderBins];
+  __shared__ int wave_tot[4];
+  const int n_solver_groups = (S + 255) / 256;
   if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling order of the following kernels
   {
-    sample_order_block(weight, S, order, reinterpret_cast<int*>(&sm[0]));
+    sample_order_block(weight, S, order, hist, wave_tot);
     return;
   }
   if ((int) blockIdx.x > n_solver_groups)  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
   {                                        // instead of in a launch of their own (12 us at C2: a launch for one wave)
-    draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
+    if (threadIdx.x < 64)
+      draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
     return;
   }
-  const int lane = threadIdx.x, gl = lane & 15, grp = lane >> 4;
-  const int s = blockIdx.x * 4 + grp;
-  if (gl == 0 && s < S)  // loud capacity / index errors (read back by agh_synchronize and the host entry points)
-  {
-    const int st_ = status[s];
-    if (st_ == kStatusOverflow || st_ == kStatusRows)
-      atomicOr(&flags[0], 1);
-    if (st_ == kStatusBadIndex)
-      atomicOr(&flags[0], 4);
-  }
-  const bool live = s < S && status[s] == kStatusOk;
-  EigSmem& E = sm[grp];
-  const double n = live ? (double) nt[s] : 1.0;
-  if (gl == 0)
-  {
-    E.fail = live ? 0 : 1;
-    double sv[kNumSums];
-    for (int k = 0; k < kNumSums; k++)
-      sv[k] = live ? sums[(int64_t) s * kSumStride + k] : 0.0;
-    for (int i = 0; i < 10; i++)
-      for (int j = 0; j < 10; j++)
-      {
-        E.M[i][j] = 0.0;
-        E.N[i][j] = 0.0;
-      }
-    // upper triangle of M (quadric.cpp:40-100)
-    for (int j = 0; j < 10; j++)
-      E.M[0][j] = sv[j];
-    for (int j = 1; j < 10; j++)
-      E.M[1][j] = sv[10 + j - 1];
-    for (int j = 2; j < 10; j++)
-      E.M[2][j] = sv[19 + j - 2];
-    E.M[3][8] = sv[27];
-    E.M[3][9] = sv[28];
-    E.M[4][9] = sv[29];
-    E.M[5][9] = sv[30];
-    E.M[6][9] = sv[31];
-    E.M[7][9] = sv[32];
-    E.M[8][9] = sv[33];
-    E.M[3][3] = E.M[0][1];
-    E.M[5][5] = E.M[0][2];
-    E.M[3][5] = E.M[0][4];
-    E.M[3][6] = E.M[0][7];
-    E.M[5][6] = E.M[0][8];
-    E.M[6][6] = E.M[0][9];
-    E.M[4][4] = E.M[1][2];
-    E.M[3][4] = E.M[1][5];
-    E.M[3][7] = E.M[1][6];
-    E.M[4][7] = E.M[1][8];
-    E.M[7][7] = E.M[1][9];
-    E.M[4][5] = E.M[2][3];
-    E.M[5][8] = E.M[2][6];
-    E.M[4][8] = E.M[2][7];
-    E.M[8][8] = E.M[2][9];
-    E.M[4][6] = E.M[3][8];
-    E.M[5][7] = E.M[3][8];
-    E.M[6][7] = E.M[3][9];
-    E.M[7][8] = E.M[4][9];
-    E.M[6][8] = E.M[5][9];
-    E.M[9][9] = n;
-    // N (quadric.cpp:103-131): every entry except (3,3),(4,4),(5,5) is an exact power-of-two multiple of an M sum
-    E.N[0][0] = 4.0 * sv[9];
-    E.N[0][3] = 2.0 * sv[28];
-    E.N[0][5] = 2.0 * sv[30];
-    E.N[0][6] = 2.0 * sv[31];
-    E.N[1][1] = 4.0 * sv[18];
-    E.N[1][3] = 2.0 * sv[28];
-    E.N[1][4] = 2.0 * sv[29];
-    E.N[1][7] = 2.0 * sv[32];
-    E.N[2][2] = 4.0 * sv[26];
-    E.N[2][4] = 2.0 * sv[29];
-    E.N[2][5] = 2.0 * sv[30];
-    E.N[2][8] = 2.0 * sv[33];
-    E.N[3][3] = sv[34];
-    E.N[3][4] = sv[30];
-    E.N[3][5] = sv[29];
-    E.N[3][6] = sv[32];
-    E.N[3][7] = sv[31];
-    E.N[4][4] = sv[35];
-    E.N[4][5] = sv[28];
-    E.N[4][7] = sv[33];
-    E.N[4][8] = sv[32];
-    E.N[5][5] = sv[36];
-    E.N[5][6] = sv[33];
-    E.N[5][8] = sv[31];
-    E.N[6][6] = n;
-    E.N[7][7] = n;
-    E.N[8][8] = n;
-    for (int i = 0; i < 10; i++)
-      for (int j = i + 1; j < 10; j++)
-      {
-        E.M[j][i] = E.M[i][j];
-        E.N[j][i] = E.N[i][j];
-      }
-    for (int k = 0; k < 9; k++)
-      E.m[k] = E.M[k][9];
-  }
-  __syncthreads();
-  const bool row = gl < 9;
-  const int i = gl;
-  const int ic = row ? gl : 0;  // (lanes 9..15 of a group compute along on row 0 and are never read)
-  double nrow[9], srow[9], lrow[9], ycol[9], yrow[9], crow[9];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= S)
+    return;
+  const int st_ = status[s];
+  // loud capacity / index errors (read back by agh_synchronize and the host entry points)
+  if (st_ == kStatusOverflow || st_ == kStatusRows)
+    atomicOr(&flags[0], 1);
+  if (st_ == kStatusBadIndex)
+    atomicOr(&flags[0], 4);
+  const bool live = st_ == kStatusOk && nt[s] > 0;
+  double sv[kNumSums];
 #pragma unroll
-  for (int j = 0; j < 9; j++)
-  {
-    srow[j] = E.M[ic][j] - (E.M[ic][9] * E.M[j][9]) / n;  // S = M9 - m m^T / n (the 10th unknown eliminated)
-    nrow[j] = E.N[ic][j];
-    lrow[j] = 0.0;
-  }
-  int fail = 0;
-  chol_step<0>(nrow, lrow, gl, fail);
-  chol_step<1>(nrow, lrow, gl, fail);
-  chol_step<2>(nrow, lrow, gl, fail);
-  chol_step<3>(nrow, lrow, gl, fail);
-  chol_step<4>(nrow, lrow, gl, fail);
-  chol_step<5>(nrow, lrow, gl, fail);
-  chol_step<6>(nrow, lrow, gl, fail);
-  chol_step<7>(nrow, lrow, gl, fail);
-  chol_step<8>(nrow, lrow, gl, fail);
-  if (gl == 0 && fail)
-    E.fail = 1;
-  ysolve_step<0>(srow, lrow, ycol);
-  ysolve_step<1>(srow, lrow, ycol);
-  ysolve_step<2>(srow, lrow, ycol);
-  ysolve_step<3>(srow, lrow, ycol);
-  ysolve_step<4>(srow, lrow, ycol);
-  ysolve_step<5>(srow, lrow, ycol);
-  ysolve_step<6>(srow, lrow, ycol);
-  ysolve_step<7>(srow, lrow, ycol);
-  ysolve_step<8>(srow, lrow, ycol);
-  // Y is held by columns and C is built by rows: one transposition through LDS; L goes along for the back substitution
-  if (row)
-  {
+  for (int k = 0; k < kNumSums; k++)
+    sv[k] = live ? sums[(int64_t) s * kSumStride + k] : 0.0;
+  double v[10];
+  const double lambda = taubin_smallest_eigenpair(sv, live ? (double) nt[s] : 1.0, v);
+  double* out = eig + (int64_t) s * 12;
 #pragma unroll
-    for (int r = 0; r < 9; r++)
-    {
-      E.Y[r][i] = ycol[r];
-      E.L[i][r] = lrow[r];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 9; j++)
-    yrow[j] = E.Y[ic][j];
-  csolve_step<0>(yrow, lrow, crow);
-  csolve_step<1>(yrow, lrow, crow);
-  csolve_step<2>(yrow, lrow, crow);
-  csolve_step<3>(yrow, lrow, crow);
-  csolve_step<4>(yrow, lrow, crow);
-  csolve_step<5>(yrow, lrow, crow);
-  csolve_step<6>(yrow, lrow, crow);
-  csolve_step<7>(yrow, lrow, crow);
-  csolve_step<8>(yrow, lrow, crow);
-  if (row)
-  {
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-      E.A[i][j] = crow[j];
-  }
-  __syncthreads();
-  // round-robin Jacobi (oracle jacobi_rr9) with the matrices in registers: lane gl of a 16-lane group holds row gl of A
-  // and of V.  The nine rounds of a sweep are unrolled so that every register index is a compile-time constant;
-  // values move between the lanes of a group with shuffles (no LDS round trips, no barriers inside a sweep).
-  double ar[9], vr[9];
-#pragma unroll
-  for (int j = 0; j < 9; j++)
-  {
-    ar[j] = row ? (j > i ? E.A[j][ic] : crow[j]) : 0.0;  // the lower triangle mirrored into the upper one
-    vr[j] = (row && i == j) ? 1.0 : 0.0;
-  }
-  const int gbase = lane & ~15;
-  for (int sweep = 0; sweep < 30; sweep++)
-  {
-    // off == 0.0 in the oracle <=> every upper-triangle square is 0 (a sum of non-negative terms)
-    bool nz = false;
-#pragma unroll
-    for (int j = 1; j < 9; j++)
-      nz = nz || (row && j > gl && (ar[j] * ar[j] != 0.0));
-    // A sweep in which every non-zero pair is negligible (possible from sweep 4 on) only sets those entries to zero:
-    // the diagonal and V are final, and the oracle's next sweep sees off == 0.  Recognise it up front (one pass over
-    // the row: own diagonal, the column's diagonal by a row broadcast) instead of running its nine rounds.
-    double dg = 0.0;
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-      dg = gl == j ? ar[j] : dg;
-    bool need = false;
-    need = rr_needs_rotation<1>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<2>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<3>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<4>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<5>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<6>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<7>(ar, gl, row, sweep, dg) || need;
-    need = rr_needs_rotation<8>(ar, gl, row, sweep, dg) || need;
-    const unsigned long long nzb = __ballot(nz), needb = __ballot(need);
-    const bool active = ((nzb >> gbase) & 0xffffull) != 0 && ((needb >> gbase) & 0xffffull) != 0;
-    if (__ballot(active) == 0ull)
-      break;
-    jacobi_round<0, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<1, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<2, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<3, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<4, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<5, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<6, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<7, LAT>(ar, vr, gl, gbase, row, active, sweep);
-    jacobi_round<8, LAT>(ar, vr, gl, gbase, row, active, sweep);
-  }
-  if (row)
-  {
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-    {
-      E.V[i][j] = vr[j];
-      if (j == i)
-        E.A[i][i] = ar[j];
-    }
-  }
-  __syncthreads();
-  if (gl == 0 && s < S)
-  {
-    double* out = eig + (int64_t) s * 12;
-    if (E.fail)
-    {
-      for (int k = 0; k < 12; k++)
-        out[k] = 0.0;
-    }
-    else
-    {
-      int mi = 0;
-      for (int k = 1; k < 9; k++)
-        if (E.A[k][k] < E.A[mi][mi])
-          mi = k;
-      double v[10];
-      for (int r = 8; r >= 0; r--)
-      {
-        double s2 = E.V[r][mi];
-        for (int k = r + 1; k < 9; k++)
-          s2 -= E.L[k][r] * v[k];
-        v[r] = s2 / E.L[r][r];
-      }
-      double bv = 0.0;
-      for (int k = 0; k < 9; k++)
-        bv += E.m[k] * v[k];
-      v[9] = -bv / n;
-      for (int k = 3; k < 6; k++)
-        v[k] *= 0.5;  // quadric.cpp:153
-      for (int k = 0; k < 10; k++)
-        out[k] = v[k];
-      out[10] = E.A[mi][mi];
-      out[11] = 1.0;
-    }
-  }
+  for (int k = 0; k < 10; k++)
+    out[k] = live ? ((k >= 3 && k < 6) ? v[k] * 0.5 : v[k]) : 0.0;  // quadric.cpp:153
+  out[10] = live ? lambda : 0.0;
+  out[11] = live ? 1.0 : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1514,20 +1049,13 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
-  // Two builds of the solver (see jacobi_round): LAT when every wave has a SIMD to itself, and again when the launch
-  // needs three waves per SIMD anyway (only LAT's 167 VGPRs allow that); the plain one for two per SIMD.  Measured, us:
-  // 500 waves 61 (plain 66), 2000 waves 95 (LAT 119), 4000 waves 197 (plain 213).
-  const int eig_groups = (Si + 3) / 4 + 1;
-  // (production mode: the sorter work-group also computes the RAND50 draw offsets, unless the caller exchanges the counts
+  const int eig_groups = (Si + 255) / 256 + 1;  // one sample per lane + the sorter work-group
+  // (production mode: one more work-group computes the RAND50 draw offsets, unless the caller exchanges the counts
   // between the ranks first -- the sharded search)
   int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
   const int eig_grid = eig_groups + (dofs ? 1 : 0);
-  if (eig_groups <= 1024 || eig_groups > 2048)
-    hipLaunchKernelGGL(k_taubin_eigen<true>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
-  else
-    hipLaunchKernelGGL(k_taubin_eigen<false>, dim3(eig_grid), dim3(64), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
+  hipLaunchKernelGGL(k_taubin_eigen, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+    c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -339,41 +339,24 @@ void jacobi_sym(double A[NN][NN], double V[NN][NN], double d[NN])
  * spectrum's low end.
  * Returns false only for an empty neighbourhood (n = 0).
  * ------------------------------------------------------------------------------------------------- */
-static const double kDeflateTol = 0x1p-40; /* relative Cholesky pivot below which a coordinate is deflated */
+static const double kDeflateTol = 0x1p-40; /* relative Cholesky pivot at or below which a coordinate is deflated */
 static const double kPivMin = 0x1p-500;    /* floor of |pivot| in the twisted factorisation */
 static const int kBisectSteps = 56;
-
-/* number of eigenvalues of the tridiagonal (d, e) below x: sign changes of the Sturm sequence
- * p_0 = 1, p_1 = d_0 - x, p_i+1 = (d_i - x) p_i - e_i-1^2 p_i-1; a zero takes the sign opposite to its predecessor */
-static inline int sturm_count9(const double d[9], const double e2[8], double x)
-{
-  double pm2 = 1.0, pm1 = d[0] - x;
-  bool neg = (pm1 < 0.0) || (pm1 == 0.0);
-  int c = neg ? 1 : 0;
-  for (int i = 1; i < 9; i++)
-  {
-    const double pi = (d[i] - x) * pm1 - e2[i - 1] * pm2;
-    const bool ng = (pi < 0.0) || (pi == 0.0 && !neg);
-    if (ng != neg)
-      c++;
-    neg = ng;
-    pm2 = pm1;
-    pm1 = pi;
-  }
-  return c;
-}
 
 static inline double pivot_floor(double x)
 {
   return (std::fabs(x) >= kPivMin) ? x : kPivMin;
 }
 
+/* Every multiply-add of the solver is a FUSED multiply-add (std::fma: one rounding; exact in glibc with or without the
+ * hardware instruction, v_fma_f64 on the GPU): this is this file's own algorithm, not a restatement of reference
+ * source, so the choice is free, and it halves the dependent chains the GPU kernel is made of. */
 bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], double* lambda)
 {
   const double n = M[9][9];
   if (!(n > 0.0))
     return false;
-  double b[9], A[9][9], L[9][9], rinv[9];
+  double b[9], C[9][9], L[9][9], rinv[9];
   bool defl[9];
   for (int i = 0; i < 9; i++)
     b[i] = M[i][9];
@@ -381,70 +364,52 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
   {
     const double ti = b[i] / n;
     for (int j = 0; j <= i; j++)
-    {
-      A[i][j] = M[i][j] - ti * b[j];
-      A[j][i] = A[i][j];
-    }
+      C[i][j] = std::fma(-ti, b[j], M[i][j]);
   }
-  /* 1. Cholesky with deflation */
+  /* 1. Cholesky with deflation (lower triangle; the diagonal lives in rinv) */
   for (int i = 0; i < 9; i++)
     for (int j = 0; j < 9; j++)
       L[i][j] = 0.0;
   for (int j = 0; j < 9; j++)
   {
-    double s = N[j][j];
+    double sp = N[j][j];
     for (int k = 0; k < j; k++)
-      s -= L[j][k] * L[j][k];
-    if (s > kDeflateTol * N[j][j])
-    {
-      const double ljj = std::sqrt(s);
-      L[j][j] = ljj;
-      rinv[j] = 1.0 / ljj;
-      defl[j] = false;
-    }
-    else
-    {
-      for (int k = 0; k <= j; k++)
+      sp = std::fma(-L[j][k], L[j][k], sp);
+    const bool ok = sp > kDeflateTol * N[j][j];
+    rinv[j] = ok ? 1.0 / std::sqrt(sp) : 0.0;
+    defl[j] = !ok;
+    if (!ok)
+      for (int k = 0; k < j; k++)
         L[j][k] = 0.0;
-      rinv[j] = 0.0;
-      defl[j] = true;
-    }
     for (int i = j + 1; i < 9; i++)
     {
       double s2 = N[i][j];
       for (int k = 0; k < j; k++)
-        s2 -= L[i][k] * L[j][k];
+        s2 = std::fma(-L[i][k], L[j][k], s2);
       L[i][j] = s2 * rinv[j];
     }
   }
-  /* 2. C = L^-1 A L^-T in place on the lower triangle (the unblocked LAPACK dsygs2 scheme, itype 1, lower), mirrored */
-  double C[9][9];
-  for (int i = 0; i < 9; i++)
-    for (int j = 0; j < 9; j++)
-      C[i][j] = A[i][j];
+  /* 2. C = L^-1 S L^-T in place on the lower triangle (the unblocked LAPACK dsygs2 scheme, itype 1, lower) */
   for (int k = 0; k < 9; k++)
   {
     const double akk = (C[k][k] * rinv[k]) * rinv[k];
     C[k][k] = akk;
     const double ct = -0.5 * akk;
     for (int i = k + 1; i < 9; i++)
-      C[i][k] = C[i][k] * rinv[k] + ct * L[i][k];
+      C[i][k] = std::fma(ct, L[i][k], C[i][k] * rinv[k]);
     for (int i = k + 1; i < 9; i++)
       for (int j = k + 1; j <= i; j++)
-        C[i][j] = (C[i][j] - C[i][k] * L[j][k]) - L[i][k] * C[j][k];
+        C[i][j] = std::fma(-L[i][k], C[j][k], std::fma(-C[i][k], L[j][k], C[i][j]));
     for (int i = k + 1; i < 9; i++)
-      C[i][k] = C[i][k] + ct * L[i][k];
+      C[i][k] = std::fma(ct, L[i][k], C[i][k]);
     for (int i = k + 1; i < 9; i++)
     {
       double s2 = C[i][k];
       for (int m = k + 1; m < i; m++)
-        s2 -= L[i][m] * C[m][k];
+        s2 = std::fma(-L[i][m], C[m][k], s2);
       C[i][k] = s2 * rinv[i];
     }
   }
-  for (int i = 0; i < 9; i++)
-    for (int j = i + 1; j < 9; j++)
-      C[i][j] = C[j][i];
   double tr = 0.0;
   for (int i = 0; i < 9; i++)
     tr += std::fabs(C[i][i]);
@@ -452,58 +417,53 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
   for (int j = 0; j < 9; j++)
     if (defl[j])
       C[j][j] = big;
-  /* 3. Householder tridiagonalisation (reflector k zeroes column k below the sub-diagonal; H_k = I - u u^T / h) */
-  double U[7][9], RH[7], e[8], d[9], e2[8];
+  /* 3. Householder tridiagonalisation on the lower triangle (reflector k zeroes column k below the sub-diagonal,
+   *    H_k = I - u u^T / h, and stays in that column) */
+  double RH[7], e[8], d[9], e2[8];
   for (int k = 0; k < 7; k++)
   {
     double sg = 0.0;
     for (int i = k + 1; i < 9; i++)
-      sg += C[i][k] * C[i][k];
+      sg = std::fma(C[i][k], C[i][k], sg);
     const double x0 = C[k + 1][k];
     const double rt = std::sqrt(sg);
     const double g = (x0 >= 0.0) ? -rt : rt;
-    const double h = sg - x0 * g;
+    const double h = std::fma(-x0, g, sg);
     const bool live = h > 0.0;
     const double rh = live ? 1.0 / h : 0.0;
     double u[9], p[9], q[9];
-    for (int i = 0; i < 9; i++)
-      u[i] = 0.0;
-    if (live)
-    {
-      for (int i = k + 1; i < 9; i++)
-        u[i] = C[i][k];
-      u[k + 1] = x0 - g;
-    }
-    for (int i = 0; i < 9; i++)
-      U[k][i] = u[i];
+    for (int i = k + 1; i < 9; i++)
+      u[i] = live ? C[i][k] : 0.0;
+    u[k + 1] = live ? x0 - g : 0.0;
     RH[k] = rh;
     e[k] = live ? g : x0;
     for (int i = k + 1; i < 9; i++)
     {
       double s2 = 0.0;
       for (int j = k + 1; j < 9; j++)
-        s2 += C[i][j] * u[j];
+        s2 = std::fma((j <= i) ? C[i][j] : C[j][i], u[j], s2);
       p[i] = s2 * rh;
     }
     double kk = 0.0;
     for (int i = k + 1; i < 9; i++)
-      kk += u[i] * p[i];
+      kk = std::fma(u[i], p[i], kk);
     kk = (kk * rh) * 0.5;
     for (int i = k + 1; i < 9; i++)
-      q[i] = p[i] - kk * u[i];
+      q[i] = std::fma(-kk, u[i], p[i]);
     for (int i = k + 1; i < 9; i++)
       for (int j = k + 1; j <= i; j++)
-      {
-        C[i][j] = (C[i][j] - u[i] * q[j]) - q[i] * u[j];
-        C[j][i] = C[i][j];
-      }
+        C[i][j] = std::fma(-q[i], u[j], std::fma(-u[i], q[j], C[i][j]));
+    for (int i = k + 1; i < 9; i++)
+      C[i][k] = u[i];
   }
   e[7] = C[8][7];
   for (int i = 0; i < 9; i++)
     d[i] = C[i][i];
   for (int i = 0; i < 8; i++)
     e2[i] = e[i] * e[i];
-  /* 4. bisection: lambda_min lies in [min_i (d_i - |e_i-1| - |e_i|), min_i d_i] (deflated coordinates excluded) */
+  /* 4. bisection: lambda_min lies in [min_i (d_i - (|e_i-1| + |e_i|)), min_i d_i] (deflated coordinates excluded).
+   *    An eigenvalue lies below x iff the Sturm sequence p_0 = 1, p_1 = d_0 - x, p_i+1 = (d_i - x) p_i - e_i-1^2 p_i-1
+   *    changes sign, i.e. iff some p_i is negative (sign bit set: -0 counts, +0 does not). */
   double lo = 0.0, hi = 0.0;
   bool first = true;
   for (int i = 0; i < 9; i++)
@@ -520,8 +480,17 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
   }
   for (int it = 0; it < kBisectSteps; it++)
   {
-    const double mid = lo + (hi - lo) * 0.5;
-    if (sturm_count9(d, e2, mid) >= 1)
+    const double mid = std::fma(hi - lo, 0.5, lo);
+    double pm2 = 1.0, pm1 = d[0] - mid;
+    bool below = std::signbit(pm1);
+    for (int i = 1; i < 9; i++)
+    {
+      const double pi = std::fma(d[i] - mid, pm1, -(e2[i - 1] * pm2));
+      below = below || std::signbit(pi);
+      pm2 = pm1;
+      pm1 = pi;
+    }
+    if (below)
       hi = mid;
     else
       lo = mid;
@@ -533,13 +502,13 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
   for (int i = 0; i < 8; i++)
   {
     lf[i] = e[i] / Dp[i];
-    Dp[i + 1] = pivot_floor((d[i + 1] - sigma) - lf[i] * e[i]);
+    Dp[i + 1] = pivot_floor(std::fma(-lf[i], e[i], d[i + 1] - sigma));
   }
   Dm[8] = pivot_floor(d[8] - sigma);
   for (int i = 7; i >= 0; i--)
   {
     ub[i] = e[i] / Dm[i + 1];
-    Dm[i] = pivot_floor((d[i] - sigma) - ub[i] * e[i]);
+    Dm[i] = pivot_floor(std::fma(-ub[i], e[i], d[i] - sigma));
   }
   int ks = -1;
   double gmin = 0.0;
@@ -567,21 +536,21 @@ bool solve_taubin(const double M[10][10], const double N[10][10], double v[10], 
   {
     double s2 = 0.0;
     for (int i = k + 1; i < 9; i++)
-      s2 += U[k][i] * z[i];
+      s2 = std::fma(C[i][k], z[i], s2);
     s2 = s2 * RH[k];
     for (int i = k + 1; i < 9; i++)
-      z[i] = z[i] - s2 * U[k][i];
+      z[i] = std::fma(-s2, C[i][k], z[i]);
   }
   for (int i = 8; i >= 0; i--)
   {
     double s2 = z[i];
     for (int k = i + 1; k < 9; k++)
-      s2 -= L[k][i] * v[k];
+      s2 = std::fma(-L[k][i], v[k], s2);
     v[i] = s2 * rinv[i];
   }
   double bv = 0.0;
   for (int k = 0; k < 9; k++)
-    bv += b[k] * v[k];
+    bv = std::fma(b[k], v[k], bv);
   v[9] = -(bv / n);
   *lambda = sigma;
   return true;

@@ -204,8 +204,15 @@ def test_edge_cases(tiny_scene):
     # empty cloud, single isolated point, two far points: no hypotheses, no crash
     ctx.set_cloud(np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
     assert len(ctx.find_hands(np.zeros(0, np.int32))) == 0
-    ctx.set_cloud(np.array([[0.5, 0.0, 0.0], [2.0, 2.0, 2.0]], np.float32), np.zeros(2, np.int32))
-    assert len(ctx.find_hands(np.array([0, 1], np.int32))) == 0
+    two = np.array([[0.5, 0.0, 0.0], [2.0, 2.0, 2.0]], np.float32)
+    ctx.set_cloud(two, np.zeros(2, np.int32))
+    from oracle import oracle_py as O
+
+    lone = ctx.find_hands(np.array([0, 1], np.int32))
+    ref = O.find_hands(O.default_params(sc.cam_origins), two, np.zeros(2, np.int32), np.array([0, 1], np.int32))["hyps"]
+    assert len(lone) == len(ref)
+    for f in INT_FIELDS + FLOAT_FIELDS:
+        assert np.array_equal(lone[f], ref[f]), f
     fr = ctx.frames()
     assert (fr["valid"] == 1).all() and list(fr["n_nb"]) == [1, 1]  # under-determined fits still yield a frame
     # duplicate samples are independent work items
