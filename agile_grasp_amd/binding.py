@@ -115,6 +115,13 @@ def shard_slice(n: int, rank: int, n_ranks: int):
     return lo.value, hi.value
 
 
+def comm_rccl_origin() -> str:
+    """Which RCCL image the library bound (binds it if that has not happened yet)."""
+    lib = load_library()
+    lib.agh_comm_rccl_origin.restype = C.c_char_p
+    return lib.agh_comm_rccl_origin().decode()
+
+
 def pack_images(images: np.ndarray) -> np.ndarray:
     """(n, 8000) uint8 images (0 / 255) -> (n, 250) uint32 words, bit (b & 31) of word (b >> 5) = pixel b."""
     im = np.ascontiguousarray(images, np.uint8).reshape(-1, 8000) != 0

@@ -22,7 +22,22 @@
 #include "agh_internal.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// RCCL is opened at run time (dlopen) and NOT needed to build this library: the handful of types and constants of
+// <rccl/rccl.h> (the NCCL 2 ABI: an opaque communicator pointer, the 128-byte unique id, result 0 = success, data
+// type 0 = char) are declared here instead of including the header.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct
+{
+  char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclChar = 0;
 
 #include <algorithm>
 #include <condition_variable>
@@ -44,6 +59,7 @@ struct Rccl
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
+  std::string origin;  // which image the entry points come from (agh_comm_rccl_origin)
 };
 
 Rccl* rccl()
@@ -51,16 +67,46 @@ Rccl* rccl()
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // A process that has PyTorch loaded already has an RCCL image mapped (torch/lib/librccl.so); loading a second copy
+    // beside it would give the process two collective runtimes with two sets of proxy threads and IPC state.  So: an image
+    // that is already mapped wins (RTLD_NOLOAD only succeeds for those), then AGH_RCCL_LIB, then the system library.
     const char* env = std::getenv("AGH_RCCL_LIB");
+    const char* mapped[] = { "librccl.so", "librccl.so.1" };
+    for (const char* n : mapped)
+      if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)))
+      {
+        r.origin = std::string("already mapped: ") + n;
+        break;
+      }
+    if (!r.lib)
+      if (FILE* f = std::fopen("/proc/self/maps", "r"))  // (a copy mapped under a path dlopen's search does not know)
+      {
+        char line[4096];
+        while (!r.lib && std::fgets(line, sizeof(line), f))
+          if (const char* hit = std::strstr(line, "librccl.so"))
+          {
+            const char* path = std::strchr(line, '/');
+            if (!path || path > hit)
+              continue;
+            std::string pth(path);
+            while (!pth.empty() && (pth.back() == '\n' || pth.back() == ' '))
+              pth.pop_back();
+            if ((r.lib = dlopen(pth.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)))
+              r.origin = "already mapped: " + pth;
+          }
+        std::fclose(f);
+      }
     const char* names[] = { env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
     for (const char* n : names)
-      if (n && (r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
-        break;
+      if (!r.lib && n && (r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+        r.origin = std::string("loaded: ") + n;
     if (!r.lib)
     {
       r.err = "RCCL not found (librccl.so.1; set AGH_RCCL_LIB)";
       return;
     }
+    if (std::getenv("AGH_VERBOSE"))
+      std::fprintf(stderr, "agile_grasp_amd: RCCL %s\n", r.origin.c_str());
     r.GetUniqueId = (decltype(r.GetUniqueId)) dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank)) dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy)) dlsym(r.lib, "ncclCommDestroy");
@@ -328,6 +374,12 @@ void agh_shard_slice(int64_t n, int32_t rank, int32_t n_ranks, int64_t* lo, int6
     *hi = shard_lo(n, (int64_t) rank + 1, n_ranks);
 }
 
+const char* agh_comm_rccl_origin(void)
+{
+  Rccl* r = rccl();
+  return r->lib ? r->origin.c_str() : r->err.c_str();
+}
+
 int agh_comm_unique_id(uint8_t id[AGH_COMM_ID_BYTES])
 {
   static_assert(AGH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -497,7 +549,9 @@ int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int
     if ((rc = grow(c, &c->d_xcnt, &have, 128)) != AGH_OK)
       return rc;
   }
-  if (rand_mode && (rc = ensure_draws(c, 50 * S, st)) != AGH_OK)
+  // (a communicator of one may run the all-points pass in the production mode: its rand() stream runs through all N
+  // points before the samples, exactly as in agh_find_hands_device)
+  if (rand_mode && (rc = ensure_draws(c, 50 * (S + (calculates_antipodal ? c->n : 0)), st)) != AGH_OK)
     return rc;
   timing_begin(c, st);
   c->zero_flags_pending = true;

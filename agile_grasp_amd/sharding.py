@@ -17,11 +17,11 @@ HEADER_BYTES = 160
 
 
 def shard_slice(n_items: int, rank: int, world: int) -> slice:
-    """The slice rank ``rank`` of ``world`` takes (the C ABI's agh_shard_slice; needs no GPU)."""
-    from . import binding
-
-    lo, hi = binding.shard_slice(n_items, rank, world)
-    return slice(lo, hi)
+    """The slice rank ``rank`` of ``world`` takes: [n r / G, n (r + 1) / G) in integer arithmetic -- agh_shard_slice of the C ABI
+    (csrc/shard.hip: shard_lo), restated here so that the host-side bookkeeping needs no built library;
+    tests/test_sharding.py checks the two against each other."""
+    world = max(int(world), 1)
+    return slice((n_items * rank) // world, (n_items * (rank + 1)) // world)
 
 
 def segment_records(n_samples: int, world: int, full: bool = False) -> int:

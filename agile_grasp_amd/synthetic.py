@@ -38,11 +38,15 @@ def camera_origins() -> np.ndarray:
     return np.stack([left[:3, 3], right[:3, 3]]).astype(np.float64)
 
 
-# The reference voxelises in the frame the cloud arrives in (a camera optical frame, localization.cpp:43), in which a
-# table top is tilted.  An axis-aligned table would put every table point of a camera on ONE lattice level, i.e. make
-# two thirds of the neighbourhoods exactly planar and the Taubin constraint matrix singular -- not what real clouds
-# look like.  The whole scene (points and camera origins alike) is therefore expressed in a frame tilted by a fixed
-# rotation about the scene pivot before the per-camera voxel snap.
+# Two variants of every scene:
+#  * AXIS-ALIGNED (name suffix "u", `tilt=False`): SURVEY section 8d to the letter.  The table top and the box faces are
+#    parallel to the axes of the frame the cloud is voxelised in -- the `/base` frame of the two-view setup
+#    (launch/baxter_grasps.launch:4) -- so every point of a horizontal face lands on ONE lattice level: two thirds of
+#    the Taubin neighbourhoods are EXACTLY planar and the generalised eigenproblem of quadric.cpp:143-153 is singular.
+#    LAPACK's dggev returns the plane's normal for them all the same, and so does this repository since round 3.
+#  * TILTED (the default, the names BASELINE's configs use since round 1): the whole scene (points and camera origins
+#    alike) is expressed in a frame rotated by 33 / -19 degrees about the scene pivot before the per-camera voxel snap,
+#    as in a camera optical frame (single_camera_grasps.launch); no neighbourhood is exactly planar.
 _PIVOT = np.array([0.9, 0.0, -0.1])
 
 
@@ -53,7 +57,9 @@ def _tilt() -> np.ndarray:
     return ry @ rx
 
 
-def to_scene_frame(p: np.ndarray) -> np.ndarray:
+def to_scene_frame(p: np.ndarray, tilt: bool = True) -> np.ndarray:
+    if not tilt:
+        return np.array(p, dtype=np.float64, copy=True)
     return (p - _PIVOT) @ _tilt().T + _PIVOT
 
 
@@ -139,7 +145,7 @@ def _voxelize(pts: np.ndarray, cell: float = 0.003) -> np.ndarray:
 
 
 def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, n_objects: int = 14,
-               name: str = "") -> Scene:
+               name: str = "", tilt: bool = True) -> Scene:
     """Build a scene with exactly ``n_points`` points and ``n_samples`` sorted sample indices."""
     rng = np.random.default_rng(seed)
     views = 2 if two_view else 1
@@ -151,7 +157,7 @@ def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, 
     lx, ly = np.sqrt(table_area * aspect), np.sqrt(table_area / aspect)
     for _ in range(6):
         table = (0.5, 0.5 + lx, -ly / 2, ly / 2, -0.10)
-        raw = to_scene_frame(_surface_points(np.random.default_rng(seed), table, n_objects, 0.0015))
+        raw = to_scene_frame(_surface_points(np.random.default_rng(seed), table, n_objects, 0.0015), tilt)
         clouds = []
         crng = np.random.default_rng(seed + 7919)
         for _cam in range(views):
@@ -171,26 +177,62 @@ def make_scene(n_points: int, n_samples: int, seed: int, two_view: bool = True, 
         keep_idx = np.sort(rng.permutation(total)[:n_points])
         xyz, cam = xyz[keep_idx], cam[keep_idx]
     samples = np.sort(rng.permutation(n_points)[:n_samples]).astype(np.int32)
-    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), to_scene_frame(camera_origins()), samples, seed,
-                 name)
+    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), to_scene_frame(camera_origins(), tilt), samples,
+                 seed, name)
 
 
 # BASELINE.json configs made concrete
 def config(name: str) -> Scene:
-    if name == "C1":
-        return make_scene(50_000, 500, seed=1, two_view=False, name="C1")
-    if name in ("C2", "C3"):
-        return make_scene(300_000, 2000, seed=2, two_view=True, name=name)
-    if name == "C4":
-        return make_scene(1_000_000, 8000, seed=4, two_view=True, n_objects=48, name="C4")
-    if name.startswith("C5"):
-        k = int(name[3:]) if len(name) > 2 else 0
-        return make_scene(300_000, 2000, seed=10 + k, two_view=True, name=name)
-    if name == "tiny":
-        return make_scene(12_000, 64, seed=3, two_view=True, n_objects=3, name="tiny")
-    if name == "small":
-        return make_scene(40_000, 200, seed=5, two_view=True, n_objects=6, name="small")
+    """`C2`, `C4`, ... are the tilted scenes; a trailing `u` (`C2u`, `smallu`, ...) selects the axis-aligned variant of the
+    same scene (same seed, same objects), `boxu` an axis-aligned table with one 6 x 6 x 9 cm box."""
+    if name == "boxu":
+        return make_box_scene()
+    tilt = True
+    base = name
+    if name.endswith("u") and name[:-1] in ("C1", "C2", "C3", "C4", "tiny", "small") or (name.startswith("C5") and name.endswith("u")):
+        tilt, base = False, name[:-1]
+    if base == "C1":
+        return make_scene(50_000, 500, seed=1, two_view=False, name=name, tilt=tilt)
+    if base in ("C2", "C3"):
+        return make_scene(300_000, 2000, seed=2, two_view=True, name=name, tilt=tilt)
+    if base == "C4":
+        return make_scene(1_000_000, 8000, seed=4, two_view=True, n_objects=48, name=name, tilt=tilt)
+    if base.startswith("C5"):
+        k = int(base[3:]) if len(base) > 2 else 0
+        return make_scene(300_000, 2000, seed=10 + k, two_view=True, name=name, tilt=tilt)
+    if base == "tiny":
+        return make_scene(12_000, 64, seed=3, two_view=True, n_objects=3, name=name, tilt=tilt)
+    if base == "small":
+        return make_scene(40_000, 200, seed=5, two_view=True, n_objects=6, name=name, tilt=tilt)
     raise KeyError(name)
+
+
+def make_box_scene(n_samples: int = 400, seed: int = 21) -> Scene:
+    """An ideal axis-aligned 36 x 36 cm table with one axis-aligned 6 x 6 x 9 cm box on it, both cameras, every point
+    exactly on the 3 mm lattice (no jitter, no drop-outs): the textbook case of exactly planar neighbourhoods."""
+    rng = np.random.default_rng(seed)
+    g = np.arange(-60, 61) * 0.003
+    u, v = np.meshgrid(g, g, indexing="ij")
+    zt = -0.099
+    table = np.stack([0.75 + u.ravel(), 0.0 + v.ravel(), np.full(u.size, zt)], 1)
+    inside = (np.abs(table[:, 0] - 0.75) < 0.0301) & (np.abs(table[:, 1]) < 0.0301)
+    table = table[~inside]
+    b = np.arange(-10, 11) * 0.003
+    h = np.arange(0, 31) * 0.003
+    bu, bv = np.meshgrid(b, b, indexing="ij")
+    top = np.stack([0.75 + bu.ravel(), bv.ravel(), np.full(bu.size, zt + 0.09)], 1)
+    su, sh = np.meshgrid(b, h[:-1], indexing="ij")
+    sides = [np.stack([0.75 + su.ravel(), np.full(su.size, sgn * 0.03), zt + sh.ravel()], 1) for sgn in (-1, 1)]
+    sides += [np.stack([0.75 + np.full(su.size, sgn * 0.03), su.ravel(), zt + sh.ravel()], 1) for sgn in (-1, 1)]
+    pts = np.unique(np.round(np.concatenate([table, top] + sides) / 0.003).astype(np.int64), axis=0) * 0.003
+    clouds = []
+    for _cam in range(2):
+        keep = rng.random(pts.shape[0]) < 0.8
+        clouds.append(pts[keep])
+    xyz = np.concatenate(clouds).astype(np.float32)
+    cam = np.concatenate([np.full(c.shape[0], i, np.int32) for i, c in enumerate(clouds)])
+    samples = np.sort(rng.permutation(xyz.shape[0])[:n_samples]).astype(np.int32)
+    return Scene(np.ascontiguousarray(xyz), np.ascontiguousarray(cam), camera_origins(), samples, seed, "boxu")
 
 
 @dataclasses.dataclass

@@ -272,6 +272,10 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
 int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks);
 int agh_comm_destroy(agh_ctx* ctx);
 int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks); /* 0 / 1 without a communicator */
+/* Which RCCL image the library bound ("already mapped: <path>" -- the copy the process had loaded, e.g. PyTorch's --, or
+ * "loaded: <name>"); "" before the first agh_comm_unique_id / agh_comm_init, or an error text if none was found.  RCCL is
+ * bound at run time: building the library needs neither its headers nor the library itself. */
+const char* agh_comm_rccl_origin(void);
 /* Length of the merged list of the last agh_find_hands_sharded (host variant) of this context; AGH_ERR_STATE if the context
  * has no communicator or has not run a sharded search. */
 int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp);

@@ -103,3 +103,36 @@ def test_batch_edge_cases(tiny_scene):
     _compare(again, [h], [sc.samples.size])
     with pytest.raises(binding.AghError):
         ctx.set_cloud_batch([sc.xyz] * 65, [sc.cam] * 65)
+
+
+def test_full_size_c5_batch_against_oracle(svm_model):
+    """BASELINE config C5 at full size on one GPU: the eight 300k-point clouds (seeds 10..17) in ONE context, 16 000 samples in
+    one launch set, against the ORACLE cloud by cloud (frames, hypotheses, SVM labels bit-identical)."""
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as O
+
+    w, rho = svm_model
+    scs = [synthetic.config(f"C5_{k}") for k in range(8)]
+    ctx = binding.Context(scs[0].cam_origins)
+    off = ctx.set_cloud_batch([s.xyz for s in scs], [s.cam for s in scs])
+    samples = np.concatenate([s.samples + off[k] for k, s in enumerate(scs)]).astype(np.int32)
+    hyps = ctx.find_hands(samples)
+    ctx.load_svm(w, rho)
+    keep = ctx.classify()
+    frames = ctx.frames()
+    pos = base = 0
+    for k, sc in enumerate(scs):
+        ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+        okeep, _ = O.classify(ref["images"], w, rho)
+        n = len(ref["hyps"])
+        part = hyps[pos:pos + n]
+        assert np.array_equal(part["sample"], ref["hyps"]["sample"] + base), k
+        for f in FIELDS:
+            assert np.array_equal(part[f], ref["hyps"][f]), (k, f)
+        assert np.array_equal(keep[pos:pos + n], okeep), k
+        fr = frames[base:base + sc.samples.size]
+        for f in ("normal", "axis", "binormal", "params", "n_nb", "max_index", "majority_cam", "valid"):
+            assert np.array_equal(fr[f], ref["frames"][f]), (k, f)
+        pos += n
+        base += sc.samples.size
+    assert pos == len(hyps) > 5000

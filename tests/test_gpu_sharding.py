@@ -146,6 +146,50 @@ def test_sharded_edge_cases(tiny_scene):
         one.find_hands_sharded(sc.samples)  # no communicator
 
 
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_full_size_eight_way_sharded_search_against_oracle(svm_model, name):
+    """BASELINE configs C2 and C4 sharded eight ways (the in-process communicator: the RCCL schedule with device copies):
+    the merged list of EVERY rank against the ORACLE's list -- not against the single-GPU HIP list."""
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config(name)
+    w, rho = svm_model
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+    okeep, _ = O.classify(ref["images"], w, rho)
+    ctxs = _group(sc, 8)
+    for c in ctxs:
+        c.load_svm(w, rho)
+    res = _run_ranks(ctxs, lambda r, c: (c.find_hands_sharded(sc.samples), c.classify_sharded()))
+    for hyps, (recs, keep) in res:
+        assert len(hyps) == len(ref["hyps"]) > sc.samples.size // 10
+        for f in FIELDS:
+            if f != "valid":
+                assert np.array_equal(hyps[f], ref["hyps"][f]), f
+        assert np.array_equal(keep, okeep)
+
+
+def test_solo_communicator_runs_the_all_points_pass_in_the_production_mode(tiny_scene):
+    """A communicator of one may combine RAND50 with calculates_antipodal (the rand() stream runs through all N points, then
+    the samples -- ADVICE r2: the draw table was sized for the samples only)."""
+    from agile_grasp_amd import binding
+    from oracle import oracle_py as O
+
+    sc = tiny_scene
+    solo = _group(sc, 1, normals_mode=binding.NORMALS_RAND50, rand_seed=7)
+    got = solo[0].find_hands_sharded(sc.samples, calculates_antipodal=True)
+    one = binding.Context(sc.cam_origins, normals_mode=binding.NORMALS_RAND50, rand_seed=7)
+    one.set_cloud(sc.xyz, sc.cam)
+    _same(got, one.find_hands(sc.samples, calculates_antipodal=True))
+    ref = O.find_hands(O.default_params(sc.cam_origins, normals_mode=O.NORMALS_RAND50, rand_seed=7), sc.xyz, sc.cam, sc.samples,
+                       calculates_antipodal=True)["hyps"]
+    assert len(got) == len(ref)
+    for f in FIELDS:
+        if f != "valid":
+            assert np.array_equal(got[f], ref[f]), f
+    assert got["half_antipodal"].sum() > 0
+
+
 def test_rccl_communicator_of_one(tiny_scene, svm_model):
     """RCCL bound at run time, ncclCommInitRank on the context's device, ncclAllGather on the search's stream."""
     from agile_grasp_amd import binding
@@ -165,6 +209,12 @@ def test_rccl_communicator_of_one(tiny_scene, svm_model):
     anti = ctx.find_hands_sharded(sc.samples, calculates_antipodal=True)
     ctx.comm_destroy()
     _same(anti, ctx.find_hands(sc.samples, calculates_antipodal=True))
+    # ONE RCCL image in the process: the library binds the copy torch mapped (RTLD_NOLOAD) instead of loading a second one
+    import torch  # noqa: F401  (maps torch/lib/librccl.so if it was not mapped yet -- it is, by the session's fixtures)
+
+    images = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+    assert len(images) == 1, images
+    assert binding.comm_rccl_origin().startswith(("already mapped", "loaded"))
 
 
 def test_cpp_adapter_sharded_search(tmp_path, small_scene, svm_model):

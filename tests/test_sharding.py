@@ -25,6 +25,18 @@ def test_shard_slices_partition_the_samples():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_host_side_slices_equal_the_c_abi():
+    """sharding.shard_slice restates agh_shard_slice (so that the bookkeeping needs no built library); the two must agree."""
+    from agile_grasp_amd import binding
+    from agile_grasp_amd.sharding import shard_slice
+
+    for n in (0, 1, 7, 2000, 2001, 8000, 300_000):
+        for world in (1, 2, 3, 5, 8, 64):
+            for r in range(world):
+                sl = shard_slice(n, r, world)
+                assert (sl.start, sl.stop) == binding.shard_slice(n, r, world)
+
+
 def test_segment_sizes():
     from agile_grasp_amd import sharding
 
