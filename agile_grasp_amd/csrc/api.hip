@@ -475,6 +475,19 @@ void agh_destroy(agh_ctx* ctx)
   delete ctx;
 }
 
+namespace
+{
+struct CloudOffArg
+{
+  int32_t v[agh::kMaxClouds + 1];
+};
+__global__ void k_set_cloud_off(CloudOffArg a, int32_t* __restrict__ out)
+{
+  if (threadIdx.x <= agh::kMaxClouds)
+    out[threadIdx.x] = a.v[threadIdx.x];
+}
+}  // namespace
+
 int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
   const int64_t* offsets, int32_t n_clouds, void* hip_stream)
 {
@@ -519,8 +532,12 @@ int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_
     c->cloud_off_i32.assign((size_t) kMaxClouds + 1, (int32_t) n);
     for (int k = 0; k <= n_clouds; k++)
       c->cloud_off_i32[(size_t) k] = (int32_t) offsets[k];
-    HIPCHK(c, hipMemcpyAsync(c->d_cloud_off, c->cloud_off_i32.data(), sizeof(int32_t) * (kMaxClouds + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));  // (pageable source: the copy has left the host vector)
+    // by value through a kernel's arguments: no pageable copy, no host synchronisation on the caller's stream (a stream of
+    // voxelised clouds changes its point count with every frame)
+    CloudOffArg a;
+    for (int k = 0; k <= kMaxClouds; k++)
+      a.v[k] = c->cloud_off_i32[(size_t) k];
+    hipLaunchKernelGGL(k_set_cloud_off, dim3(1), dim3(128), 0, st, a, c->d_cloud_off);
     c->cloud_off_on_device = true;
   }
   if (n > c->grid_cap)

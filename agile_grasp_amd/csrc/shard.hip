@@ -126,10 +126,14 @@ struct LocalGroup
   std::condition_variable cv;
   int arrived = 0;
   uint64_t generation = 0;
+  bool failed = false;  // a rank left a collective call with an error: the others must not wait for it
   std::vector<const void*> send;
-  void barrier()
+  // false: the group is broken (a rank failed between two collectives); the caller reports an error instead of waiting
+  bool barrier()
   {
     std::unique_lock<std::mutex> lk(m);
+    if (failed)
+      return false;
     const uint64_t g = generation;
     if (++arrived == n)
     {
@@ -138,7 +142,14 @@ struct LocalGroup
       cv.notify_all();
     }
     else
-      cv.wait(lk, [&] { return generation != g; });
+      cv.wait(lk, [&] { return generation != g || failed; });
+    return !failed;
+  }
+  void abort()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    failed = true;
+    cv.notify_all();
   }
 };
 }  // namespace
@@ -195,12 +206,21 @@ int all_gather(Ctx* c, void* buf, size_t bytes, hipStream_t st)
     std::lock_guard<std::mutex> lk(g->m);
     g->send[(size_t) cm->rank] = (const char*) buf + (size_t) cm->rank * bytes;
   }
-  g->barrier();
+  const char* broken = "a rank of the in-process communicator left the collective with an error; the communicator is unusable";
+  if (!g->barrier())
+  {
+    c->err = broken;
+    return AGH_ERR_STATE;
+  }
   for (int q = 0; q < cm->n_ranks; q++)
     if (q != cm->rank)
       HIPCHK(c, hipMemcpyAsync((char*) buf + (size_t) q * bytes, g->send[(size_t) q], bytes, hipMemcpyDeviceToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  g->barrier();  // nobody reuses a segment before everyone has copied it
+  if (!g->barrier())  // nobody reuses a segment before everyone has copied it
+  {
+    c->err = broken;
+    return AGH_ERR_STATE;
+  }
   return AGH_OK;
 }
 
@@ -209,6 +229,13 @@ constexpr int kHeaderBytes = 160;  // one record's size: keeps the records of a 
 __host__ __device__ inline int64_t shard_lo(int64_t n, int64_t r, int64_t G)
 {
   return (n * r) / G;
+}
+
+// header of an empty slice: no hypotheses, and the capacity-class flag (bit 0 of flags[0]) as k_compact_* would write it
+__global__ void k_shard_empty_header(int64_t* __restrict__ hdr, const int32_t* __restrict__ flags)
+{
+  hdr[0] = 0;
+  hdr[1] = flags[0] & 1;
 }
 
 // RAND50: draws my slice consumes (50 per neighbourhood of more than 50 points, quadric.cpp:177-193)
@@ -494,7 +521,21 @@ int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks)
   return AGH_OK;
 }
 
+static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
+
 int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
+{
+  const int rc = find_hands_sharded_device_impl(ctx, d_sample_idx, n_samples, calculates_antipodal, d_out, cap, d_n_out, hip_stream);
+  // A rank that fails on its own (out of memory, a launch error) has left the others inside a collective: release them with
+  // an error instead of letting them wait for ever.  (In-process communicator; across processes RCCL's own watchdog applies.)
+  if (rc != AGH_OK && ctx && ctx->c.comm && ctx->c.comm->local && rc != AGH_ERR_INVALID_ARGUMENT && rc != AGH_ERR_NO_CLOUD)
+    ctx->c.comm->local->abort();
+  return rc;
+}
+
+static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
 {
   if (!ctx)
@@ -659,8 +700,9 @@ int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int
       return rc;
     }
   }
-  else
-    HIPCHK(c, hipMemsetAsync(my_count, 0, 2 * sizeof(int64_t), st));  // count and header flags
+  else  // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must
+        // learn of a capacity-class retry from EVERY rank, or this one would repeat the collective alone)
+    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags);
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
     return rc;
   timing_mark(c, "shard_exchange", st);

@@ -135,6 +135,76 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
                          "note": "HIP events of an untimed pass of the same steps"}}
 
 
+def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label):
+    """One more single-GPU measurement of the same step on another scene / normals mode (extra keys of the N = 1 line):
+    device-resident cloud and samples, `steps` // 2 timed steps after the same settling and warm-up."""
+    from agile_grasp_amd import binding, synthetic
+
+    sc = synthetic.config(scene_name)
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
+    s_t = torch.from_numpy(sc.samples).to(dev)
+    S = sc.samples.size
+    out_t = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
+    nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.set_cloud_torch(xyz_t, cam_t, stream=stream)
+        ctx.find_hands_torch(s_t, out_t, nout_t, stream=stream)
+
+    settle(ctx, step, torch.cuda.synchronize)
+    for _ in range(max(args.warmup, 5)):
+        step()
+    torch.cuda.synchronize()
+    steps = max(10, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.synchronize()
+    n_hyp = int(nout_t.item())
+    valid = int((ctx.frames()["valid"] != 0).sum())
+    k_ms = {}
+    if not args.no_events:  # per-kernel HIP events of a second, untimed pass
+        ctx.set_profile(1)
+        ctx.timing()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        k_ms = {k: v / steps for k, v in ctx.timing().items()}
+    ctx.close()
+    return {"workload": label, "points": sc.n, "samples": S, "frames": valid, "hypotheses": n_hyp, "steps": steps,
+            "ms_per_step": dt * 1e3, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_step": k_ms}
+
+
+def host_api_extra(args, dev, sc, normals_mode):
+    """What a caller of the HOST-buffer entry points pays (agh_set_cloud + agh_find_hands: the C++ adapter's
+    HandSearch::findHands, hand_search.h:101-104 takes a host cloud): upload of the cloud, grid build, search, read-back
+    of flags, count and records, two synchronisations.  SURVEY 8d asks for both figures; this one is never `value`."""
+    from agile_grasp_amd import binding
+
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    for _ in range(3):
+        ctx.set_cloud(sc.xyz, sc.cam)
+        hyps = ctx.find_hands(sc.samples)
+    calls = max(10, args.steps // 2)
+    t_set = t_find = 0.0
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        ctx.set_cloud(sc.xyz, sc.cam)
+        t1 = time.perf_counter()
+        hyps = ctx.find_hands(sc.samples)
+        t_set += t1 - t0
+        t_find += time.perf_counter() - t1
+    ctx.close()
+    dt = (t_set + t_find) / calls
+    return {"what": "agh_set_cloud (H2D of 12 B/point + camera ids, grid build) + agh_find_hands (search, D2H of count, flags and "
+                    "160-byte records), host numpy buffers in and out", "calls": calls, "ms_per_call": dt * 1e3,
+            "ms_set_cloud": t_set / calls * 1e3, "ms_find_hands": t_find / calls * 1e3, "value": len(hyps) / dt,
+            "unit": "hypotheses/s", "hypotheses": int(len(hyps))}
+
+
 def settle(ctx, step, fence):
     """Two untimed steps on every rank before anything is measured.  A context starts with the launches of the larger
     capacity classes switched off (they are empty for voxelised clouds); the first step of a cloud that needs them reports
@@ -211,6 +281,64 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
             "ms_per_step": dt / args.steps * 1e3, "value": n_hyp * args.steps / dt, "unit": "hypotheses/s", "hypotheses": n_hyp}
 
 
+def c4_sharded_secondary(args, dev, stream, rank, world, normals_mode):
+    """N > 1, a second extra key: BASELINE config C4 (1M points, 8000 samples) with its samples sharded over the GPUs --
+    strong scaling on the smallest configuration whose sample count warrants sharding; C2's 2000
+    samples, the headline, do not."""
+    import torch.distributed as dist
+
+    from agile_grasp_amd import binding, synthetic
+
+    sc = synthetic.config("C4")
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(binding.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    ctx.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+    S = sc.samples.size
+    xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
+    s_t = torch.from_numpy(sc.samples).to(dev)
+    out_t = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
+    nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.set_cloud_torch(xyz_t, cam_t, stream=stream)
+        ctx.find_hands_sharded_torch(s_t, out_t, nout_t, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    settle(ctx, step, fence)
+    steps = max(5, args.steps // 2)
+    for attempt in range(3):
+        for _ in range(max(args.warmup, 3)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        try:
+            ctx.synchronize()
+            break
+        except binding.AghError as e:
+            if e.code != binding.AGH_ERR_RETRY or attempt == 2:
+                raise
+    tv = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+    dt = float(tv[0].item())
+    n_hyp = int(nout_t.item())
+    ctx.comm_destroy()
+    ctx.close()
+    return {"workload": f"C4: two-view {sc.n}-point cloud, {S} samples sharded over {world} GPUs, one all-gather of the lists",
+            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": n_hyp * steps / dt,
+            "unit": "hypotheses/s", "hypotheses": n_hyp}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +354,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
     ap.add_argument("--batch-clouds", type=int, default=8,
                     help="N = 1: also time a batch of this many C5 clouds in one context (extra key 'batched'); 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the extra keys untilted / rand50 / host_api")
     ap.add_argument("--spin-seconds", type=float, default=0.5,
                     help="untimed run of the same step before the warm-up steps, so that the clocks are at their steady state")
     args = ap.parse_args()
@@ -407,7 +536,7 @@ def main():
         dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
         dt = float(tvals[0].item())
 
-    secondary, hung = None, False
+    secondary, secondary_c4, hung = None, None, False
     if distributed and (world > 1 or os.environ.get("AGH_BENCH_FORCE_SECONDARY") == "1") and lib_comm and not by_cloud \
             and base == "C2" and not classify:
         # never at the price of the headline line: the extra measurement runs on a watched thread
@@ -422,12 +551,18 @@ def main():
                 box["res"] = cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode)
             except Exception as e:
                 box["res"] = {"error": str(e)}
+            if "error" not in box["res"] and not args.no_extras:
+                try:
+                    box["c4"] = c4_sharded_secondary(args, dev, stream, rank, world, normals_mode)
+                except Exception as e:
+                    box["c4"] = {"error": str(e)}
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        th.join(timeout=120)
+        th.join(timeout=420)
         hung = th.is_alive()
-        secondary = {"error": "timed out"} if hung else box.get("res")
+        secondary = {"error": "timed out"} if hung and "res" not in box else box.get("res")
+        secondary_c4 = {"error": "timed out"} if hung else box.get("c4")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -443,20 +578,25 @@ def main():
         achieved = sweep_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
         traffic, traffic_src = None, None
         if not distributed:
-            for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+            import hashlib
+
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tf):
                     try:
-                        traffic = json.load(open(tf)).get(f"{args.config}:{args.normals}", {}).get("hand_sweep_bytes_per_launch")
+                        blob = open(tf, "rb").read()
+                        traffic = json.loads(blob).get(f"{args.config}:{args.normals}", {}).get("hand_sweep_bytes_per_launch")
                     except Exception:
                         traffic = None
                     if traffic is not None:
-                        traffic_src = (f"static: profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
-                                       "workload, gfx950 corrections applied); not measured in this run")
+                        traffic_src = (f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (separate rocprofv3 --pmc "
+                                       "FETCH_SIZE / WRITE_SIZE passes over this workload, gfx950 corrections applied); not measured in this run")
                         break
         # whole-path algorithmic bytes (B_alg of BASELINE.md section 4), of this rank's share
         b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_local_hyp + (14112 if classify else 0)
-        scaling = "weak" if by_cloud or not distributed else "strong"
+        # --shard samples (the default at every N, so also the N = 1 member of the driver's 1/2/4/8 series): the SAME cloud and
+        # sample list whatever N is -- total work fixed; --shard clouds: one more cloud per GPU
+        scaling = "weak" if by_cloud else "strong"
         par = "single GPU" if not distributed else (
             f"cloud-per-gpu x{world}: every rank searches its own cloud, one all-gather of the lists" if by_cloud else
             f"sample-sharded x{world}: rank g searches samples [g S/N, (g+1) S/N) of the same cloud, one all-gather of the lists")
@@ -489,6 +629,12 @@ def main():
         }
         if secondary is not None:
             res["cloud_per_gpu"] = secondary
+        if secondary_c4 is not None:
+            res["c4_sample_sharded"] = secondary_c4
+        if distributed and not by_cloud and base == "C2":
+            res["config"]["note"] = ("C2's 2000 samples do not warrant sharding (every rank still builds the whole grid and runs "
+                                     "the same latency chains: DESIGN.md section 6); the node's GPUs are used by cloud_per_gpu (weak) "
+                                     "and c4_sample_sharded (strong), reported beside this line")
         if distributed:
             res["config"]["exchange"] = exchange
             res["config"]["segment_records"] = seg[0] if not lib_comm else None
@@ -496,6 +642,16 @@ def main():
             res["config"]["svm_kept"] = n_kept
         if not distributed and args.batch_clouds > 1 and base == "C2":
             res["batched"] = batched_throughput(args, dev, stream, normals_mode, classify, svm)
+        if not distributed and base == "C2" and not classify and not args.no_extras:
+            # SURVEY 8d's scene to the letter (axis-aligned: 60 % of the samples are exactly planar neighbourhoods, which the
+            # reference does not drop and, since round 3, neither does this path), the reference's production normals mode
+            # (HandSearch hard-wires it, hand_search.h:84), and the host-buffer entry points
+            res["untilted"] = single_cloud_extra(args, dev, stream, "C2u", normals_mode,
+                                                 "C2u: the same scene axis-aligned (SURVEY 8d literally), deterministic normals")
+            if args.normals == "det":
+                res["rand50"] = single_cloud_extra(args, dev, stream, "C2", binding.NORMALS_RAND50,
+                                                   "C2, the reference's production mode: 50 x rand() % n normals per sample")
+            res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
         if not args.no_cpu_baseline and not distributed:
             res["cpu_baseline"] = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)
         elif not args.no_cpu_baseline:

@@ -29,7 +29,7 @@ class GraspHypothesis
 {
 public:
   GraspHypothesis() : cam_source_(-1), grasp_width_(0), full_antipodal_(false), half_antipodal_(false), device_index_(-1),
-    epoch_(0), n_points_for_learning_(0), points_fetched_(false)
+    local_index_(-1), epoch_(0), n_points_for_learning_(0), points_fetched_(false)
   {
   }
 
@@ -40,20 +40,24 @@ public:
     const std::vector<int>& indices_cam2, int cam_source)
     : axis_(axis), approach_(approach), binormal_(binormal), grasp_bottom_(bottom), grasp_surface_(surface),
       cam_source_(cam_source), grasp_width_(width), full_antipodal_(false), half_antipodal_(false), device_index_(-1),
-      epoch_(0), n_points_for_learning_((int) points_for_learning.cols()), points_fetched_(true),
+      local_index_(-1), epoch_(0), n_points_for_learning_((int) points_for_learning.cols()), points_fetched_(true),
       points_for_learning_(points_for_learning), indices_cam1_(indices_cam1), indices_cam2_(indices_cam2)
   {
   }
 
-  /** Built from one record of agh_find_hands; device_index = its position in that call's result list. */
+  /** Built from one record of agh_find_hands; device_index = its position in that call's result list.  A SHARDED search
+   *  returns the merged list of all ranks, but a rank's device keeps only the results (points, images) of its own samples:
+   *  local_index = the record's position in THIS rank's device-side list, or -1 if another rank searched its sample
+   *  (default: the same as device_index, the single-GPU case). */
   GraspHypothesis(const agh_hypothesis& h, long device_index,
-    const std::shared_ptr<detail::SearchLink>& link = std::shared_ptr<detail::SearchLink>())
+    const std::shared_ptr<detail::SearchLink>& link = std::shared_ptr<detail::SearchLink>(), long local_index = -2)
     : axis_(make_vec3(h.axis[0], h.axis[1], h.axis[2])), approach_(make_vec3(h.approach[0], h.approach[1], h.approach[2])),
       binormal_(make_vec3(h.binormal[0], h.binormal[1], h.binormal[2])),
       grasp_bottom_(make_vec3(h.bottom[0], h.bottom[1], h.bottom[2])),
       grasp_surface_(make_vec3(h.surface[0], h.surface[1], h.surface[2])), cam_source_(h.cam_source),
       grasp_width_(h.width), full_antipodal_(h.full_antipodal != 0), half_antipodal_(h.half_antipodal != 0),
-      device_index_(device_index), epoch_(h.epoch), n_points_for_learning_(h.n_in_box), points_fetched_(false), link_(link)
+      device_index_(device_index), local_index_(local_index == -2 ? device_index : local_index), epoch_(h.epoch),
+      n_points_for_learning_(h.n_in_box), points_fetched_(false), link_(link)
   {
   }
 
@@ -126,16 +130,19 @@ public:
   /** Position of this hypothesis in the device-side result list of the HandSearch call that produced it, and that
    *  call's stamp (agh_hypothesis::epoch). */
   long getDeviceIndex() const { return device_index_; }
+  /** Position in the device-side list of the context that searched this hypothesis' sample (what agh_get_learning_points
+   *  takes); -1 if that was another rank of a sharded search. */
+  long getLocalIndex() const { return local_index_; }
   int getEpoch() const { return epoch_; }
-  /** The device context that still holds this hypothesis' search results, or nullptr (search gone, re-created, or it has
-   *  run another findHands since). */
+  /** The device context that still holds this hypothesis' search results, or nullptr (search gone, re-created, it has run
+   *  another findHands since, or -- sharded search -- the results live on another rank). */
   agh_ctx* getLiveContext() const
   {
-    if (!link_ || !link_->ctx || device_index_ < 0)
+    if (!link_ || !link_->ctx || local_index_ < 0)
       return nullptr;
     std::int32_t e = 0;
     std::int64_t n = 0;
-    if (agh_get_epoch(link_->ctx, &e, &n) != AGH_OK || e != epoch_ || device_index_ >= n)
+    if (agh_get_epoch(link_->ctx, &e, &n) != AGH_OK || e != epoch_ || local_index_ >= n)
       return nullptr;
     return link_->ctx;
   }
@@ -193,8 +200,12 @@ private:
     agh_ctx* ctx = getLiveContext();
     if (!ctx)
     {
-      std::cout << " Error: getPointsForLearning: the search that produced this hypothesis no longer holds its cloud and "
-                   "results (it ran another findHands or was destroyed); fetch the points before the next search\n";
+      if (local_index_ < 0)
+        std::cout << " Error: getPointsForLearning: this hypothesis of a sharded search was found by another rank; its points "
+                     "live on that rank's GPU\n";
+      else
+        std::cout << " Error: getPointsForLearning: the search that produced this hypothesis no longer holds its cloud and "
+                     "results (it ran another findHands or was destroyed); fetch the points before the next search\n";
       return;
     }
     const std::size_t n_b = (std::size_t) n_points_for_learning_;
@@ -202,7 +213,7 @@ private:
     std::vector<double> dummy(3);
     std::int64_t n = 0;
     double* dst = resize_3xn(points_for_learning_, n_b);
-    if (agh_get_learning_points(ctx, device_index_, n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
+    if (agh_get_learning_points(ctx, local_index_, n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
     {
       std::cout << " Error in agh_get_learning_points: " << agh_last_error(ctx) << "\n";
       resize_3xn(points_for_learning_, 0);
@@ -219,7 +230,7 @@ private:
   int cam_source_;
   double grasp_width_;
   bool full_antipodal_, half_antipodal_;
-  long device_index_;
+  long device_index_, local_index_;
   int epoch_;
   int n_points_for_learning_;
   mutable bool points_fetched_;

@@ -101,7 +101,7 @@ public:
     std::int64_t n = 0;
     double* dst = resize_3xn(points_for_learning, n_b);
     std::vector<double> dummy(3);
-    if (agh_get_learning_points(ctx_, h.getDeviceIndex(), n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
+    if (agh_get_learning_points(ctx_, h.getLocalIndex(), n_b ? dst : dummy.data(), cam.data(), (std::int64_t) n_b, &n) != AGH_OK)
     {
       std::cout << " Error in agh_get_learning_points: " << agh_last_error(ctx_) << "\n";
       resize_3xn(points_for_learning, 0);
@@ -315,9 +315,22 @@ public:
       // every rank holds the complete list; the device-side state (images, points) of a hypothesis lives on the rank that
       // searched its sample, so the hypotheses carry no image here and Learning::classify goes through the collective
       // agh_classify_sharded (see learning.h)
+      // The records of THIS rank's samples (a contiguous run of the merged list: slices are contiguous and the list is
+      // sample-major) keep their position in this rank's own device-side list, so getPointsForLearning() and the index
+      // getters work for them; the others say that their points live on another rank.
+      std::int32_t rank = 0, n_ranks = 1;
+      std::int64_t lo = 0, hi = 0;
+      agh_comm_rank(ctx_, &rank, &n_ranks);
+      agh_shard_slice((std::int64_t) idx.size(), rank, n_ranks, &lo, &hi);
+      std::int64_t first = 0;
+      while (first < n_out && out[(std::size_t) first].sample < lo)
+        first++;
       hand_list.reserve((std::size_t) n_out);
       for (std::int64_t i = 0; i < n_out; i++)
-        hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i, link_));
+      {
+        const std::int64_t smp = out[(std::size_t) i].sample;
+        hand_list.push_back(GraspHypothesis(out[(std::size_t) i], (long) i, link_, (smp >= lo && smp < hi) ? (long) (i - first) : -1L));
+      }
       std::cout << " Found " << hand_list.size() << " robot hand poses\n";
       return hand_list;
     }

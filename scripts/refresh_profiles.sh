@@ -8,12 +8,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 for cfg in C2 C3 C4; do
   rm -rf /tmp/kt_$cfg
   # (--batch-clouds 0: every k_hand_sweep launch of the trace is the single-cloud launch the bench line's roofline describes)
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$cfg -o kt -- python $R/bench.py --config $cfg --steps 50 --warmup 5 \
-    --no-events --no-cpu-baseline --batch-clouds 0 > /tmp/kt_$cfg.log 2>&1
+    --no-events --no-cpu-baseline --no-extras --batch-clouds 0 > /tmp/kt_$cfg.log 2>&1
   db=$(find /tmp/kt_$cfg -name "*.db" | head -1)
   [ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_$(echo $cfg | tr A-Z a-z)_kernel_trace_stats.csv > /dev/null
 done
@@ -26,7 +26,7 @@ db=$(find /tmp/kt_batch -name "*.db" | head -1)
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o pmc -- python $R/bench.py --config C2 --steps 10 --warmup 2 \
-    --no-events --no-cpu-baseline --batch-clouds 0 --spin-seconds 0 > /tmp/pmc_$ctr.log 2>&1
+    --no-events --no-cpu-baseline --no-extras --batch-clouds 0 --spin-seconds 0 > /tmp/pmc_$ctr.log 2>&1
 done
 rm -rf /tmp/pmc_sq
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \

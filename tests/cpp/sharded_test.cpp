@@ -83,5 +83,29 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < kept[(size_t) g].size(); i++)
       std::printf("K%d %ld\n", g, kept[(size_t) g][i].getDeviceIndex());
   }
+  // GraspHypothesis::getPointsForLearning after a sharded search: the points live on the rank that searched the sample;
+  // exactly one rank serves each hypothesis, the others say so (the merged index used to be taken for a local one)
+  for (size_t i = 0; i < hands[0].size(); i += 5)
+  {
+    int owners = 0, owner = -1;
+    for (int g = 0; g < G; g++)
+      if (hands[(size_t) g][i].getLocalIndex() >= 0)
+      {
+        owners++;
+        owner = g;
+      }
+    double sum = 0.0;
+    long cols = -1, foreign_cols = 0;
+    if (owners == 1)
+    {
+      const Matrix3Xd& pts = hands[(size_t) owner][i].getPointsForLearning();
+      cols = (long) pts.cols();
+      for (long c = 0; c < cols; c++)
+        for (int r = 0; r < 3; r++)
+          sum += pts(r, (size_t) c);
+      foreign_cols = (long) hands[(size_t) ((owner + 1) % G)][i].getPointsForLearning().cols();  // prints why, returns empty
+    }
+    std::printf("P %zu %d %ld %d %ld %.17g\n", i, owners, cols, hands[0][i].getNumPointsForLearning(), G > 1 ? foreign_cols : 0L, sum);
+  }
   return 0;
 }

@@ -249,3 +249,10 @@ def test_cpp_adapter_sharded_search(tmp_path, small_scene, svm_model):
         assert f"RANK {g} {len(hyps)} {int(keep.sum())}" in lines
         assert [[float(v) for v in l.split()[1:]] for l in lines if l.startswith(f"H{g} ")] == exp
         assert [int(l.split()[1]) for l in lines if l.startswith(f"K{g} ")] == list(np.nonzero(keep)[0])
+    # the lazy point getters: one owner per hypothesis, its points are the single-GPU search's, the other ranks return none
+    plines = [l.split() for l in lines if l.startswith("P ")]
+    assert len(plines) == (len(hyps) + 4) // 5
+    for _p, i, owners, cols, n_box, foreign, total in plines:
+        pts, _cam = ctx.learning_points(int(i))
+        assert int(owners) == 1 and int(cols) == int(n_box) == pts.shape[1] and int(foreign) == 0
+        assert float(total) == (float(np.cumsum(pts.T.reshape(-1))[-1]) if pts.size else 0.0)  # sequential sum, point-major
