@@ -30,7 +30,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf /tmp/pmc_sq
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
-  SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_sq -o sq -- python $R/bench.py --config C2 --steps 10 --warmup 2 --no-events --no-cpu-baseline \
+  SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_sq -o sq -- python $R/bench.py --config C2 --steps 10 --warmup 2 --no-events --no-cpu-baseline --no-extras \
   --batch-clouds 0 --spin-seconds 0 > /tmp/pmc_sq.log 2>&1
 q=$(find /tmp/pmc_sq -name "*.db" | head -1); [ -n "$q" ] && python $R/scripts/pmc_table.py $q > $OUT/${TAG}_c2_sq_counters.txt
 f=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
