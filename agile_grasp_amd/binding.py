@@ -84,7 +84,7 @@ EXPORTS = [
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
-    "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images",
+    "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images", "agh_comm_rccl_origin",
     "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_set_segment_records",
     "agh_shard_slice", "agh_find_hands_sharded_device", "agh_find_hands_sharded", "agh_classify_sharded_device",
     "agh_classify_sharded",

@@ -691,24 +691,13 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     __threadfence_block();
     if (lane == 0)
     {
-      double A[3][3] = { { sM3[0], sM3[1], sM3[2] }, { sM3[1], sM3[3], sM3[4] }, { sM3[2], sM3[4], sM3[5] } };
-      double V[3][3], dd[3];
-      if (debug_stop == 6 || debug_stop == 7)
-      {
-        for (int r = 0; r < 3; r++)
-          for (int q = 0; q < 3; q++)
-            V[r][q] = (r == q) ? 1.0 : 0.0;
-        dd[0] = dd[1] = dd[2] = 0.0;
-      }
-      else
-        jacobi3_serial(A, V, dd);
-      int mi = 0;
-      for (int r = 1; r < 3; r++)
-        if (dd[r] < dd[mi])
-          mi = r;
-      sAxis[0] = V[0][mi];
-      sAxis[1] = V[1][mi];
-      sAxis[2] = V[2][mi];
+      const double m3[6] = { sM3[0], sM3[1], sM3[2], sM3[3], sM3[4], sM3[5] };
+      double ax[3] = { 1.0, 0.0, 0.0 };
+      if (!(debug_stop == 6 || debug_stop == 7))
+        smallest_eigvec3(m3, ax);
+      sAxis[0] = ax[0];
+      sAxis[1] = ax[1];
+      sAxis[2] = ax[2];
     }
   };
   // ---- argmax_j sum_i (n_i . n_j)^6 (quadric.cpp:283-284) by filter-and-refine ----
@@ -722,12 +711,86 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   // With at most 64 normals (always in the reference's production mode, which subsamples 50) a column's exact sum is
   // one term per lane plus the butterfly: evaluating all columns exactly is cheaper than estimating them first
   // (measured; with up to 128 it is not).
-  if (ks <= 64)
+  // Round 3: with at most 64 normals the columns are not queued at all -- ONE wave evaluates them all at once, a column per
+  // lane: lane j walks the 64 leaves of the LaneSum64 tree of ITS column (terms i = 0 .. ks - 1, zeros beyond) in
+  // bit-reversed order and combines them pairwise on a six-deep register stack, which is the butterfly's order of
+  // additions exactly (p[l] + p[l + o], o = 32 .. 1).  The normals are LDS broadcasts.  The queue gave every column a
+  // round trip of its own (an LDS atomic, a 6-step ds_bpermute butterfly): 23 us for 50 columns, the kernel's critical
+  // path in the production mode; this is ~1.5 us, and runs on the last wave while wave 0 finds the axis.
+  // (only in the classes made for few normals -- the production mode's and the all-points pass's; in the large classes a
+  // sample with at most 64 neighbours is rare and takes the queue, so that their register budgets stay what they were)
+  constexpr bool kSmallCols = CAP <= 128;
+  const bool small_cols = kSmallCols && ks <= 64;
+  double small_best = -1.0;
+  int small_best_j = 0x7fffffff;
+  if (!kSmallCols && ks <= 64)
   {
     for (int j = tid; j < ks; j += THREADS)
       cand[j] = (unsigned short) j;
     if (tid == 0)
       ncand = ks;
+  }
+  else if (small_cols)
+  {
+    if (tid == 0)
+      ncand = 0;
+    if (wave == NW - 1)
+    {
+      const int j = lane < ks ? lane : 0;
+      const double jx = nx[j], jy = ny[j], jz = nz[j];
+      // visit counter c = 8 b + k: leaf i = bitrev6(c) = (bitrev3(k) << 3) | bitrev3(b).  The eight leaves of a block close
+      // three levels of the tree among themselves (unrolled: a three-deep stack in registers); the block sums are combined
+      // by the same counter scheme one level up (b is uniform: plain branches).
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+      for (int b = 0; b < 8; b++)
+      {
+        const int br = ((b & 1) << 2) | (b & 2) | ((b & 4) >> 2);
+        double stk[4];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+          const int i = ((((k & 1) << 2) | (k & 2) | ((k & 4) >> 2)) << 3) | br;
+          const int ii = i < ks ? i : 0;
+          const double gdot = (nx[ii] * jx + ny[ii] * jy) + nz[ii] * jz;
+          const double g2 = gdot * gdot;
+          double v = i < ks ? (g2 * g2) * g2 : 0.0;
+          int depth = __builtin_popcount(k);
+#pragma unroll
+          for (int m = 0; m < 3; m++)
+            if (((k >> m) & 1) && ((k & ((1 << m) - 1)) == ((1 << m) - 1)))
+            {
+              depth--;
+              v = stk[depth] + v;  // the earlier (lower-index) half is the left operand
+            }
+          stk[depth] = v;
+        }
+        double v = stk[0];
+        if (b & 1)
+        {
+          v = s0 + v;
+          if (b & 2)
+          {
+            v = s1 + v;
+            if (b & 4)
+              v = s2 + v;
+            else
+              s2 = v;
+          }
+          else
+            s1 = v;
+        }
+        else
+          s0 = v;
+        if (b == 7)
+          s0 = v;
+      }
+      if (lane < ks)
+      {
+        small_best = s0;
+        small_best_j = lane;
+      }
+    }
   }
   else if (CAP <= 64)
     ;  // (this instantiation never estimates: the branch below would only cost it registers)
@@ -752,12 +815,17 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
           py[k] = py[k - 1] * y;
           pz[k] = pz[k - 1] * z;
         }
+        // (an ESTIMATE: it only selects the columns that get the exact sum, with a margin hundreds of times its error --
+        // so its multiply-adds may be fused: one product and one fma per moment)
         int k = 0;
   #pragma unroll
         for (int a = 6; a >= 0; a--)
   #pragma unroll
           for (int b = 6 - a; b >= 0; b--)
-            T[k++] += (px[a] * py[b]) * pz[6 - a - b];
+          {
+            T[k] = fma(px[a], py[b] * pz[6 - a - b], T[k]);
+            k++;
+          }
       }
       // Wave reduction of the 28 moments by a halving butterfly: in the step with partner distance o a lane keeps one
       // half of its values and receives the partner's copies of that half, so 16 + 8 + 4 + 2 + 1 + 1 exchanges do what 28
@@ -819,19 +887,25 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
         if (j < ks)
         {
           const double x = nx[j], y = ny[j], z = nz[j];
-          double px[7], py[7], pz[7];
-          px[0] = py[0] = pz[0] = 1.0;
+          // sum_a x^a sum_b W_ab y^b z^(6-a-b) by nested Horner schemes with fused multiply-adds (an estimate, see above):
+          // W[base(a) + j] belongs to y^(6-a-j) z^j, so the inner scheme runs down in y with the powers of z as weights
+          double pz[7];
+          pz[0] = 1.0;
+  #pragma unroll
           for (int k = 1; k < 7; k++)
-          {
-            px[k] = px[k - 1] * x;
-            py[k] = py[k - 1] * y;
             pz[k] = pz[k - 1] * z;
-          }
           e_ = 0.0;
-          int k = 0;
+          int base = 0;
+  #pragma unroll
           for (int a = 6; a >= 0; a--)
-            for (int b = 6 - a; b >= 0; b--)
-              e_ += W[k++] * ((px[a] * py[b]) * pz[6 - a - b]);
+          {
+            double r = W[base];
+  #pragma unroll
+            for (int jz = 1; jz <= 6 - a; jz++)
+              r = fma(r, y, W[base + jz] * pz[jz]);
+            e_ = fma(e_, x, r);
+            base += 7 - a;
+          }
           if (!(e_ == e_))
             e_ = 1e300;  // NaN normals: keep every such column as a candidate (exhaustive fallback)
         }
@@ -908,6 +982,11 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       best = acc;
       best_j = j;
     }
+  }
+  if (small_cols && wave == NW - 1)
+  {
+    best = small_best;
+    best_j = small_best_j;
   }
   if (debug_stop == 4)
     return;

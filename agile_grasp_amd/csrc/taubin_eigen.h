@@ -345,4 +345,87 @@ AGH_EIG_TEMPLATE __device__ __forceinline__ double taubin_smallest_eigenpair(con
   return sigma;
 }
 
+
+// The unit eigenvector of the smallest eigenvalue of the symmetric 3 x 3 matrix M3 = sum n n^T (quadric.cpp:266-280), one
+// lane: one Householder reflection, bisection on the Sturm sequence, twisted factorisation (the oracle's
+// smallest_eigvec3, operation for operation).  m = { M00, M01, M02, M11, M12, M22 }.
+__device__ __forceinline__ void smallest_eigvec3(const double (&m)[6], double (&axis)[3])
+{
+  const double x0 = m[1], x1 = m[2];
+  const double sg = fma(x1, x1, x0 * x0);
+  const double rt = sqrt(sg);
+  const double g = (x0 >= 0.0) ? -rt : rt;
+  const double h = fma(-x0, g, sg);
+  const bool live = h > 0.0;
+  const double rh = live ? 1.0 / h : 0.0;
+  const double u1 = live ? x0 - g : 0.0, u2 = live ? x1 : 0.0;
+  const double p1 = fma(m[4], u2, m[3] * u1) * rh;
+  const double p2 = fma(m[5], u2, m[4] * u1) * rh;
+  const double kk = (fma(u2, p2, u1 * p1) * rh) * 0.5;
+  const double q1 = fma(-kk, u1, p1), q2 = fma(-kk, u2, p2);
+  const double d0 = m[0], d1 = fma(-q1, u1, fma(-u1, q1, m[3])), d2 = fma(-q2, u2, fma(-u2, q2, m[5]));
+  const double e0 = live ? g : x0, e1 = fma(-q2, u1, fma(-u2, q1, m[4]));
+  const double e20 = e0 * e0, e21 = e1 * e1;
+  const double r0 = fabs(e0), r1 = fabs(e0) + fabs(e1), r2 = fabs(e1);
+  double lo = d0 - r0, hi = d0;
+  lo = (d1 - r1 < lo) ? d1 - r1 : lo;
+  lo = (d2 - r2 < lo) ? d2 - r2 : lo;
+  hi = (d1 < hi) ? d1 : hi;
+  hi = (d2 < hi) ? d2 : hi;
+#pragma unroll 1
+  for (int it = 0; it < kBisectSteps; it++)
+  {
+    const double mid = fma(hi - lo, 0.5, lo);
+    const double s1 = d0 - mid;
+    const double s2 = fma(d1 - mid, s1, -e20);
+    const double s3 = fma(d2 - mid, s2, -(e21 * s1));
+    const bool below = ((__double2hiint(s1) | __double2hiint(s2)) | __double2hiint(s3)) < 0;
+    hi = below ? mid : hi;
+    lo = below ? lo : mid;
+  }
+  const double sigma = lo;
+  const double Dp0 = pivot_floor(d0 - sigma);
+  const double lf0 = e0 / Dp0;
+  const double Dp1 = pivot_floor(fma(-lf0, e0, d1 - sigma));
+  const double lf1 = e1 / Dp1;
+  const double Dp2 = pivot_floor(fma(-lf1, e1, d2 - sigma));
+  const double Dm2 = pivot_floor(d2 - sigma);
+  const double ub1 = e1 / Dm2;
+  const double Dm1 = pivot_floor(fma(-ub1, e1, d1 - sigma));
+  const double ub0 = e0 / Dm1;
+  const double Dm0 = pivot_floor(fma(-ub0, e0, d0 - sigma));
+  const double g0 = fabs((Dp0 + Dm0) - (d0 - sigma)), g1 = fabs((Dp1 + Dm1) - (d1 - sigma)), g2 = fabs((Dp2 + Dm2) - (d2 - sigma));
+  int ks = 0;
+  double gmin = g0;
+  ks = (g1 < gmin) ? 1 : ks;
+  gmin = (g1 < gmin) ? g1 : gmin;
+  ks = (g2 < gmin) ? 2 : ks;
+  // z_ks = 1; below it z_i = -lf_i z_i+1, above it z_i+1 = -ub_i z_i
+  double z0, z1, z2;
+  if (ks == 0)
+  {
+    z0 = 1.0;
+    z1 = -(ub0 * z0);
+    z2 = -(ub1 * z1);
+  }
+  else if (ks == 1)
+  {
+    z1 = 1.0;
+    z0 = -(lf0 * z1);
+    z2 = -(ub1 * z1);
+  }
+  else
+  {
+    z2 = 1.0;
+    z1 = -(lf1 * z2);
+    z0 = -(lf0 * z1);
+  }
+  const double sdot = fma(u2, z2, u1 * z1) * rh;
+  const double y0 = z0, y1 = fma(-sdot, u1, z1), y2 = fma(-sdot, u2, z2);
+  const double nn = sqrt(fma(y2, y2, fma(y1, y1, y0 * y0)));
+  axis[0] = y0 / nn;
+  axis[1] = y1 / nn;
+  axis[2] = y2 / nn;
+}
+
 }  // namespace agh

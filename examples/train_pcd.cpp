@@ -1,5 +1,8 @@
-// train_pcd.cpp -- what src/nodes/train.cpp does, without ROS/boost: collect hands with antipodal labels from a set of
-// two-view PCD captures, train the SVM on their grasp images, write the OpenCV model file.
+// train_pcd.cpp -- DEMO of the kept API, not part of the hot-path scope (the reference's CLI nodes are out
+// of scope; this file only shows that a caller written against Localization / Learning compiles and runs unchanged).
+// What src/nodes/train.cpp does, without ROS/boost: collect hands with antipodal labels from a set of two-view PCD captures,
+// train the SVM on their grasp images, write the OpenCV model file.  With the reference's default `uses_clustering = true`
+// the search returns nothing (the RANSAC table-plane removal is not built: INTEGRATION.md); this demo passes false.
 //
 //   g++ -std=c++11 -O2 -Iinclude examples/train_pcd.cpp -o train_pcd -Lagile_grasp_amd/lib -lagile_grasp_hip
 //       -Wl,-rpath,$PWD/agile_grasp_amd/lib -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib

@@ -677,6 +677,97 @@ inline double pow6(double v, int libm)
 }
 
 /* ---------------------------------------------------------------------------------------------------
+ * Eigen::EigenSolver on M3 = sum n n^T (quadric.cpp:268-280) -- THIRD PARTY -- as far as the reference uses it: the unit
+ * eigenvector of the smallest eigenvalue (its sign cancels at quadric.cpp:291-304).  Same scheme as solve_taubin, for a
+ * symmetric 3 x 3: one Householder reflection to tridiagonal form, the smallest eigenvalue by bisection on the Sturm
+ * sequence inside its Gershgorin bracket, the eigenvector from the twisted factorisation, back-transformed and
+ * normalised; every multiply-add fused.  (Round 2 ran a cyclic Jacobi here: ~20 us of dependent divisions and square roots
+ * on one GPU lane per sample.)  Pinned against numpy.linalg.eig (LAPACK dgeev) by tests/golden/e2e_lapack.npz.
+ * A double smallest eigenvalue (all normals parallel: exactly planar patches) leaves the direction inside the
+ * eigenspace to this arithmetic, as it is left to the solver's in the reference; an exactly diagonal M3 = diag(0, 0, n)
+ * yields the x axis, as EigenSolver's identity eigenvectors would.
+ * ------------------------------------------------------------------------------------------------- */
+void smallest_eigvec3(const double M3[3][3], double axis[3])
+{
+  /* Householder: zero the (2,0) entry */
+  const double x0 = M3[1][0], x1 = M3[2][0];
+  const double sg = std::fma(x1, x1, x0 * x0);
+  const double rt = std::sqrt(sg);
+  const double g = (x0 >= 0.0) ? -rt : rt;
+  const double h = std::fma(-x0, g, sg);
+  const bool live = h > 0.0;
+  const double rh = live ? 1.0 / h : 0.0;
+  const double u1 = live ? x0 - g : 0.0, u2 = live ? x1 : 0.0;
+  /* p = A22 u / h, kk = u.p / (2h), q = p - kk u, A22 -= u q^T + q u^T (lower triangle) */
+  const double p1 = std::fma(M3[2][1], u2, M3[1][1] * u1) * rh;
+  const double p2 = std::fma(M3[2][2], u2, M3[2][1] * u1) * rh;
+  const double kk = (std::fma(u2, p2, u1 * p1) * rh) * 0.5;
+  const double q1 = std::fma(-kk, u1, p1), q2 = std::fma(-kk, u2, p2);
+  const double d[3] = { M3[0][0], std::fma(-q1, u1, std::fma(-u1, q1, M3[1][1])), std::fma(-q2, u2, std::fma(-u2, q2, M3[2][2])) };
+  const double e[2] = { live ? g : x0, std::fma(-q2, u1, std::fma(-u2, q1, M3[2][1])) };
+  const double e2[2] = { e[0] * e[0], e[1] * e[1] };
+  /* bisection in [min_i (d_i - |e_i-1| - |e_i|), min_i d_i] */
+  const double r0 = std::fabs(e[0]), r1 = std::fabs(e[0]) + std::fabs(e[1]), r2 = std::fabs(e[1]);
+  double lo = d[0] - r0, hi = d[0];
+  if (d[1] - r1 < lo)
+    lo = d[1] - r1;
+  if (d[2] - r2 < lo)
+    lo = d[2] - r2;
+  if (d[1] < hi)
+    hi = d[1];
+  if (d[2] < hi)
+    hi = d[2];
+  for (int it = 0; it < kBisectSteps; it++)
+  {
+    const double mid = std::fma(hi - lo, 0.5, lo);
+    const double s1 = d[0] - mid;
+    const double s2 = std::fma(d[1] - mid, s1, -e2[0]);
+    const double s3 = std::fma(d[2] - mid, s2, -(e2[1] * s1));
+    if (std::signbit(s1) || std::signbit(s2) || std::signbit(s3))
+      hi = mid;
+    else
+      lo = mid;
+  }
+  const double sigma = lo;
+  /* twisted factorisation of T - sigma I */
+  double Dp[3], Dm[3], lf[2], ub[2];
+  Dp[0] = pivot_floor(d[0] - sigma);
+  lf[0] = e[0] / Dp[0];
+  Dp[1] = pivot_floor(std::fma(-lf[0], e[0], d[1] - sigma));
+  lf[1] = e[1] / Dp[1];
+  Dp[2] = pivot_floor(std::fma(-lf[1], e[1], d[2] - sigma));
+  Dm[2] = pivot_floor(d[2] - sigma);
+  ub[1] = e[1] / Dm[2];
+  Dm[1] = pivot_floor(std::fma(-ub[1], e[1], d[1] - sigma));
+  ub[0] = e[0] / Dm[1];
+  Dm[0] = pivot_floor(std::fma(-ub[0], e[0], d[0] - sigma));
+  int ks = 0;
+  double gmin = std::fabs((Dp[0] + Dm[0]) - (d[0] - sigma));
+  for (int k = 1; k < 3; k++)
+  {
+    const double gk = std::fabs((Dp[k] + Dm[k]) - (d[k] - sigma));
+    if (gk < gmin)
+    {
+      ks = k;
+      gmin = gk;
+    }
+  }
+  double z[3] = { 0.0, 0.0, 0.0 };
+  z[ks] = 1.0;
+  for (int i = ks - 1; i >= 0; i--)
+    z[i] = -(lf[i] * z[i + 1]);
+  for (int i = ks; i < 2; i++)
+    z[i + 1] = -(ub[i] * z[i]);
+  /* y = H z, normalised */
+  const double sdot = std::fma(u2, z[2], u1 * z[1]) * rh;
+  const double y0 = z[0], y1 = std::fma(-sdot, u1, z[1]), y2 = std::fma(-sdot, u2, z[2]);
+  const double nn = std::sqrt(std::fma(y2, y2, std::fma(y1, y1, y0 * y0)));
+  axis[0] = y0 / nn;
+  axis[1] = y1 / nn;
+  axis[2] = y2 / nn;
+}
+
+/* ---------------------------------------------------------------------------------------------------
  * a3+a4+a5  Quadric::fitQuadric -> findTaubinNormalAxis -> findAverageNormalAxis
  * (quadric.cpp:14-157, 159-251, 263-305) for one sample.  draws = the glibc rand() values this sample
  * consumes in ORC_NORMALS_RAND50 mode (quadric.cpp:184), or nullptr for the deterministic mode.
@@ -766,13 +857,8 @@ void fit_frame(const orc_params& P, const Cloud& cl, const std::vector<Neighbor>
       M3[r][q] = acc.total();
       M3[q][r] = M3[r][q];
     }
-  double V3[3][3], d3[3];
-  jacobi_sym<3>(M3, V3, d3);
-  int mi = 0;
-  for (int r = 1; r < 3; r++)
-    if (d3[r] < d3[mi])
-      mi = r;
-  double axis[3] = { V3[0][mi], V3[1][mi], V3[2][mi] };
+  double axis[3];
+  smallest_eigvec3(M3, axis);
 
   /* max_index: argmax_j sum_i (n_i . n_j)^6, first maximum wins (quadric.cpp:283-284) */
   int max_index = 0;
