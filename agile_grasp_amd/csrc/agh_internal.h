@@ -92,7 +92,7 @@ enum SampleStatus : int
 {
   kStatusOk = 0,
   kStatusOverflow = 1,    // neighbourhood larger than the kernel's LDS capacity
-  kStatusDegenerate = 2,  // N9 not positive definite: no frame, no hypotheses
+  kStatusDegenerate = 2,  // no frame (an empty neighbourhood; rank-deficient pencils DO get one since round 3): no hypotheses
   kStatusRows = 3,
   kStatusBadIndex = 4     // sample index outside the cloud (device-resident sample lists are validated on the device)
 };

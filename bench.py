@@ -651,6 +651,8 @@ def main():
             if args.normals == "det":
                 res["rand50"] = single_cloud_extra(args, dev, stream, "C2", binding.NORMALS_RAND50,
                                                    "C2, the reference's production mode: 50 x rand() % n normals per sample")
+                res["untilted_rand50"] = single_cloud_extra(args, dev, stream, "C2u", binding.NORMALS_RAND50,
+                                                            "C2u (axis-aligned) in the reference's production mode")
             res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
         if not args.no_cpu_baseline and not distributed:
             res["cpu_baseline"] = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)

@@ -75,7 +75,7 @@ typedef struct orc_frame
   int32_t n_nb;
   int32_t majority_cam;
   int32_t max_index;  /* argmax column of quadric.cpp:283-284 */
-  int32_t valid;      /* 0 if the 9x9 reduction is not positive definite */
+  int32_t valid;      /* 0 only for an empty neighbourhood (rank-deficient pencils are deflated, not dropped) */
 } orc_frame;
 
 /* a2: exact radius search; output sorted ascending by (float d2, index). Returns count (may exceed cap). */
