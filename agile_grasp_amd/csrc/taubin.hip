@@ -12,10 +12,11 @@
 //                          SEQUENTIALLY in that order (56-neighbour chunks: all four waves form the products, 37 lanes
 //                          run the 37 dependent add chains) -- the same fp64 operation order as the reference loop, so
 //                          the sums are bit-identical to the CPU path.
-//   k_taubin_eigen         four samples per wave, 9 lanes each: builds M, N, reduces the 10x10 pencil to the 9x9
-//                          symmetric-definite problem, Cholesky in LDS, round-robin Jacobi in registers without a
-//                          divergent branch (same rotation order and arithmetic as the CPU path), smallest eigenpair
-//                          -> quadric parameters.  One extra work-group sorts the samples longest-first.
+//   k_taubin_eigen         one sample per LANE (taubin_eigen.h): eliminates the 10th unknown, Cholesky of N9 with deflation of
+//                          rank-deficient coordinates, in-place reduction, Householder tridiagonalisation, bisection,
+//                          twisted factorisation -> the ONE eigenpair the reference uses -> quadric parameters; every
+//                          multiply-add fused, the oracle's loop nest verbatim.  One extra work-group sorts the samples
+//                          longest-first.
 //   k_taubin_frame         one workgroup per sample: quadric-gradient normals; the 3x3 scatter of the normals and the
 //                          n x n (n_i . n_j)^6 column sums in the oracle's LaneSum64 order (64 interleaved partials +
 //                          tree), the latter only for the columns a moment-based estimate cannot rule out; argmax,
