@@ -376,11 +376,13 @@ struct RowTable
 // starts from is off by < 1e-8 m) -- and rows the slab misses are dropped: half the candidates and half the row segments
 // of the plain ball at C2.  The caller's exact test still decides every point; this only prunes what it never accepts.
 constexpr double kSlabMargin = 1e-6;
+// `gpre`: the query's grid descriptor if the caller has loaded it already (so that the load could be issued before other
+// loads the caller had to wait for).
 template <bool SLAB = false>
 __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float qy, float qz, double rpad, RowTable& rt,
-  const double* slab_axis = nullptr, double slab_hh = 0.0)
+  const double* slab_axis = nullptr, double slab_hh = 0.0, const GridDesc* gpre = nullptr)
 {
-  const GridDesc& g = *gv.desc;
+  const GridDesc& g = gpre ? *gpre : *gv.desc;
   const int tid = threadIdx.x;
   const int lx = cell_coord(g, (double) qx - rpad, 0), hx = cell_coord(g, (double) qx + rpad, 0);
   const int ly = cell_coord(g, (double) qy - rpad, 1), hy = cell_coord(g, (double) qy + rpad, 1);
@@ -396,7 +398,9 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
   {
     for (int t = tid; t < nrows; t += blockDim.x)
     {
-      const int cy = ly + t % ny, cz = lz + t / ny;
+      // (t / ny for ny <= 9, t < 128, without the ~40-instruction integer division: exact in float)
+      const int tq = (int) (((float) t + 0.5f) * (1.0f / (float) ny));
+      const int cy = ly + (t - tq * ny), cz = lz + tq;
       // distance from q to the row's (y,z) slab; rows that cannot touch the ball are skipped
       const double y0 = g.mn[1] + cy * g.cell, z0 = g.mn[2] + cz * g.cell;
       const double dy = fmax(fmax(y0 - (double) qy, (double) qy - (y0 + g.cell)), 0.0);
@@ -423,7 +427,8 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
           const double ax = slab_axis[0];
           if (fabs(ax) > 1e-9)
           {
-            const double b1 = lo_n / ax, b2 = hi_n / ax;
+            const double inv_ax = 1.0 / ax;  // (one division instead of two: these bounds only prune, with kSlabMargin to spare)
+            const double b1 = lo_n * inv_ax, b2 = hi_n * inv_ax;
             xlo = fmax(xlo, ((double) qx + fmin(b1, b2)) - kSlabMargin);
             xhi = fmin(xhi, ((double) qx + fmax(b1, b2)) + kSlabMargin);
             keep = xlo <= xhi;

@@ -172,6 +172,18 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
   AGH_STAMP(0);
+  // The work-group's first microseconds are a chain of dependent loads (frame -> grid descriptor -> cell table -> points).
+  // Everything that does not depend on the frame is ISSUED before the frame is waited for: the geometry words this thread
+  // stages, the sample's grid descriptor, the hand angles.
+  constexpr int kGeomWords = (int) (sizeof(HandGeom) / 4), kGeomPer = (kGeomWords + 255) / 256;
+  unsigned gw[kGeomPer];
+#pragma unroll
+  for (int k = 0; k < kGeomPer; k++)
+    gw[k] = (tid + 256 * k) < kGeomWords ? ((const unsigned*) geom_p)[tid + 256 * k] : 0u;
+  gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));  // the sample's cloud of the batch
+  const GridDesc gd = *gv.desc;
+  const int to = tid / 9, tij = tid - 9 * to;  // thread (o, i, j) of the 72 entries of frame_ * rot^T (below)
+  const double t_cs = tid < 72 ? geom_p->cos_a[to] : 0.0, t_sn = tid < 72 ? geom_p->sin_a[to] : 0.0;
   const agh_frame F = frames[s];
   if (!F.valid)
   {
@@ -191,8 +203,10 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     return;
   }
   // stage the geometry tables in LDS
-  for (int k = tid; k < (int) (sizeof(HandGeom) / 4); k += 256)
-    ((unsigned*) &G)[k] = ((const unsigned*) geom_p)[k];
+#pragma unroll
+  for (int k = 0; k < kGeomPer; k++)
+    if ((tid + 256 * k) < kGeomWords)
+      ((unsigned*) &G)[tid + 256 * k] = gw[k];
   if (tid == 0)
   {
     cnt_crop = 0;
@@ -205,22 +219,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   for (int k = tid; k < kImgPlanes * (kImageWords + 2); k += 256)
     (&img[0][0])[k] = 0u;
   const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
-  gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));  // the sample's cloud of the batch
-  // only the rows (and the parts of rows) that can hold a point of the hand's slab |axis . (p - sample)| < hand_height
-  build_rows<true>(gv, sx, sy, sz, rpad, rt, F.axis, geom_p->hand_height);  // ends with barriers: G and counters are visible afterwards
-  if (tid < 64)
-    thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
-  if (tid < 24)
-    dep_s[tid] = tid < G.n_depths ? G.depths[tid] : INFINITY;
-  if (rt.bad)
-  {
-    if (tid == 0)
-    {
-      status[s] = kStatusRows;
-      vmask[s] = 0;
-    }
-    return;
-  }
   // frame_ << normal, normal x axis, axis (rotating_hand.cpp:24-25); column r of fr is fr[.][r]
   double fr[3][3];
   {
@@ -234,6 +232,34 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       fr[r][2] = ax[r];
     }
   }
+  // frame_ * rot^T of the eight orientations (rotating_hand.cpp:89-96), an entry per thread, while the row table's loads are
+  // in flight (eight threads used to form all 72 entries one after the other behind it)
+  if (tid < 72)
+  {
+    const int i = tij / 3, j = tij - 3 * i;
+    const double rj0 = j == 0 ? t_cs : (j == 1 ? t_sn : 0.0);
+    const double rj1 = j == 0 ? -1.0 * t_sn : (j == 1 ? t_cs : 0.0);
+    const double rj2 = j == 2 ? 1.0 : 0.0;
+    const double fi0 = i == 0 ? fr[0][0] : (i == 1 ? fr[1][0] : fr[2][0]);
+    const double fi1 = i == 0 ? fr[0][1] : (i == 1 ? fr[1][1] : fr[2][1]);
+    const double fi2 = i == 0 ? fr[0][2] : (i == 1 ? fr[1][2] : fr[2][2]);
+    ori[to].T[i][j] = (fi0 * rj0 + fi1 * rj1) + fi2 * rj2;
+  }
+  // only the rows (and the parts of rows) that can hold a point of the hand's slab |axis . (p - sample)| < hand_height
+  build_rows<true>(gv, sx, sy, sz, rpad, rt, F.axis, geom_p->hand_height, &gd);  // ends with barriers: G, ori[].T and counters are visible afterwards
+  if (tid < 64)
+    thr_s[tid] = tid < G.n_thr ? G.thr[tid] : INFINITY;
+  if (tid < 24)
+    dep_s[tid] = tid < G.n_depths ? G.depths[tid] : INFINITY;
+  if (rt.bad)
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusRows;
+      vmask[s] = 0;
+    }
+    return;
+  }
   const double hh = G.hand_height;
   const int total = rt.total;
   // ---- orientation setup (rotating_hand.cpp:86-104) ----
@@ -241,11 +267,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   {
     const int o = tid;
     OriState& O = ori[o];
-    const double cs = G.cos_a[o], sn = G.sin_a[o];
-    const double rot[3][3] = { { cs, -1.0 * sn, 0.0 }, { sn, cs, 0.0 }, { 0.0, 0.0, 1.0 } };
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++)
-        O.T[i][j] = (fr[i][0] * rot[j][0] + fr[i][1] * rot[j][1]) + fr[i][2] * rot[j][2];  // frame_ * rot^T
+    const double cs = G.cos_a[o], sn = G.sin_a[o];  // (O.T = frame_ * rot^T was formed above, an entry per thread)
     double cams[2][3];
     for (int c = 0; c < 2; c++)
       for (int r = 0; r < 3; r++)
