@@ -487,13 +487,14 @@ __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t
     *total_io = carry;
 }
 
+template <int LPS>
 __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
   const int* __restrict__ weight, int* __restrict__ order, int32_t* __restrict__ draw_ofs, int32_t* __restrict__ draw_total_io)
 {
   __shared__ int hist[kOrderBins];
   __shared__ int wave_tot[4];
-  const int n_solver_groups = (S + 255) / 256;
+  const int n_solver_groups = (S * LPS + 255) / 256;
   if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling order of the following kernels
   {
     sample_order_block(weight, S, order, hist, wave_tot);
@@ -505,14 +506,16 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
       draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
     return;
   }
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  // LPS consecutive lanes hold the same sample (taubin_eigen.h: they share the bisection); the first of them reports
+  const int s = (int) (blockIdx.x * 256 + threadIdx.x) / LPS;
+  const bool writer = (threadIdx.x % LPS) == 0;
   if (s >= S)
     return;
   const int st_ = status[s];
   // loud capacity / index errors (read back by agh_synchronize and the host entry points)
-  if (st_ == kStatusOverflow || st_ == kStatusRows)
+  if (writer && (st_ == kStatusOverflow || st_ == kStatusRows))
     atomicOr(&flags[0], 1);
-  if (st_ == kStatusBadIndex)
+  if (writer && st_ == kStatusBadIndex)
     atomicOr(&flags[0], 4);
   const bool live = st_ == kStatusOk && nt[s] > 0;
   double sv[kNumSums];
@@ -520,7 +523,9 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
   for (int k = 0; k < kNumSums; k++)
     sv[k] = live ? sums[(int64_t) s * kSumStride + k] : 0.0;
   double v[10];
-  const double lambda = taubin_smallest_eigenpair(sv, live ? (double) nt[s] : 1.0, v);
+  const double lambda = taubin_smallest_eigenpair<LPS>(sv, live ? (double) nt[s] : 1.0, v);
+  if (!writer)
+    return;
   double* out = eig + (int64_t) s * 12;
 #pragma unroll
   for (int k = 0; k < 10; k++)
@@ -1129,13 +1134,21 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
-  const int eig_groups = (Si + 255) / 256 + 1;  // one sample per lane + the sorter work-group
+  // One sample per lane, or -- for up to 4096 samples: 512 waves, every second SIMD -- eight, which share the bisection
+  // (taubin_eigen.h): C2 22.9 -> 18.5 us (HIP events); with C4's 8000 samples (1000 waves) it measured 24.7 against 22.6, so
+  // C4, the 16 000 samples of a batch and the 300 000 of the all-points pass stay at one lane each.
+  const int lps = Si <= 4096 ? 8 : 1;
+  const int eig_groups = (Si * lps + 255) / 256 + 1;  // + the sorter work-group
   // (production mode: one more work-group computes the RAND50 draw offsets, unless the caller exchanges the counts
   // between the ranks first -- the sharded search)
   int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
   const int eig_grid = eig_groups + (dofs ? 1 : 0);
-  hipLaunchKernelGGL(k_taubin_eigen, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-    c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
+  if (lps == 8)
+    hipLaunchKernelGGL(k_taubin_eigen<8>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
+  else
+    hipLaunchKernelGGL(k_taubin_eigen<1>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

@@ -6,7 +6,7 @@
 #include "agh_internal.h"
 
 #ifndef AGH_EIG_STAMP0  // phase boundaries; scripts/micro/eigen_phases.hip turns them into truncation points
-#define AGH_EIG_TEMPLATE
+#define AGH_EIG_TEMPLATE template <int LPS>
 #define AGH_EIG_STAMP0
 #define AGH_EIG_STAMP1
 #define AGH_EIG_STAMP2
@@ -26,7 +26,13 @@ constexpr int kBisectSteps = 56;
 __device__ __forceinline__ double pivot_floor(double x) { return (fabs(x) >= kPivMin) ? x : kPivMin; }
 
 // sv = the 37 sums of k_taubin_moments, n = the neighbour count; v = the 10 quadric parameters (quadric.cpp:152, before
-// the halving of 3..5), returns the eigenvalue
+// the halving of 3..5), returns the eigenvalue.
+// LPS = lanes per sample: 1, or 8 consecutive lanes that hold the SAME sample (every lane computes everything; only the
+// bisection shares work).  The bisection is 56 dependent decisions, 60 % of the solve.  With eight lanes per sample the
+// lanes 1..7 of a group evaluate the seven nodes of the next THREE levels of the decision tree at once -- lane q walks to
+// node q (heap numbering) from the common bracket with the same fused multiply-adds the serial loop would execute on that
+// path, so every midpoint is bit-identical to the serial one -- a ballot collects the seven verdicts, and every lane
+// replays the three decisions: 19 passes instead of 56 steps.  Worth it while the samples x 8 still fit one wave per SIMD.
 AGH_EIG_TEMPLATE __device__ __forceinline__ double taubin_smallest_eigenpair(const double (&sv)[kNumSums], double n, double (&v)[10])
 {
   // S = M9 - b b^T / n, lower triangle (M's upper triangle by quadric.cpp:40-100; the 10th unknown eliminated)
@@ -249,27 +255,72 @@ AGH_EIG_TEMPLATE __device__ __forceinline__ double taubin_smallest_eigenpair(con
     hi = (take && (first || d[i] < hi)) ? d[i] : hi;
     first = first && !take;
   }
-#pragma unroll 1
-  for (int it = 0; it < kBisectSteps; it++)
-  {
-    const double mid = fma(hi - lo, 0.5, lo);
-    // an eigenvalue of T lies below mid iff the Sturm sequence changes sign, i.e. iff one of its members is negative
-    // (p_0 = 1): the OR of their sign bits, gathered off the dependent chain of fused multiply-adds
-    double pm2 = 1.0, pm1 = d[0] - mid;
+  // an eigenvalue of T lies below x iff the Sturm sequence changes sign, i.e. iff one of its members is negative
+  // (p_0 = 1): the OR of their sign bits, gathered off the dependent chain of fused multiply-adds
+  auto below_at = [&](double x) -> bool {
+    double pm2 = 1.0, pm1 = d[0] - x;
     int sgn = __double2hiint(pm1);
 #pragma unroll
     for (int i = 1; i < 9; i++)
     {
-      const double pi = fma(d[i] - mid, pm1, -(e2[i - 1] * pm2));
+      const double pi = fma(d[i] - x, pm1, -(e2[i - 1] * pm2));
       sgn |= __double2hiint(pi);
       pm2 = pm1;
       pm1 = pi;
     }
-    const bool below = sgn < 0;
-    hi = below ? mid : hi;
-    lo = below ? lo : mid;
+    return sgn < 0;
+  };
+  if (LPS == 1)
+  {
+#pragma unroll 1
+    for (int it = 0; it < kBisectSteps; it++)
+    {
+      const double mid = fma(hi - lo, 0.5, lo);
+      const bool below = below_at(mid);
+      hi = below ? mid : hi;
+      lo = below ? lo : mid;
+    }
   }
-  AGH_EIG_STAMP4;
+  else
+  {
+    static_assert(LPS == 1 || LPS == 8, "one lane per sample, or eight");
+    const int q = (int) (threadIdx.x & 7);  // my node of the three-level tree (1 = root, 2 q = below, 2 q + 1 = not below); lane 0 idles
+    const int gshift = (int) (threadIdx.x & 63 & ~7);
+    int left = kBisectSteps;
+#pragma unroll 1
+    while (left > 0)
+    {
+      const int levels = left >= 3 ? 3 : left;
+      // walk from the common bracket to my node: the path is the bits of q below its leading one, most significant first
+      double nlo = lo, nhi = hi;
+      const int depth = q >= 4 ? 2 : (q >= 2 ? 1 : 0);
+#pragma unroll
+      for (int l = 0; l < 2; l++)
+        if (l < depth)
+        {
+          const double m = fma(nhi - nlo, 0.5, nlo);
+          const bool right = ((q >> (depth - 1 - l)) & 1) != 0;  // child 2 p + 1: the parent's verdict was "not below": lo = mid
+          nlo = right ? m : nlo;
+          nhi = right ? nhi : m;
+        }
+      const double mid = fma(nhi - nlo, 0.5, nlo);
+      const bool below = below_at(mid);
+      const unsigned verdicts = (unsigned) (__ballot(below) >> gshift) & 0xffu;  // bit p = verdict of node p of my sample
+      // replay: every lane of the group takes the same `levels` decisions
+      int node = 1;
+#pragma unroll
+      for (int l = 0; l < 3; l++)
+        if (l < levels)
+        {
+          const double m = fma(hi - lo, 0.5, lo);
+          const bool b = ((verdicts >> node) & 1u) != 0;
+          hi = b ? m : hi;
+          lo = b ? lo : m;
+          node = 2 * node + (b ? 0 : 1);
+        }
+      left -= levels;
+    }
+  }
   const double sigma = lo;
   // 5. twisted factorisation of T - sigma I
   double Dp[9], Dm[9], lf[8], ub[8];

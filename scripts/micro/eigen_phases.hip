@@ -19,7 +19,7 @@
 #define AGH_EIG_STAMP4 if (STOP == 4) return AGH_SUM_LOWER(C) + AGH_SUM_VEC(b, 9) + AGH_SUM_STRICT(L) + AGH_SUM_VEC(rinv, 9) + AGH_SUM_VEC(RH, 7) + AGH_SUM_VEC(e, 8) + lo + hi
 #define AGH_EIG_STAMP5 if (STOP == 5) return AGH_SUM_LOWER(C) + AGH_SUM_VEC(b, 9) + AGH_SUM_STRICT(L) + AGH_SUM_VEC(rinv, 9) + AGH_SUM_VEC(RH, 7) + AGH_SUM_VEC(z, 9)
 #define AGH_EIG_STAMP6 if (STOP == 6) return AGH_SUM_VEC(b, 9) + AGH_SUM_VEC(v, 9)
-#define AGH_EIG_TEMPLATE template <int STOP>
+#define AGH_EIG_TEMPLATE template <int STOP, int LPS = 1>
 #include "taubin_eigen.h"
 
 using namespace agh;
