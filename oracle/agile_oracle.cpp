@@ -1865,6 +1865,15 @@ void orc_glibc_rand(uint32_t seed, int32_t* out, int64_t count)
     out[i] = g.next();
 }
 
+void orc_smallest_eigvec3(const double* M3, double* axis_out)
+{
+  double Mm[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Mm[i][j] = M3[i * 3 + j];
+  smallest_eigvec3(Mm, axis_out);
+}
+
 int orc_solve_taubin(const double* M, const double* N, double* v_out, double* lambda_out)
 {
   double Mm[10][10], Nm[10][10];

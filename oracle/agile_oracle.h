@@ -117,6 +117,8 @@ void orc_glibc_rand(uint32_t seed, int32_t* out, int64_t count);
 
 /* generalized eigen reduction exposed for the LAPACK goldens: M,N 10x10 row-major; v_out 10. */
 int orc_solve_taubin(const double* M, const double* N, double* v_out, double* lambda_out);
+/* The unit eigenvector of the smallest eigenvalue of a symmetric 3 x 3 (row-major), as fit_frame uses it (quadric.cpp:268-280). */
+void orc_smallest_eigvec3(const double* M3, double* axis_out);
 
 /* f2: HandleSearch::findHandles + Handle (handle_search.cpp:4-128, handle.cpp:3-74). */
 typedef struct orc_handle

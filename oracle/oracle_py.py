@@ -229,6 +229,13 @@ def solve_taubin(M: np.ndarray, N: np.ndarray):
     return rc, v, lam.value
 
 
+def smallest_eigvec3(M3: np.ndarray) -> np.ndarray:
+    M3 = np.ascontiguousarray(M3, np.float64)
+    out = np.zeros(3)
+    lib().orc_smallest_eigvec3(_fp(M3, C.c_double), _fp(out, C.c_double))
+    return out
+
+
 def preprocess(xyz: np.ndarray, size_left: int, workspace, cell_size: float = 0.003, dense: bool = False):
     """NaN removal + workspace filter + per-camera voxelisation (localization.cpp:17-45,216-355)."""
     xyz = np.ascontiguousarray(xyz, np.float32)

@@ -223,7 +223,7 @@ def test_edge_cases(tiny_scene):
     assert len(h) == 3 * len(one)
 
 
-@pytest.mark.parametrize("kind", ["duplicates", "lattice_plane", "collinear", "random_blob", "two_sheets"])
+@pytest.mark.parametrize("kind", ["duplicates", "lattice_plane", "diagonal_plane", "collinear", "random_blob", "two_sheets"])
 def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
     """Ties in the neighbour order (duplicate points, lattice symmetry), singular fits (exact planes, lines), tiny and
     ragged neighbourhoods: whatever the oracle does with them, the kernels must do the same, bit for bit."""
@@ -239,6 +239,12 @@ def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
         g = np.arange(-0.06, 0.06, 0.003)
         u, v = np.meshgrid(g, g, indexing="ij")
         xyz = c0 + np.stack([u.ravel(), v.ravel(), np.zeros(u.size)], 1)  # exactly planar: singular pencil, deflated -> frames with the plane's normal
+    elif kind == "diagonal_plane":
+        # x + y + z = const on a 2^-8 m lattice (every coordinate and the plane equation exact in float32): a singular pencil
+        # whose Cholesky fails at the LAST pivot, where the axis-aligned plane's fails at pivot 8 of a sparser matrix
+        k = np.arange(-18, 19)
+        i, j = np.meshgrid(k, k, indexing="ij")
+        xyz = np.stack([i.ravel(), j.ravel(), -(i + j).ravel()], 1) * 2.0 ** -8 + np.array([192, 13, -12]) * 2.0 ** -8
     elif kind == "collinear":
         t = np.linspace(-0.08, 0.08, 300)
         xyz = np.concatenate([c0 + np.stack([t, 0 * t, 0 * t], 1), c0 + rng.uniform(-0.02, 0.02, (40, 3))])
