@@ -964,6 +964,53 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   // the terms l, l + 64, ... and a butterfly combines the 64 partials (every lane ends with the same total)
   double best = -1.0;
   int best_j = 0x7fffffff;
+  // Many candidates -- an exactly planar neighbourhood, where every normal is +-n and no estimate can tell the columns apart:
+  // all n of them, n^2 terms -- take them FOUR at a time: a term's normal is read from LDS once and serves four columns
+  // (one column at a time the phase is bound by LDS bandwidth: 24 bytes per 9 flops; 275 us at the axis-aligned C2).
+  if (CAP > 128 && ncnd >= 16)
+    for (;;)
+    {
+      int c = 0;
+      if (lane == 0)
+        c = atomicAdd(&next_col, 4);
+      c = __shfl(c, 0);
+      if (c >= ncnd)
+        break;
+      int jj[4];
+      double jx[4], jy[4], jz[4], acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+        jj[u] = cand[min(c + u, ncnd - 1)];  // (a short last group repeats its last column; the repeats are not compared)
+        jx[u] = nx[jj[u]];
+        jy[u] = ny[jj[u]];
+        jz[u] = nz[jj[u]];
+        acc[u] = 0.0;
+      }
+      for (int t = lane; t < ks; t += 64)
+      {
+        const double tx = nx[t], ty = ny[t], tz = nz[t];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+          const double gdot = (tx * jx[u] + ty * jy[u]) + tz * jz[u];
+          const double g2 = gdot * gdot;
+          acc[u] += (g2 * g2) * g2;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+        double a = acc[u];
+        for (int o = 32; o > 0; o >>= 1)
+          a = a + __shfl_xor(a, o);
+        if (c + u < ncnd && (a > best || (a == best && jj[u] < best_j) || best_j == 0x7fffffff))
+        {
+          best = a;
+          best_j = jj[u];
+        }
+      }
+    }
   for (;;)
   {
     int c = 0;
