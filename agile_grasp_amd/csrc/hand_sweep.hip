@@ -309,9 +309,12 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // Straight-line code: the kernel is bound by the instructions a wave issues, and exec-mask juggling around the
   // ~1/8 of the lanes that survive costs more than computing the hand-frame coordinates for all of them.
   auto classify1 = [&](const float4& p, bool have, bool& inball, bool& keep, double& tx, double& ty) {
-    const float d2 = flann_d2(sx, sy, sz, p.x, p.y, p.z);
+    // p - sample in float32 (hand_search.cpp:157-158) serves FLANN's distance too: q - p = -(p - q) exactly, and the squares
+    // are the same bits -- three subtractions per candidate less
+    const float fx = p.x - sx, fy = p.y - sy, fz = p.z - sz;
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));  // flann_d2's order
     inball = have & (d2 < r2f);
-    const double cx = (double) (p.x - sx), cy = (double) (p.y - sy), cz = (double) (p.z - sz);  // 157-158
+    const double cx = (double) fx, cy = (double) fy, cz = (double) fz;
     const double tz = (fr[0][2] * cx + fr[1][2] * cy) + fr[2][2] * cz;
     keep = inball & (tz > -1.0 * hh) & (tz < hh);  // (bitwise: no exec-mask regions around three compares)
     tx = (fr[0][0] * cx + fr[1][0] * cy) + fr[2][0] * cz;
