@@ -187,6 +187,9 @@ def config(name: str) -> Scene:
     same scene (same seed, same objects), `boxu` an axis-aligned table with one 6 x 6 x 9 cm box."""
     if name == "boxu":
         return make_box_scene()
+    if name.startswith("seed"):  # `seed123` / `seed123u`: a C2-sized scene from any seed (sweeps over many scenes)
+        axis_aligned = name.endswith("u")
+        return make_scene(300_000, 2000, seed=int(name[4:-1] if axis_aligned else name[4:]), two_view=True, name=name, tilt=not axis_aligned)
     tilt = True
     base = name
     if name.endswith("u") and name[:-1] in ("C1", "C2", "C3", "C4", "tiny", "small") or (name.startswith("C5") and name.endswith("u")):

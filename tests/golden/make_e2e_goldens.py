@@ -322,7 +322,7 @@ def lapack_normals(pool, sc, samples, frames):
     return normals, pts, fr, ex
 
 
-def run_case(pool, name, n_samples, w, rho, rand50=False, antipodal=False, **search_kw):
+def run_case(pool, name, n_samples, w, rho, rand50=False, antipodal=False, self_all=False, **search_kw):
     sc = synthetic.config(name)
     set_scene(sc)
     samples = sc.samples[:n_samples]
@@ -340,7 +340,7 @@ def run_case(pool, name, n_samples, w, rho, rand50=False, antipodal=False, **sea
         if antipodal:
             normals, pts, nfr, nex = lapack_normals(pool, sc, samples, frames)
         frames_p = None
-        if degenerate.any() and not search_kw:  # the reference against itself, one input bit flipped
+        if (degenerate.any() or self_all) and not search_kw:  # the reference against itself, one input bit flipped
             frames_p, _ = lapack_frames(pool, samples, perturb=True, light=True)
     res = O.hands_from_frames(p, sc.xyz, sc.cam, samples, frames, normals=normals, want_images=True)
     keep, sums = O.classify(res["images"], w, rho)
@@ -392,6 +392,18 @@ def run_case(pool, name, n_samples, w, rho, rand50=False, antipodal=False, **sea
         "svm_kept": int(keep.sum()), "min_abs_svm_sum": float(np.abs(sums).min()) if len(sums) else None,
     })
     rep.update(rep_n)
+    if self_all and frames_p is not None:  # LAPACK against LAPACK with one ulp on every entry of M, regular samples: the yardstick
+        resp = O.hands_from_frames(p, sc.xyz, sc.cam, samples, frames_p, normals=normals, want_images=True)
+        keep_p, sums_p = O.classify(resp["images"], w, rho)
+        rs, common_s, ka_s, kb_s = compare_lists(res["hyps"], resp["hyps"], regular)
+        pa = {(int(h["sample"]), int(h["orientation"])): i for i, h in enumerate(res["hyps"])}
+        pb = {(int(h["sample"]), int(h["orientation"])): i for i, h in enumerate(resp["hyps"])}
+        rep["self"] = {k: rs[k] for k in ("n_a", "only_a", "only_b", "flips_finger_index", "flips_depth_index", "flips_cam_source",
+                                            "flips_n_in_box", "max_abs_n_in_box", "max_abs_axis", "max_abs_bottom", "max_abs_surface",
+                                            "max_abs_width")}
+        rep["self"]["svm_label_flips"] = int(sum(int(keep[pa[k]]) != int(keep_p[pb[k]]) for k in common_s))
+        rep["self"]["max_abs_svm_sum"] = float(max([abs(sums[pa[k]] - sums_p[pb[k]]) for k in common_s] or [0.0]))
+        rep["self"]["max_index_mismatch"] = int((frames["max_index"] != frames_p["max_index"])[regular].sum())
     if degenerate.any():
         # degenerate samples: the surface normal is what every minimiser agrees on; the in-plane axis is not
         fin = np.isfinite(frames["normal"]).all(1) & np.isfinite(of["normal"]).all(1) & degenerate
