@@ -450,32 +450,45 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
     }
   }
   __syncthreads();
-  if (tid < 64)  // wave 0: inclusive scan of the (<= 128) row lengths, two per lane
-  {
+  if (tid < 64)  // wave 0: inclusive scan of the (<= 128) row lengths, two per lane -- and the rows without candidates are
+  {              // squeezed out of the table (the walks then never meet an empty row): a second scan, of the non-empty flags
     const int nr = rt.bad ? 0 : nrows;
     const int v0 = tid < nr ? rt.prefix[tid + 1] : 0;
     const int v1 = (64 + tid) < nr ? rt.prefix[64 + tid + 1] : 0;
-    int i0 = v0, i1 = v1;
+    const int b0 = tid < nr ? rt.begin[tid] : 0;
+    const int b1 = (64 + tid) < nr ? rt.begin[64 + tid] : 0;
+    const int f0 = v0 > 0 ? 1 : 0, f1 = v1 > 0 ? 1 : 0;
+    int i0 = v0, i1 = v1, c0 = f0, c1 = f1;
     for (int o = 1; o < 64; o <<= 1)
     {
-      const int a = __shfl_up(i0, o), b = __shfl_up(i1, o);
+      const int a = __shfl_up(i0, o), b = __shfl_up(i1, o), c = __shfl_up(c0, o), d = __shfl_up(c1, o);
       if (tid >= o)
       {
         i0 += a;
         i1 += b;
+        c0 += c;
+        c1 += d;
       }
     }
-    const int t0 = __shfl(i0, 63);
-    i1 += t0;
-    if (tid < nr)
-      rt.prefix[tid + 1] = i0;
-    if ((64 + tid) < nr)
-      rt.prefix[64 + tid + 1] = i1;
-    const int tot = __shfl(i1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the grand total
+    i1 += __shfl(i0, 63);
+    c1 += __shfl(c0, 63);
+    // (all reads of the table above precede these writes in the wave's program order; a row only moves down)
+    if (f0)
+    {
+      rt.begin[c0 - 1] = b0;
+      rt.prefix[c0] = i0;
+    }
+    if (f1)
+    {
+      rt.begin[c1 - 1] = b1;
+      rt.prefix[c1] = i1;
+    }
+    const int tot = __shfl(i1, 63), nkept = __shfl(c1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the totals
     if (tid == 0)
     {
       rt.prefix[0] = 0;
       rt.total = tot;
+      rt.nrows = nkept;
     }
   }
   __syncthreads();
@@ -503,6 +516,71 @@ __device__ __forceinline__ int row_lookup(const RowTable& rt, int j)
   }
   return rt.begin[lo] + (j - rt.prefix[lo]);
 }
+
+// The candidates of a ball query as ONE run of `total` flat indices, walked in segments of 128 (lane: flat index
+// 128 j + lane and 128 j + 64 + lane).  A row-per-wave walk leaves a third of the lanes without a candidate (a slab row of
+// the hand search holds 87 candidates on average, a Taubin row 83) and gives the waves unequal numbers of rows; flat
+// segments are full except the last, and wave w takes segments w, w + 4, ... .  The row table lives in lane registers
+// (lane k: rows k and k + 64) and is read with v_readlane at wave-uniform indices, so finding a segment's rows costs no LDS
+// round trip: a scalar loop over the row boundaries inside the segment and two selects per boundary and lane.
+struct FlatRows
+{
+  int pre_lo, pre_hi;  // prefix[k + 1], prefix[k + 65]: the flat index at which row k (k + 64) ENDS
+  int adj_lo, adj_hi;  // begin[k] - prefix[k] (rows k, k + 64): position in the sorted array = flat index + adj
+  int nrows, total;
+
+  __device__ __forceinline__ void init(const RowTable& rt, int lane)
+  {
+    nrows = rt.nrows;
+    total = rt.total;
+    pre_lo = lane < nrows ? rt.prefix[lane + 1] : total;
+    pre_hi = lane + 64 < nrows ? rt.prefix[lane + 65] : total;
+    adj_lo = lane < nrows ? rt.begin[lane] - rt.prefix[lane] : 0;
+    adj_hi = lane + 64 < nrows ? rt.begin[lane + 64] - rt.prefix[lane + 64] : 0;
+  }
+  __device__ __forceinline__ int row_end(int r) const  // r wave-uniform; (two reads and a scalar select: no branch)
+  {
+    const int a = __builtin_amdgcn_readlane(pre_lo, r & 63), b = __builtin_amdgcn_readlane(pre_hi, r & 63);
+    return r < 64 ? a : b;
+  }
+  __device__ __forceinline__ int row_adj(int r) const
+  {
+    const int a = __builtin_amdgcn_readlane(adj_lo, r & 63), b = __builtin_amdgcn_readlane(adj_hi, r & 63);
+    return r < 64 ? a : b;
+  }
+  __device__ __forceinline__ int segments() const { return (total + 127) >> 7; }
+  // Segment j (wave-uniform; r0 = the wave's row cursor, which only grows with j): positions of the lane's two candidates
+  // in the sorted array and whether it has them.
+  __device__ __forceinline__ void locate(int j, int& r0, int lane, int& a0, int& a1, bool& h0, bool& h1) const
+  {
+    // (j and r0 derive from the wave's index, i.e. from threadIdx: tell the compiler they are wave-uniform, or the two
+    // loops below become exec-masked vector loops)
+    j = __builtin_amdgcn_readfirstlane(j);
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    const int tot = __builtin_amdgcn_readfirstlane(total), nrows = __builtin_amdgcn_readfirstlane(this->nrows);
+    const int start = j << 7, end = min(start + 128, tot);
+    const int i0 = start + lane, i1 = i0 + 64;
+    h0 = i0 < tot;
+    h1 = i1 < tot;
+    while (r0 + 1 < nrows && row_end(r0) <= start)
+      r0++;
+    int adj = row_adj(r0);
+    a0 = adj;
+    a1 = adj;
+    for (int r = r0; r + 1 < nrows;)  // the row boundaries inside the segment (build_rows leaves no empty rows)
+    {
+      const int b = row_end(r);
+      if (b >= end)
+        break;
+      r++;
+      adj = row_adj(r);
+      a0 = i0 >= b ? adj : a0;
+      a1 = i1 >= b ? adj : a1;
+    }
+    a0 += i0;
+    a1 += i1;
+  }
+};
 
 // Cyclic Jacobi of a symmetric 3x3 (oracle jacobi_sym<3>): one lane, the oracle's operation order.
 __device__ inline void jacobi3_serial(double A[3][3], double V[3][3], double d[3])

@@ -292,17 +292,16 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     return;
   AGH_STAMP(1);
 
-  // Gather: every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes, two loads in
-  // flight per lane (row base and length are wave-uniform: no per-candidate row look-up, fully coalesced).  Each
+  // Gather: every wave owns the 128-candidate segments j = wave, wave + 4, ... of the concatenated grid rows and walks each
+  // with its 64 lanes, two loads in flight per lane (a segment spans one to three rows: coalesced runs).  Each
   // candidate is filtered (FLANN float32 distance), rotated into the hand frame and cropped (rotating_hand.cpp:26,37-51)
   // and the survivors are appended to the LDS tile: one LDS atomic per wave-instruction reserves their slots; if the
   // reservation does not fit, the tile is closed and the wave pauses AT that instruction, so a neighbourhood that does
-  // not fit one tile streams through it in several rounds.  The cursor (row, offset) says where to resume.
-  int cur_r = wave, cur_i = 0;
-  const int nrows = rt.nrows;
+  // not fit one tile streams through it in several rounds.  The cursor (segment, first row) says where to resume.
+  int cur_j = wave, cur_r0 = 0;
   auto gather_reset = [&]() {
-    cur_r = wave;
-    cur_i = 0;
+    cur_j = wave;
+    cur_r0 = 0;
   };
   // Filters two candidates per lane (a 128-candidate row segment per wave) and appends the survivors with ONE
   // reservation; returns false if the tile is full (nothing was appended, the segment must be offered again).
@@ -366,65 +365,44 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // Must be entered with cnt_crop == 0 made visible by a barrier.
   // The walk is software-pipelined: the loads of the NEXT 128 candidates are issued before the current 128 are
   // filtered, so a wave always has two row segments in flight (the gather is bound by L2 latency, not by bandwidth).
-  // (the wave's rows wave, wave + 4, ... live in lane registers -- lane k: start and length of row wave + 4 k -- and the
-  // walk reads them with v_readlane: no LDS round trip between a row's end and the next row's first load)
-  const int my_row = wave + 4 * lane;
-  const int row_begin_v = my_row < nrows ? rt.begin[my_row] : 0;
-  const int row_len_v = my_row < nrows ? rt.prefix[my_row + 1] - rt.prefix[my_row] : 0;
-  auto seg_normalize = [&](int& r, int& i, int& rb, int& len) {  // skip exhausted / empty rows
-    for (;;)
-    {
-      if (r >= nrows)
-      {
-        len = 0;
-        rb = 0;
-        return;
-      }
-      const int k = __builtin_amdgcn_readfirstlane((r - wave) >> 2);
-      rb = __builtin_amdgcn_readlane(row_begin_v, k);
-      len = __builtin_amdgcn_readlane(row_len_v, k);
-      if (i < len)
-        return;
-      r += 4;
-      i = 0;
-    }
-  };
-  auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
-    h0 = (r < nrows) & (i + lane < len);
-    h1 = (r < nrows) & (i + 64 + lane < len);
+  // (the candidates are walked as flat 128-candidate segments over the concatenated rows -- FlatRows, agh_internal.h: full
+  // segments and an equal share per wave, where a row per wave left a third of the lanes idle; the row table lives in lane
+  // registers and is read with v_readlane: no LDS round trip between a segment and the next one's first load)
+  FlatRows flat;
+  flat.init(rt, lane);
+  const int nseg = flat.segments();
+  auto seg_load = [&](int j, int& r0, float4& p0, float4& p1, bool& h0, bool& h1) {
+    int a0, a1;
+    flat.locate(j, r0, lane, a0, a1, h0, h1);
     // unconditional loads (a lane without a candidate reads element 0 and ignores it): a load under a branch would
     // be waited for at the join, which is exactly the latency the pipeline is there to hide
-    p0 = gv.sorted[h0 ? rb + i + lane : 0];
-    p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
+    p0 = gv.sorted[h0 ? a0 : 0];
+    p1 = gv.sorted[h1 ? a1 : 0];
   };
   auto gather_tile = [&](bool& all_done) -> int {
     bool full = false;
-    int rb = 0, len = 0;
-    seg_normalize(cur_r, cur_i, rb, len);
     float4 p0, p1;
     bool h0, h1;
-    seg_load(cur_r, cur_i, rb, len, p0, p1, h0, h1);
-    while (cur_r < nrows && !full)
+    seg_load(cur_j, cur_r0, p0, p1, h0, h1);
+    while (cur_j < nseg && !full)
     {
-      int nr = cur_r, ni = cur_i + 128, nrb = 0, nlen = 0;
-      seg_normalize(nr, ni, nrb, nlen);
+      int nr0 = cur_r0;
       float4 q0, q1;
       bool g0, g1;
-      seg_load(nr, ni, nrb, nlen, q0, q1, g0, g1);  // in flight while the current segment is consumed
+      seg_load(cur_j + 4, nr0, q0, q1, g0, g1);  // in flight while the current segment is consumed
       if (!consume2(p0, h0, p1, h1))
         full = true;
       else
       {
-        cur_r = nr;
-        cur_i = ni;
-        len = nlen;
+        cur_j += 4;
+        cur_r0 = nr0;
         p0 = q0;
         p1 = q1;
         h0 = g0;
         h1 = g1;
       }
     }
-    if (lane == 0 && cur_r < nrows)
+    if (lane == 0 && cur_j < nseg)
       pending = 1;
     __syncthreads();
     const int c = min(cnt_crop, tile_end);

@@ -105,34 +105,19 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   }
   const float binscale = (float) kSortBins / r2f;  // monotone map of d2 in [0, r2f) onto the sort bins
   // ---- gather + FLANN distance filter + compaction into LDS ----
-  // every wave owns the grid rows r = wave, wave + 4, ... and walks each run with its 64 lanes: row base and length
-  // are wave-uniform (no per-candidate row look-up) and the reads are fully coalesced.
-  // The walk is software-pipelined like k_hand_sweep's: the (unconditional) loads of the next 128 candidates are issued
-  // before the current 128 are filtered, and the two candidates of a lane share one reservation.
+  // every wave owns the 128-candidate segments j = wave, wave + 4, ... of the concatenated grid rows (FlatRows,
+  // agh_internal.h: full segments, an equal share per wave, the row table in lane registers) and the reads are coalesced
+  // runs.  The walk is software-pipelined like k_hand_sweep's: the (unconditional) loads of the next 128 candidates are
+  // issued before the current 128 are filtered, and the two candidates of a lane share one reservation.
   {
-    const int nrows = rt.nrows;
-    auto seg_normalize = [&](int& r, int& i, int& rb, int& len) {  // skip exhausted / empty rows
-      for (;;)
-      {
-        if (r >= nrows)
-        {
-          len = 0;
-          rb = 0;
-          return;
-        }
-        rb = rt.begin[r];
-        len = rt.prefix[r + 1] - rt.prefix[r];
-        if (i < len)
-          return;
-        r += 4;
-        i = 0;
-      }
-    };
-    auto seg_load = [&](int r, int i, int rb, int len, float4& p0, float4& p1, bool& h0, bool& h1) {
-      h0 = (r < nrows) & (i + lane < len);
-      h1 = (r < nrows) & (i + 64 + lane < len);
-      p0 = gv.sorted[h0 ? rb + i + lane : 0];  // a lane without a candidate reads element 0 and ignores it
-      p1 = gv.sorted[h1 ? rb + i + 64 + lane : 0];
+    FlatRows flat;
+    flat.init(rt, lane);
+    const int nseg = flat.segments();
+    auto seg_load = [&](int j, int& r0, float4& p0, float4& p1, bool& h0, bool& h1) {
+      int a0, a1;
+      flat.locate(j, r0, lane, a0, a1, h0, h1);
+      p0 = gv.sorted[h0 ? a0 : 0];  // a lane without a candidate reads element 0 and ignores it
+      p1 = gv.sorted[h1 ? a1 : 0];
     };
     auto take2 = [&](const float4& p0, bool h0, const float4& p1, bool h1) {
       const float d0 = flann_d2(qx, qy, qz, p0.x, p0.y, p0.z), d1 = flann_d2(qx, qy, qz, p1.x, p1.y, p1.z);
@@ -161,21 +146,17 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
         }
       }
     };
-    int cur_r = wave, cur_i = 0, rb = 0, len = 0;
-    seg_normalize(cur_r, cur_i, rb, len);
+    int cur_j = wave, r0 = 0;
     float4 p0, p1;
     bool h0, h1;
-    seg_load(cur_r, cur_i, rb, len, p0, p1, h0, h1);
-    while (cur_r < nrows)
+    seg_load(cur_j, r0, p0, p1, h0, h1);
+    while (cur_j < nseg)
     {
-      int nr = cur_r, ni = cur_i + 128, nrb = 0, nlen = 0;
-      seg_normalize(nr, ni, nrb, nlen);
       float4 q0, q1;
       bool g0, g1;
-      seg_load(nr, ni, nrb, nlen, q0, q1, g0, g1);  // in flight while the current segment is filtered
+      seg_load(cur_j + 4, r0, q0, q1, g0, g1);  // in flight while the current segment is filtered
       take2(p0, h0, p1, h1);
-      cur_r = nr;
-      cur_i = ni;
+      cur_j += 4;
       p0 = q0;
       p1 = q1;
       h0 = g0;
