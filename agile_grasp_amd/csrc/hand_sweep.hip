@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   // (work-groups in sample order: the caller's samples are spatially sorted, neighbouring work-groups share grid rows in L2,
   // and since the gather only walks the hand's slab no weight known before the launch predicts a work-group's duration well
   // enough to beat that -- longest-first by ball candidates: 104 us, by Taubin neighbours: 109, sample order: 102)
+#ifdef AGH_DEBUG_HOOKS  // scripts/sweep_order_experiment.py: an explicit blockIdx -> sample map (AGH_DEBUG_SWEEP_ORDER)
+  const int s = order ? order[blockIdx.x] : blockIdx.x;
+#else
   const int s = blockIdx.x;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
   AGH_STAMP(0);
@@ -1162,12 +1166,33 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const int Si = (int) S;
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
-  // blockIdx -> sample goes through c->d_order (longest first; computed by k_taubin_eigen's sorter work-group)
+  const int* order = nullptr;  // (the kernel runs in sample order; c->d_order serves k_taubin_frame)
+#ifdef AGH_DEBUG_HOOKS
+  {
+    static int* dbg_order = nullptr;
+    static int dbg_n = -1;
+    if (dbg_n < 0)
+    {
+      dbg_n = 0;
+      if (const char* f = getenv("AGH_DEBUG_SWEEP_ORDER"))
+        if (FILE* fp = fopen(f, "rb"))
+        {
+          std::vector<int> h(1 << 20);
+          dbg_n = (int) fread(h.data(), 4, h.size(), fp);
+          fclose(fp);
+          hipMalloc(&dbg_order, sizeof(int) * (size_t) dbg_n);
+          hipMemcpy(dbg_order, h.data(), sizeof(int) * (size_t) dbg_n, hipMemcpyHostToDevice);
+        }
+    }
+    if (dbg_n == Si)
+      order = dbg_order;
+  }
+#endif
   const bool few = c->geom.x_probes <= 2 && c->geom.y_probes <= 1;
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
   hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
     r2f, rpad, nrm, img_cell, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
-    (const int*) c->d_order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
+    order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
   const bool train = nrm && c->training_images && c->d_images_cam;
   if (train)
     AGH_LAUNCH_SWEEP(2, kLutProbe, kLutProbe);  // (offline path: one instantiation covers every geometry)
