@@ -1188,10 +1188,15 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
       order = dbg_order;
   }
 #endif
+  long long* sweep_dbg = c->d_dbg;
+#ifdef AGH_DEBUG_HOOKS
+  if (getenv("AGH_DEBUG_CLOCKS_KERNEL"))
+    sweep_dbg = nullptr;  // another kernel's timestamps are wanted (k_taubin_frame)
+#endif
   const bool few = c->geom.x_probes <= 2 && c->geom.y_probes <= 1;
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
   hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
-    r2f, rpad, nrm, img_cell, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, c->d_dbg,             \
+    r2f, rpad, nrm, img_cell, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg,             \
     order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
   const bool train = nrm && c->training_images && c->d_images_cam;
   if (train)

@@ -24,6 +24,7 @@
 // No MFMA: fp64 separately-rounded mul/add is required for bit parity (MFMA fuses), and the work is LDS/VALU bound.
 #include "agh_internal.h"
 
+#include <cstring>
 #include <utility>
 
 #include "taubin_eigen.h"
@@ -44,8 +45,17 @@ template <int CAP>
 __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud)
+  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud, long long* __restrict__ dbg)
 {
+#ifdef AGH_DEBUG_HOOKS  // scripts/moments_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=moments)
+#define AGH_MSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[(int64_t) blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+  long long mt_prod = 0, mt_cons = 0, mt_wait = 0, mt_last = 0;
+#define AGH_MLAP(acc) do { if (dbg) { const long long now_ = wall_clock64(); acc += now_ - mt_last; mt_last = now_; } } while (0)
+#else
+#define AGH_MSTAMP(i) do { } while (0)
+#define AGH_MLAP(acc) do { } while (0)
+#endif
+  AGH_MSTAMP(0);
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
   constexpr int kSortBytes = CAP * 8 + CAP * 2 + (kSortBins + 1) * 4 + kSortBins * 4;
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     }
     return;
   }
+  AGH_MSTAMP(1);
   const float binscale = (float) kSortBins / r2f;  // monotone map of d2 in [0, r2f) onto the sort bins
   // ---- gather + FLANN distance filter + compaction into LDS ----
   // every wave owns the 128-candidate segments j = wave, wave + 4, ... of the concatenated grid rows (FlatRows,
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     }
     return;
   }
+  AGH_MSTAMP(2);
   if (debug_stop == 1)
     return;
   // ---- sort into FLANN's sorted radius-search order: ascending (d2, index) ----
@@ -222,11 +234,15 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   __syncthreads();
   if (debug_stop == 2)
     return;
+  AGH_MSTAMP(3);
   // ---- sorted neighbour list to global (consumed by k_taubin_frame) ----
   for (int i = tid; i < n; i += 256)
     nbr[(int64_t) s * nbr_stride + i] = stage[slot[i]];
   // ---- 37 sequential sums (quadric.cpp:40-131) ----
   double acc = 0.0;
+#ifdef AGH_DEBUG_HOOKS
+  mt_last = wall_clock64();
+#endif
   for (int c0 = 0; c0 < n; c0 += kChunk)
   {
     const int rows = min(kChunk, n - c0);
@@ -288,6 +304,7 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
       }
     }
     __syncthreads();
+    AGH_MLAP(mt_prod);
     if (wave == 0 && lane < kNumSums && rows == kChunk)
     {
       // full chunk: all 56 loads are issued up front (two register halves), so the dependent add chain -- the critical
@@ -322,7 +339,13 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
       for (; k < rows; k++)
         acc += termbuf[k * kNumSums + lane];
     }
+#ifdef AGH_DEBUG_HOOKS
+    if (dbg && acc == 1.2345e300)  // (keeps the adds in front of the clock read)
+      mt_cons++;
+#endif
+    AGH_MLAP(mt_cons);
     __syncthreads();
+    AGH_MLAP(mt_wait);
   }
   if (wave == 0 && lane < kNumSums)
     sums[(int64_t) s * kSumStride + lane] = acc;
@@ -331,6 +354,17 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     nt[s] = n;
     status[s] = kStatusOk;
   }
+  AGH_MSTAMP(4);
+#ifdef AGH_DEBUG_HOOKS
+  if (dbg && threadIdx.x == 0)
+  {
+    dbg[(int64_t) blockIdx.x * 8 + 5] = mt_prod;
+    dbg[(int64_t) blockIdx.x * 8 + 6] = mt_cons;
+    dbg[(int64_t) blockIdx.x * 8 + 7] = mt_wait;
+  }
+#endif
+#undef AGH_MSTAMP
+#undef AGH_MLAP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -533,8 +567,14 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
   double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop,
-  const int* __restrict__ order)
+  const int* __restrict__ order, long long* __restrict__ dbg)
 {
+#ifdef AGH_DEBUG_HOOKS  // scripts/frame_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=frame)
+#define AGH_FSTAMP(i, t) do { if (dbg && threadIdx.x == (t)) dbg[(int64_t) order[blockIdx.x] * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define AGH_FSTAMP(i, t) do { } while (0)
+#endif
+  AGH_FSTAMP(0, 0);
   __shared__ double nx[CAP], ny[CAP], nz[CAP];
   __shared__ int camcnt[2];
   __shared__ int next_col;
@@ -588,6 +628,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   const double a = ev[0], b = ev[1], c = ev[2];
   const double d = 2.0 * ev[3], e = 2.0 * ev[4], f = 2.0 * ev[5];
   const double g = ev[6], h = ev[7], i9 = ev[8];
+  AGH_FSTAMP(1, 0);
   const bool sub = rand_mode && n > 50;  // quadric.cpp:177-193
   const int ks = sub ? 50 : n;
   if (tid < 2)
@@ -621,6 +662,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   if (lane == 0 && cam1)
     atomicAdd(&camcnt[1], cam1);
   __syncthreads();
+  AGH_FSTAMP(2, 0);
   if (debug_stop == 1)
     return;
   // Division of labour in the four-wave variant when the columns are estimated first (more than 64 normals): waves 1..3 run
@@ -837,6 +879,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       if ((lane & 1) == 0 && (lane >> 1) < 28)
         sT[ew][lane >> 1] = R[0];
     }
+    AGH_FSTAMP(3, 64);
     ebar();
     if (et < 28)  // multinomial-weighted moments, once per block
     {
@@ -924,6 +967,8 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       }
     }
   }
+  AGH_FSTAMP(4, 64);  // waves 1..3: candidate list written
+  AGH_FSTAMP(5, 0);   // wave 0: M3 and axis done (split variant)
   if (use3)
   {
     if (wave == 0)
@@ -1022,6 +1067,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     best = small_best;
     best_j = small_best_j;
   }
+  AGH_FSTAMP(6, 0);
   if (debug_stop == 4)
     return;
   // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum)
@@ -1107,7 +1153,9 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       o[1] = normal[1];
       o[2] = normal[2];
     }
+    AGH_FSTAMP(7, 0);
   }
+#undef AGH_FSTAMP
 }
 
 __global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
@@ -1137,6 +1185,12 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   const int Si = (int) S;
   // capacity classes: smallest first; later classes only touch samples flagged kStatusOverflow
   const bool small_first = radius <= 0.015;
+  long long* moments_dbg = nullptr;
+#ifdef AGH_DEBUG_HOOKS
+  if (const char* k = getenv("AGH_DEBUG_CLOCKS_KERNEL"))
+    if (!strcmp(k, "moments") && !small_first)
+      moments_dbg = c->d_dbg;
+#endif
   bool first = true;
   int32_t* zf = c->zero_flags_pending ? c->d_flags : nullptr;
   c->zero_flags_pending = false;
@@ -1144,7 +1198,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
-      zf, c->d_scloud);
+      zf, c->d_scloud, moments_dbg);
     zf = nullptr;
     first = false;
   }
@@ -1154,11 +1208,11 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   if (first || c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
-      zf, c->d_scloud);
+      zf, c->d_scloud, moments_dbg);
   if (c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
-      (int32_t*) nullptr, c->d_scloud);
+      (int32_t*) nullptr, c->d_scloud, (long long*) nullptr);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
@@ -1198,11 +1252,17 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
   // (measured: in the production mode the four-wave kernel is faster -- its 50 exact column sums are shared by four
   // waves -- so the one-wave class serves the all-points pass only: 5.3 -> 4.0 ms at 300k points)
   const bool small_class = radius <= 0.015;
+  long long* frame_dbg = nullptr;
+#ifdef AGH_DEBUG_HOOKS
+  if (const char* k = getenv("AGH_DEBUG_CLOCKS_KERNEL"))
+    if (!strcmp(k, "frame") && !small_class)
+      frame_dbg = c->d_dbg;
+#endif
 #define AGH_LAUNCH_FRAME(CAP, THREADS, NMIN)                                                                            \
   hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(Si), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,      \
     c->d_eig, c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], \
     co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, NMIN, c->debug_stop_frame,           \
-    (const int*) c->d_order)
+    (const int*) c->d_order, frame_dbg)
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
   if (rand_mode && !small_class)
