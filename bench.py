@@ -10,14 +10,15 @@ uniform-grid build (the reference's kd-tree build, hand_search.cpp:10-11) -> Tau
 N = 1 runs BASELINE config C2 (two-view 300k-point cloud, 2000 samples; quadric fit + hand sweep) -- the configuration the
 metric is quoted on.
 
-N > 1, default (--shard samples): the SAME cloud and the SAME 2000 samples, the sample set sharded over the N GPUs
-(rank g searches samples [g S/N, (g+1) S/N)); every rank builds the search grid of the cloud, and the ranks' hypothesis
-lists are exchanged by ONE RCCL all-gather per step issued by the library itself (agh_find_hands_sharded_device, C++ ->
-ncclAllGather on the search's stream over xGMI).  Total work is fixed: "scaling": "strong"; value = hypotheses of the
-merged list per second.  This is the north star's sharding; it pays only when the sample count warrants it (2000 samples
-leave 250 work-groups per GPU at N = 8: see DESIGN.md section 6).
---shard clouds: every rank owns one cloud of the C5 batch (seeds 10..) and searches all of its samples; the results are
-all-gathered the same way (weak scaling; the mode for a stream of independent clouds).
+N > 1, default (--shard clouds) = BASELINE config C5, "batch of 300k-point clouds, samples sharded across the GPUs": the
+sample list of the batch is sharded in cloud order, i.e. GPU g owns cloud g of the batch (seeds 10 + g; the same size and
+make as C2) and searches all 2000 of its samples; the ranks' hypothesis lists are exchanged by ONE RCCL all-gather per step
+issued by the library itself (agh_find_hands_sharded_device, C++ -> ncclAllGather on the search's stream over xGMI).
+Per-GPU work is fixed: "scaling": "weak"; value = hypotheses of the merged list per second.
+--shard samples: ONE cloud (C2 / C4), the SAME sample list whatever N is, sharded over the GPUs (rank g searches samples
+[g S/N, (g+1) S/N)); every rank builds the search grid of the cloud; the same all-gather.  Total work is fixed: "strong".
+It pays only when the sample count warrants it (2000 samples leave 250 work-groups per GPU at N = 8: DESIGN.md section 6).
+A default N > 1 run reports both: the C5 line, and c2_sample_sharded / c4_sample_sharded as extra keys.
 
 Prints ONE JSON line on rank 0.
 """
@@ -282,15 +283,15 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
             "ms_per_step": dt / args.steps * 1e3, "value": n_hyp * args.steps / dt, "unit": "hypotheses/s", "hypotheses": n_hyp}
 
 
-def c4_sharded_secondary(args, dev, stream, rank, world, normals_mode):
-    """N > 1, a second extra key: BASELINE config C4 (1M points, 8000 samples) with its samples sharded over the GPUs --
-    strong scaling on the smallest configuration whose sample count warrants sharding; C2's 2000
-    samples, the headline, do not."""
+def sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, cfg):
+    """N > 1, extra keys: ONE cloud with its samples sharded over the GPUs (strong scaling) -- BASELINE config C4 (1M points,
+    8000 samples), the smallest configuration whose sample count warrants sharding, and C2, whose 2000
+    samples do not (every rank still builds the whole grid and runs the same latency chains)."""
     import torch.distributed as dist
 
     from agile_grasp_amd import binding, synthetic
 
-    sc = synthetic.config("C4")
+    sc = synthetic.config(cfg)
     ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
     idt = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:
@@ -313,7 +314,7 @@ def c4_sharded_secondary(args, dev, stream, rank, world, normals_mode):
         torch.cuda.synchronize()
 
     settle(ctx, step, fence)
-    steps = max(5, args.steps // 2)
+    steps = max(5, args.steps // 2) if cfg == "C4" else args.steps
     for attempt in range(3):
         for _ in range(max(args.warmup, 3)):
             step()
@@ -335,7 +336,7 @@ def c4_sharded_secondary(args, dev, stream, rank, world, normals_mode):
     n_hyp = int(nout_t.item())
     ctx.comm_destroy()
     ctx.close()
-    return {"workload": f"C4: two-view {sc.n}-point cloud, {S} samples sharded over {world} GPUs, one all-gather of the lists",
+    return {"workload": f"{cfg}: two-view {sc.n}-point cloud, {S} samples sharded over {world} GPUs, one all-gather of the lists",
             "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": n_hyp * steps / dt,
             "unit": "hypotheses/s", "hypotheses": n_hyp}
 
@@ -347,7 +348,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "small"])
     ap.add_argument("--normals", default="det", choices=["det", "rand50"])
-    ap.add_argument("--shard", default="samples", choices=["samples", "clouds"],
+    ap.add_argument("--shard", default="clouds", choices=["samples", "clouds"],
                     help="N > 1: shard one cloud's samples over the GPUs (default) or give every GPU its own cloud")
     ap.add_argument("--cpu-samples", type=int, default=1 << 30,
                     help="samples of the cloud the CPU baseline is timed on (default: all of them)")
@@ -538,9 +539,8 @@ def main():
         dt = float(tvals[0].item())
 
     secondary, secondary_c4, hung = None, None, False
-    if distributed and (world > 1 or os.environ.get("AGH_BENCH_FORCE_SECONDARY") == "1") and lib_comm and not by_cloud \
-            and base == "C2" and not classify:
-        # never at the price of the headline line: the extra measurement runs on a watched thread
+    if distributed and (world > 1 or os.environ.get("AGH_BENCH_FORCE_SECONDARY") == "1") and lib_comm and base == "C2" and not classify:
+        # never at the price of the headline line: the extra measurements run on a watched thread
         import threading
 
         box = {}
@@ -549,12 +549,15 @@ def main():
             try:
                 torch.cuda.set_device(dev)
                 torch.cuda.set_stream(tstream)
-                box["res"] = cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode)
+                if by_cloud:  # the other way of using the node: ONE cloud, its samples sharded (strong scaling)
+                    box["res"] = sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, "C2")
+                else:
+                    box["res"] = cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode)
             except Exception as e:
                 box["res"] = {"error": str(e)}
             if "error" not in box["res"] and not args.no_extras:
                 try:
-                    box["c4"] = c4_sharded_secondary(args, dev, stream, rank, world, normals_mode)
+                    box["c4"] = sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, "C4")
                 except Exception as e:
                     box["c4"] = {"error": str(e)}
 
@@ -595,9 +598,9 @@ def main():
                         break
         # whole-path algorithmic bytes (B_alg of BASELINE.md section 4), of this rank's share
         b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_local_hyp + (14112 if classify else 0)
-        # --shard samples (the default at every N, so also the N = 1 member of the driver's 1/2/4/8 series): the SAME cloud and
-        # sample list whatever N is -- total work fixed; --shard clouds: one more cloud per GPU
-        scaling = "weak" if by_cloud else "strong"
+        # --shard clouds (the default; N = 1 is its first member: one cloud on one GPU): one more cloud per GPU -- per-GPU work
+        # fixed; --shard samples: the SAME cloud and sample list whatever N is -- total work fixed
+        scaling = "weak" if (by_cloud or not distributed) else "strong"
         par = "single GPU" if not distributed else (
             f"cloud-per-gpu x{world}: every rank searches its own cloud, one all-gather of the lists" if by_cloud else
             f"sample-sharded x{world}: rank g searches samples [g S/N, (g+1) S/N) of the same cloud, one all-gather of the lists")
@@ -630,13 +633,19 @@ def main():
             "path_GBps": b_alg / (dt / args.steps) / 1e9,
         }
         if secondary is not None:
-            res["cloud_per_gpu"] = secondary
+            res["c2_sample_sharded" if by_cloud else "cloud_per_gpu"] = secondary
         if secondary_c4 is not None:
             res["c4_sample_sharded"] = secondary_c4
-        if distributed and not by_cloud and base == "C2":
-            res["config"]["note"] = ("C2's 2000 samples do not warrant sharding (every rank still builds the whole grid and runs "
-                                     "the same latency chains: DESIGN.md section 6); the node's GPUs are used by cloud_per_gpu (weak) "
-                                     "and c4_sample_sharded (strong), reported beside this line")
+        if distributed and base == "C2":
+            res["config"]["note"] = (
+                "BASELINE config C5: the batch of 300k-point clouds with its samples sharded over the GPUs in cloud order -- GPU g "
+                "searches cloud g (seed 10 + g; N = 1: the C2 cloud), per-GPU work fixed; ONE cloud's samples sharded is reported "
+                "beside it: c4_sample_sharded (8000 samples: strong scaling pays) and c2_sample_sharded (2000 samples do not "
+                "warrant it: every rank still builds the whole grid and runs the same latency chains, DESIGN.md section 6)"
+                if by_cloud else
+                "C2's 2000 samples do not warrant sharding (every rank still builds the whole grid and runs the same latency "
+                "chains: DESIGN.md section 6); the node's GPUs are used by cloud_per_gpu (weak) and c4_sample_sharded (strong), "
+                "reported beside this line")
         if distributed:
             res["config"]["exchange"] = exchange
             res["config"]["segment_records"] = seg[0] if not lib_comm else None

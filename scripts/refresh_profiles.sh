@@ -40,7 +40,7 @@ cd $R
 timeout 400 python bench.py --config C2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_c2.json 2> /dev/null   # the driver's own command line
 # the sample-sharded path through the library's RCCL communicator, as far as one GPU can show it (a communicator of one)
 (AGH_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
-  bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c2_sharded_x1.json)
+  bench.py --gpus 1 --shard samples --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c2_sharded_x1.json)
 timeout 300 python bench.py --config C3 > $OUT/${TAG}_bench_c3.json 2> /dev/null
 timeout 300 python bench.py --config C2 --normals rand50 --no-cpu-baseline > $OUT/${TAG}_bench_c2_rand50.json 2> /dev/null
 timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TAG}_bench_c4.json 2> /dev/null
