@@ -77,6 +77,42 @@ def test_sharded_search_equals_single_gpu(small_scene, svm_model, G):
     assert int(ref_keep.sum()) > 0 and len(ref) > 50
 
 
+def test_cloud_per_rank_is_the_same_sharded_call():
+    """BASELINE config C5 as `bench.py --gpus N` runs it: the sample list of a BATCH of clouds sharded in cloud order, i.e.
+    rank r holds cloud r and its slice of the concatenated list is that cloud's own samples (the other slices are never
+    read by it).  Every rank ends with the concatenation of the clouds' lists, sample positions counted through the batch."""
+    from agile_grasp_amd import binding, synthetic
+
+    G, S = 3, 120
+    scenes = [synthetic.make_scene(30_000, S, seed=60 + r, two_view=True, n_objects=5, name=f"batch_{r}") for r in range(G)]
+    refs = []
+    for sc in scenes:
+        one = binding.Context(sc.cam_origins)
+        one.set_cloud(sc.xyz, sc.cam)
+        refs.append(one.find_hands(sc.samples))
+    assert all(len(r) > 10 for r in refs)
+    ctxs = [binding.Context(sc.cam_origins) for sc in scenes]
+    for c, sc in zip(ctxs, scenes):
+        c.set_cloud(sc.xyz, sc.cam)
+    binding.comm_init_local(ctxs)
+
+    def search(r, c):
+        idx = np.zeros(G * S, np.int32)
+        idx[r * S:(r + 1) * S] = scenes[r].samples
+        return c.find_hands_sharded(idx)
+
+    for hyps in _run_ranks(ctxs, search):
+        assert len(hyps) == sum(len(r) for r in refs)
+        at = 0
+        for r, ref in enumerate(refs):
+            part = hyps[at:at + len(ref)]
+            at += len(ref)
+            assert np.array_equal(part["sample"], ref["sample"] + r * S)
+            for f in FIELDS:
+                if f != "sample":
+                    assert np.array_equal(part[f], ref[f]), (r, f)
+
+
 def test_sharded_antipodal_pass(tiny_scene):
     """calculates_antipodal: the all-points normals pass sharded by point range, cloud_normals_ and the samples' own
     normals all-gathered before the hand search (hand_search.cpp:13-26, 102)."""
