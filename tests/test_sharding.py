@@ -25,6 +25,18 @@ def test_shard_slices_partition_the_samples():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_a_batch_of_equal_clouds_shards_in_cloud_order():
+    """BASELINE config C5 (bench.py --gpus N): G clouds of S samples each, the concatenated list sharded G ways -- rank r's
+    slice is exactly cloud r's samples, so "samples sharded across the GPUs" and "one cloud per GPU" are the same schedule."""
+    from agile_grasp_amd.sharding import shard_slice
+
+    for S in (1, 64, 2000, 8000):
+        for G in (1, 2, 4, 8):
+            for r in range(G):
+                sl = shard_slice(G * S, r, G)
+                assert (sl.start, sl.stop) == (r * S, (r + 1) * S)
+
+
 def test_host_side_slices_equal_the_c_abi():
     """sharding.shard_slice restates agh_shard_slice (so that the bookkeeping needs no built library); the two must agree."""
     from agile_grasp_amd import binding
