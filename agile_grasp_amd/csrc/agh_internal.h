@@ -30,7 +30,7 @@ struct GridDesc
   double inv_cell;
   int dim[3];
   int ncell;
-  unsigned done;     // work-groups of k_bbox that have contributed (reset by the last one)
+  unsigned done;     // (unused since k_cell_count reduces k_bbox's slots itself)
   unsigned ticket;   // tile tickets of k_cell_scan (reset by the holder of the last one)
 };
 

@@ -50,19 +50,19 @@ __device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const floa
   d->ncell = dim[0] * dim[1] * dim[2];
 }
 
-// Bounding box of the cloud and, in the work-group that finishes last, the grid descriptor (one launch instead of
-// init + reduce + finish: a launch costs ~4.7 us of its own on this part, more than any of these does work).
-// Every work-group leaves its six extrema in its own slot of `part` (plain stores) and counts itself in; the last one
-// reduces the slots.  (Six atomicMin/Max per work-group on one cache line cost 128 x 6 x ~12 ns = 9 us of serialised
-// same-line atomics: the kernel took 9.8 us; the arrival counter alone is a sixth of that.)
+// Bounding box of the cloud, first half: every work-group leaves its six extrema in its own slot of `part` (plain stores).
+// The second half -- the reduction of the (<= 128) slots and the grid descriptor -- is done by EVERY work-group of
+// k_cell_count for itself, behind its own point load: the "last work-group finishes" form of this kernel (slot stores, fence,
+// arrival counter, fence, agent-scope reads of the slots, descriptor) was a chain of four memory round trips inside one
+// launch, 8.2 us for a 300k-point cloud of which the point loop is two.  (Six atomicMin/Max per work-group on one cache
+// line, the form before that: 9.8 us.)
 constexpr int kBboxThreads = 1024;
 __global__ __launch_bounds__(kBboxThreads) void k_bbox(const float* __restrict__ xyz, int64_t stride, const int* __restrict__ cloud_off,
-  GridDesc* d, double base_cell, float* __restrict__ part)
+  float* __restrict__ part)
 {
   // blockIdx.y = cloud of the batch
   const int64_t p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
   xyz += p0 * stride;
-  d += blockIdx.y;
   part += (int64_t) blockIdx.y * kBboxBlocks * 6;
   float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
   // (the loop is latency bound: 131072 threads, two points in flight per thread, so a 300k-point cloud takes two rounds)
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(kBboxThreads) void k_bbox(const float* __restrict__
   }
   constexpr int kW = kBboxThreads / 64;
   __shared__ float smn[kW][3], smx[kW][3];
-  __shared__ unsigned last;
   for (int a = 0; a < 3; a++)
     for (int o = 32; o > 0; o >>= 1)
     {
@@ -103,51 +102,78 @@ __global__ __launch_bounds__(kBboxThreads) void k_bbox(const float* __restrict__
       lo = fminf(lo, smn[w][a]);
       hi = fmaxf(hi, smx[w][a]);
     }
-    __hip_atomic_store(&part[blockIdx.x * 6 + a], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&part[blockIdx.x * 6 + 3 + a], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();  // this group's slot is written before its arrival is counted
+    part[blockIdx.x * 6 + a] = lo;
+    part[blockIdx.x * 6 + 3 + a] = hi;
   }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    last = atomicAdd(&d->done, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (last && threadIdx.x < 64)
-  {
-    __threadfence();
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (int b = threadIdx.x; b < (int) gridDim.x; b += 64)
-      for (int a = 0; a < 3; a++)
-      {
-        lo[a] = fminf(lo[a], __hip_atomic_load(&part[b * 6 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        hi[a] = fmaxf(hi[a], __hip_atomic_load(&part[b * 6 + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      }
+}
+
+// The reduction of k_bbox's slots and the grid descriptor, by one work-group for itself (256 threads; `g` in LDS).
+__device__ __forceinline__ void desc_from_parts(const float* __restrict__ part, int nparts, double base_cell, int64_t n, GridDesc* g)
+{
+  __shared__ float red[4][6];
+  const int tid = threadIdx.x, lane = tid & 63;
+  float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+  for (int b = tid; b < nparts; b += blockDim.x)
     for (int a = 0; a < 3; a++)
-      for (int o = 32; o > 0; o >>= 1)
-      {
-        lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
-        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
-      }
-    if (threadIdx.x == 0)
     {
-      d->done = 0u;  // the reset state for the next build
-      desc_finish(d, base_cell, n, lo, hi);
+      lo[a] = fminf(lo[a], part[b * 6 + a]);
+      hi[a] = fmaxf(hi[a], part[b * 6 + 3 + a]);
     }
+  for (int a = 0; a < 3; a++)
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+    }
+  if (lane == 0 && tid < 256)
+    for (int a = 0; a < 3; a++)
+    {
+      red[tid >> 6][a] = lo[a];
+      red[tid >> 6][3 + a] = hi[a];
+    }
+  __syncthreads();
+  if (tid == 0)
+  {
+    for (int a = 0; a < 3; a++)
+      for (int w = 1; w < 4; w++)
+      {
+        lo[a] = fminf(lo[a], red[w][a]);
+        hi[a] = fmaxf(hi[a], red[w][3 + a]);
+      }
+    desc_finish(g, base_cell, n, lo, hi);
   }
+  __syncthreads();
 }
 
 // Cell histogram.  Clouds arrive in voxel order (localization.cpp:282-351), so consecutive points mostly share a cell:
 // each run of equal cells inside a wave issues ONE atomic (with return), and every point remembers its rank inside its
 // cell, which makes the scatter below atomic-free.
 __global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xyz, int64_t stride,
-  const int* __restrict__ cloud_off, const GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ rank_of,
-  int* __restrict__ count)
+  const int* __restrict__ cloud_off, GridDesc* __restrict__ d, int* __restrict__ cell_of, int* __restrict__ rank_of,
+  int* __restrict__ count, const float* __restrict__ part, int nparts, double base_cell)
 {
   const int64_t p0 = cloud_off[blockIdx.y], n = cloud_off[blockIdx.y + 1] - p0;
   xyz += p0 * stride;
   cell_of += p0;
   rank_of += p0;
   count += (int64_t) blockIdx.y * kCellCap;
-  const GridDesc g = d[blockIdx.y];
+  // the grid descriptor from k_bbox's slots: every work-group for itself; the first one of a cloud publishes it for the
+  // kernels after this one
+  __shared__ GridDesc gs;
+  desc_from_parts(part + (int64_t) blockIdx.y * kBboxBlocks * 6, nparts, base_cell, n, &gs);
+  const GridDesc g = gs;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    GridDesc* o = d + blockIdx.y;  // (field by field: `ticket` belongs to k_cell_scan)
+    for (int a = 0; a < 3; a++)
+    {
+      o->mn[a] = g.mn[a];
+      o->dim[a] = g.dim[a];
+    }
+    o->cell = g.cell;
+    o->inv_cell = g.inv_cell;
+    o->ncell = g.ncell;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t step = (int64_t) gridDim.x * blockDim.x;
   const int64_t n_up = (n + 63) & ~(int64_t) 63;  // whole waves iterate together (the shuffles below need all lanes)
@@ -337,11 +363,12 @@ int grid_build(Ctx* c, hipStream_t st)
   }
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
-  hipLaunchKernelGGL(k_bbox, dim3(std::max(1, std::min(nblk, kBboxBlocks)), C), dim3(kBboxThreads), 0, st, c->d_xyz, c->stride_floats,
-    (const int*) c->d_cloud_off, c->d_desc, base_cell, c->d_bbox_part);
-  if (nmax > 0)
-    hipLaunchKernelGGL(k_cell_count, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
-      c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count);
+  const int nparts = std::max(1, std::min(nblk, kBboxBlocks));
+  hipLaunchKernelGGL(k_bbox, dim3(nparts, C), dim3(kBboxThreads), 0, st, c->d_xyz, c->stride_floats,
+    (const int*) c->d_cloud_off, c->d_bbox_part);
+  // (also for an empty cloud: one work-group writes the descriptor of an empty grid)
+  hipLaunchKernelGGL(k_cell_count, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
+    c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count, (const float*) c->d_bbox_part, nparts, base_cell);
   hipLaunchKernelGGL(k_cell_scan, dim3(C == 1 ? 256 : 64, C), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_tile_state,
     c->build_gen, c->d_cell_start, (const int*) c->d_cloud_off);
   if (nmax > 0)
