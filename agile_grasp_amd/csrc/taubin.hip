@@ -526,6 +526,11 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
   const bool writer = (threadIdx.x % LPS) == 0;
   if (s >= S)
     return;
+  // (the sums are read whatever the status says -- the record exists for every sample -- so that the reads do not wait for it)
+  double sv[kNumSums];
+#pragma unroll
+  for (int k = 0; k < kNumSums; k++)
+    sv[k] = sums[(int64_t) s * kSumStride + k];
   const int st_ = status[s];
   // loud capacity / index errors (read back by agh_synchronize and the host entry points)
   if (writer && (st_ == kStatusOverflow || st_ == kStatusRows))
@@ -533,10 +538,9 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
   if (writer && st_ == kStatusBadIndex)
     atomicOr(&flags[0], 4);
   const bool live = st_ == kStatusOk && nt[s] > 0;
-  double sv[kNumSums];
 #pragma unroll
   for (int k = 0; k < kNumSums; k++)
-    sv[k] = live ? sums[(int64_t) s * kSumStride + k] : 0.0;
+    sv[k] = live ? sv[k] : 0.0;
   double v[10];
   const double lambda = taubin_smallest_eigenpair<LPS>(sv, live ? (double) nt[s] : 1.0, v);
   if (!writer)
