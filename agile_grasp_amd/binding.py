@@ -36,7 +36,7 @@ class AghParams(C.Structure):
 
 
 class AghTiming(C.Structure):
-    _fields_ = [("ms", C.c_float * 16), ("name", C.c_char_p * 16), ("n", C.c_int32), ("total_ms", C.c_float)]
+    _fields_ = [("ms", C.c_float * 16), ("name", C.c_char_p * 16), ("n", C.c_int32), ("total_ms", C.c_float), ("count", C.c_int32 * 16)]
 
 
 HYP_DTYPE = np.dtype(
@@ -496,10 +496,15 @@ class Context:
         n = self._check(self.lib.agh_get_hog(self._h, _p(desc, C.c_float), _p(sums, C.c_double), C.c_int64(self.last_n)))
         return desc[:n], sums[:n]
 
-    def timing(self) -> dict:
+    def timing(self, counts: bool = False):
+        """Summed kernel times [ms] per phase since the previous call; with counts=True also the number of timed launches behind
+        each sum (profile level 3 times every fourth call only)."""
         t = AghTiming()
         self._check(self.lib.agh_get_timing(self._h, C.byref(t)))
-        return {t.name[i].decode(): float(t.ms[i]) for i in range(t.n)}
+        ms = {t.name[i].decode(): float(t.ms[i]) for i in range(t.n)}
+        if counts:
+            return ms, {t.name[i].decode(): int(t.count[i]) for i in range(t.n)}
+        return ms
 
     def set_profile(self, level: int):
         self._check(self.lib.agh_set_profile(self._h, C.c_int32(level)))

@@ -276,6 +276,8 @@ struct Ctx
   std::vector<hipEvent_t> ev;
   std::vector<const char*> ev_name;
   int ev_used = 0;
+  unsigned prof_calls = 0;     // profile 3: calls seen; every fourth one is timed
+  bool prof_sampled = false;
   agh_timing timing;
 };
 

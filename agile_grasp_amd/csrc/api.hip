@@ -319,7 +319,14 @@ void timing_mark(Ctx* c, const char* name, hipStream_t st)
 {
   if (!c->p.profile)
     return;
-  if (c->p.profile == 2)  // two events per call: the end of the kernel before the hand sweep, and its own end
+  if (c->p.profile == 3)  // every fourth search: the decision is taken at the first of its two marks
+  {
+    if (std::strcmp(name, "taubin_frame") == 0)
+      c->prof_sampled = (c->prof_calls++ & 3u) == 0;
+    if (!c->prof_sampled)
+      return;
+  }
+  if (c->p.profile >= 2)  // two events per (timed) call: the end of the kernel before the hand sweep, and its own end
   {
     if (std::strcmp(name, "taubin_frame") == 0)
       name = "start";
@@ -1178,12 +1185,13 @@ int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points)
 
 int agh_set_profile(agh_ctx* ctx, int32_t level)
 {
-  if (!ctx || level < 0 || level > 2)
+  if (!ctx || level < 0 || level > 3)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
   c->p.profile = level;
+  c->prof_calls = 0;
   c->ev_used = 0;
   c->ev_name.clear();
   return AGH_OK;
@@ -1220,6 +1228,7 @@ int agh_get_timing(agh_ctx* ctx, agh_timing* out)
       out->name[slot] = c->ev_name[i];
     }
     out->ms[slot] += ms;
+    out->count[slot]++;
     out->total_ms += ms;
   }
   out->n = k;

@@ -386,7 +386,7 @@ def main():
     else:  # one cloud: the whole of it on one GPU, or its samples sharded over the GPUs
         sc = synthetic.config(base)
     normals_mode = binding.NORMALS_RAND50 if args.normals == "rand50" else binding.NORMALS_DETERMINISTIC
-    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0 if args.no_events else 2)
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0 if args.no_events else 3)
     svm = None
     if classify:
         z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
@@ -510,16 +510,17 @@ def main():
             break
         seg[0] = 8 * S
     ctx.synchronize()  # raises if any neighbourhood overflowed the kernels' capacity
-    # HIP events on the launch stream bracket k_hand_sweep inside the timed region (2 events per step; bracketing all
-    # six phases costs ~35 us per step, so the full breakdown comes from a second, untimed pass of K steps).
-    kern = ctx.timing()
+    # HIP events on the launch stream bracket k_hand_sweep inside the timed region -- on every fourth step (profile level 3):
+    # an event record between two dependent kernels costs ~3 us, two per step 6.3 us of a 0.24 ms step (measured: 0.2436
+    # against 0.2373 ms), and bracketing all six phases ~35 us, so the full breakdown comes from a second, untimed pass.
+    kern, kern_n = ctx.timing(counts=True)
     if not args.no_events:
         ctx.set_profile(1)
         for _ in range(args.steps):
             step()
         fence()
         kern_all = ctx.timing()
-        ctx.set_profile(2)
+        ctx.set_profile(3)
     else:
         kern_all = {}
     if not distributed or lib_comm:
@@ -574,7 +575,9 @@ def main():
         # ---- roofline of the kernel that moves the bytes (B_alg): the hand sweep reads 16 B per
         # r = 0.08 neighbour (12 B xyz + 4 B id/cam) and writes 160 B + a 1000 B image per hypothesis slot kept.
         k_ms = {k: v / args.steps for k, v in kern_all.items()}
-        k_ms["hand_sweep"] = kern.get("hand_sweep", 0.0) / args.steps   # the one measured inside the timed region
+        sweep_timed = kern_n.get("hand_sweep", 0)
+        if sweep_timed:
+            k_ms["hand_sweep"] = kern["hand_sweep"] / sweep_timed   # the one measured inside the timed region
         n_local_hyp = n_hyp if not distributed else (int(ctx.epoch()[1]) if ctx.epoch()[1] >= 0 else n_hyp // world)
         n_local_samples = sl.stop - sl.start
         sweep_bytes = 16.0 * float(nh.sum()) + 200.0 * n_local_samples + (160.0 + 1000.0) * n_local_hyp
@@ -627,6 +630,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
+                         "launches_timed": sweep_timed, "launches_timed_note": "HIP events around every fourth k_hand_sweep "
+                         "launch of the timed region (two event records per step cost 6 us of a 0.24 ms step)",
                          "launch_samples": n_local_samples},
             "kernel_ms_per_step": k_ms,
             "path_algorithmic_bytes": b_alg,

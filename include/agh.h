@@ -67,7 +67,8 @@ typedef struct agh_params
   int32_t normals_mode;       /* AGH_NORMALS_* */
   uint32_t rand_seed;         /* srand() seed for AGH_NORMALS_RAND50 */
   int32_t device;             /* HIP device ordinal */
-  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing); 2: only k_hand_sweep */
+  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing); 2: only k_hand_sweep; 3: k_hand_sweep on
+                                 every fourth call (two event records between dependent kernels cost ~6 us per call) */
 } agh_params;
 
 /* One grasp hypothesis, fixed size (160 B).  The variable-size points_for_learning_ of the reference
@@ -117,6 +118,7 @@ typedef struct agh_timing
   const char* name[AGH_TIMING_SLOTS];
   int32_t n;
   float total_ms;
+  int32_t count[AGH_TIMING_SLOTS]; /* timed launches behind ms[i] (profile 3 times a sample of the calls) */
 } agh_timing;
 
 typedef struct agh_ctx agh_ctx;
@@ -317,7 +319,7 @@ int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points);  /* clou
  * AGH_ERR_CAPACITY if n_b > cap.  A lazy getter (one pass over the cloud per call), not part of the hot path. */
 int agh_get_learning_points(agh_ctx* ctx, int64_t hyp, double* points, int32_t* cam_source, int64_t cap, int64_t* n_out);
 int agh_get_timing(agh_ctx* ctx, agh_timing* out);
-/* Change agh_params::profile of a live context (0, 1 or 2); pending timings are dropped. */
+/* Change agh_params::profile of a live context (0 .. 3); pending timings are dropped. */
 int agh_set_profile(agh_ctx* ctx, int32_t level);
 int agh_synchronize(agh_ctx* ctx);
 /* Device self-test of the IEEE assumptions the parity contract rests on (fp64 div/sqrt, fp32 div/sqrt correctly
