@@ -277,7 +277,6 @@ struct Ctx
   std::vector<const char*> ev_name;
   int ev_used = 0;
   unsigned prof_calls = 0;     // profile 3: calls seen; every fourth one is timed
-  bool prof_sampled = false;
   agh_timing timing;
 };
 
@@ -308,6 +307,8 @@ void hog_tables_host(HogTablesDev* t);
 int64_t selftest_math(Ctx* c, int64_t n, uint64_t seed);
 
 void timing_mark(Ctx* c, const char* name, hipStream_t st);
+hipEvent_t timing_next_event(Ctx* c, const char* name);
+bool timing_launch_events(Ctx* c, const char* name, hipEvent_t* start, hipEvent_t* stop);
 void timing_begin(Ctx* c, hipStream_t st);
 int32_t next_epoch();
 int ensure_call_buffers(Ctx* c, int64_t S);

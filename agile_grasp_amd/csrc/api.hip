@@ -319,30 +319,51 @@ void timing_mark(Ctx* c, const char* name, hipStream_t st)
 {
   if (!c->p.profile)
     return;
-  if (c->p.profile == 3)  // every fourth search: the decision is taken at the first of its two marks
-  {
-    if (std::strcmp(name, "taubin_frame") == 0)
-      c->prof_sampled = (c->prof_calls++ & 3u) == 0;
-    if (!c->prof_sampled)
-      return;
-  }
-  if (c->p.profile >= 2)  // two events per (timed) call: the end of the kernel before the hand sweep, and its own end
-  {
-    if (std::strcmp(name, "taubin_frame") == 0)
-      name = "start";
-    else if (std::strcmp(name, "hand_sweep") != 0)
-      return;
-  }
+  if (c->p.profile >= 2)  // only k_hand_sweep is timed, by the two events its own launch carries (timing_launch_events)
+    return;
+  hipEvent_t e = timing_next_event(c, name);
+  if (e)
+    (void) hipEventRecord(e, st);
+}
+
+// The next event of the pool, entered into the list under `name` (nullptr if none can be created).
+hipEvent_t timing_next_event(Ctx* c, const char* name)
+{
   if (c->ev_used >= (int) c->ev.size())
   {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess)
-      return;
+      return nullptr;
     c->ev.push_back(e);
   }
-  (void) hipEventRecord(c->ev[c->ev_used], st);
   c->ev_name.push_back(name);
-  c->ev_used++;
+  return c->ev[c->ev_used++];
+}
+
+// profile 2 / 3: the start and stop events of a k_hand_sweep launch (hipExtLaunchKernelGGL attaches them to the dispatch
+// itself: no barrier packets between the dependent kernels, where two hipEventRecord calls cost ~6 us per step); profile 3
+// hands them out on every fourth call only.  false: launch without events.
+bool timing_launch_events(Ctx* c, const char* name, hipEvent_t* start, hipEvent_t* stop)
+{
+  *start = *stop = nullptr;
+  if (c->p.profile < 2)
+    return false;
+  if (c->p.profile == 3 && (c->prof_calls++ & 3u) != 0)
+    return false;
+  hipEvent_t a = timing_next_event(c, "start");
+  hipEvent_t b = a ? timing_next_event(c, name) : nullptr;
+  if (!b)
+  {
+    if (a)
+    {
+      c->ev_used--;
+      c->ev_name.pop_back();
+    }
+    return false;
+  }
+  *start = a;
+  *stop = b;
+  return true;
 }
 }  // namespace agh
 

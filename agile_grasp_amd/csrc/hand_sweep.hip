@@ -22,6 +22,8 @@
 
 #include <cstddef>
 
+#include <hip/hip_ext.h>
+
 namespace agh
 {
 
@@ -1194,10 +1196,21 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
     sweep_dbg = nullptr;  // another kernel's timestamps are wanted (k_taubin_frame)
 #endif
   const bool few = c->geom.x_probes <= 2 && c->geom.y_probes <= 1;
+  // (profile levels 2 and 3: the launch carries its own start and stop events)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  const bool timed = timing_launch_events(c, "hand_sweep", &ev_start, &ev_stop);
+#define AGH_SWEEP_ARGS                                                                                                  \
+  gv, dg, (const agh_frame*) c->d_frames, d_samples, (const int32_t*) c->d_cam, Si, r2f, rpad, nrm, img_cell, c->d_status, \
+    c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg, order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr),   \
+    (int) c->nbr_stride, c->d_images_cam
 #define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
-  hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, gv, dg, c->d_frames, d_samples, c->d_cam, Si, \
-    r2f, rpad, nrm, img_cell, c->d_status, c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg,             \
-    order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr), (int) c->nbr_stride, c->d_images_cam)
+  do                                                                                                                    \
+  {                                                                                                                     \
+    if (timed)                                                                                                          \
+      hipExtLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, ev_start, ev_stop, 0, AGH_SWEEP_ARGS); \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, AGH_SWEEP_ARGS);                          \
+  } while (0)
   const bool train = nrm && c->training_images && c->d_images_cam;
   if (train)
     AGH_LAUNCH_SWEEP(2, kLutProbe, kLutProbe);  // (offline path: one instantiation covers every geometry)
@@ -1211,6 +1224,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
     AGH_LAUNCH_SWEEP(0, kLutProbe, kLutProbe);
   c->last_has_cam_images = train;
 #undef AGH_LAUNCH_SWEEP
+#undef AGH_SWEEP_ARGS
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }

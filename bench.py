@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1 << 30,
                     help="samples of the cloud the CPU baseline is timed on (default: all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-level", type=int, default=3, choices=[2, 3],
+                    help="HIP events around k_hand_sweep in the timed region: 2 = every launch, 3 = every fourth")
     ap.add_argument("--no-events", action="store_true", help="do not time kernels with HIP events (for rocprofv3 runs)")
     ap.add_argument("--batch-clouds", type=int, default=8,
                     help="N = 1: also time a batch of this many C5 clouds in one context (extra key 'batched'); 0 = skip")
@@ -386,7 +388,7 @@ def main():
     else:  # one cloud: the whole of it on one GPU, or its samples sharded over the GPUs
         sc = synthetic.config(base)
     normals_mode = binding.NORMALS_RAND50 if args.normals == "rand50" else binding.NORMALS_DETERMINISTIC
-    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0 if args.no_events else 3)
+    ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0 if args.no_events else args.event_level)
     svm = None
     if classify:
         z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
@@ -520,7 +522,7 @@ def main():
             step()
         fence()
         kern_all = ctx.timing()
-        ctx.set_profile(3)
+        ctx.set_profile(args.event_level)
     else:
         kern_all = {}
     if not distributed or lib_comm:

@@ -67,8 +67,8 @@ typedef struct agh_params
   int32_t normals_mode;       /* AGH_NORMALS_* */
   uint32_t rand_seed;         /* srand() seed for AGH_NORMALS_RAND50 */
   int32_t device;             /* HIP device ordinal */
-  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing); 2: only k_hand_sweep; 3: k_hand_sweep on
-                                 every fourth call (two event records between dependent kernels cost ~6 us per call) */
+  int32_t profile;            /* 1: time every kernel with HIP events (agh_get_timing); 2: only k_hand_sweep (start / stop events
+                                 attached to its dispatch); 3: the same on every fourth call (a timed launch costs ~6 us) */
 } agh_params;
 
 /* One grasp hypothesis, fixed size (160 B).  The variable-size points_for_learning_ of the reference
