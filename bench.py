@@ -653,6 +653,9 @@ def main():
                 "C2's 2000 samples do not warrant sharding (every rank still builds the whole grid and runs the same latency "
                 "chains: DESIGN.md section 6); the node's GPUs are used by cloud_per_gpu (weak) and c4_sample_sharded (strong), "
                 "reported beside this line")
+        if not distributed:
+            res["config"]["scaling_note"] = ("N = 1 member of the default --gpus N series, which is weak: every GPU searches one cloud "
+                                             "of this size (BASELINE config C5, the batch's samples sharded in cloud order)")
         if distributed:
             res["config"]["exchange"] = exchange
             res["config"]["segment_records"] = seg[0] if not lib_comm else None
