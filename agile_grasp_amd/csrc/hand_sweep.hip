@@ -543,7 +543,12 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       break;
     next_tile();
   }
+  // (no work-group barrier here: a wave's finger logic only reads what the wave itself wrote in pass A -- the table copies of
+  // its own two orientations, its running y extrema -- so a wave whose orientations were rejected by the camera test, or
+  // that is simply ahead, goes on while the others still classify; the phase clocks of the debug build keep the barrier)
+#ifdef AGH_DEBUG_HOOKS
   __syncthreads();
+#endif
   AGH_STAMP(3);
   if (debug_stop == 3)
     return;
