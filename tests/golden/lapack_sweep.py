@@ -3,7 +3,7 @@ script runs the same comparison over MANY C2-sized scenes (300 000 points, the f
 and adds the counts up, so that the rates behind the contract of DESIGN.md section 2.1 -- hypotheses only in one list, SVM label
 flips, index / flag flips -- rest on tens of thousands of hypotheses instead of 1 478; and beside every count it puts the
 YARDSTICK: the LAPACK path against ITSELF with one unit in the last place added to or subtracted from every entry of M.  Needs
-scipy; CPU only; prints one JSON line per scene and a total.  Usage: python tests/golden/lapack_sweep.py [first_seed] [scenes] [samples_per_scene]"""
+scipy; CPU only; prints one JSON line per scene and a total.  Usage: python tests/golden/lapack_sweep.py [first_seed] [scenes] [samples_per_scene] [antipodal | rand50]"""
 import json
 import os
 import sys
@@ -17,6 +17,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 antipodal = len(sys.argv) > 4 and sys.argv[4] == "antipodal"  # calculates_antipodal: the r = 0.01 all-points fits through LAPACK too
+rand50 = len(sys.argv) > 4 and sys.argv[4] == "rand50"        # the reference's production normals mode (50 x rand() % n)
 w, rho = O.load_svm(os.path.join(G.ROOT, "tests", "golden", "svm_032015_linear_20_20_same"))
 keys = ("n_a", "only_a", "only_b", "svm_label_flips", "flips_finger_index", "flips_depth_index", "flips_cam_source", "flips_n_in_box",
         "max_index_mismatch", "degenerate_samples", "flips_half_antipodal", "flips_full_antipodal")
@@ -25,8 +26,8 @@ tot_self, worst_self = {}, {}
 worst = {"max_abs_axis": 0.0, "max_abs_bottom": 0.0, "max_abs_surface": 0.0, "max_abs_width": 0.0, "max_abs_svm_sum": 0.0,
          "max_angle_params_rad": 0.0, "max_abs_n_in_box": 0}
 for k in range(scenes):
-    _sc, _samples, _gold, _hyps, _keep, _sums, rep = G.run_case(None, f"seed{first + k}", ns, w, rho, antipodal=antipodal,
-                                                               self_all=not antipodal)
+    _sc, _samples, _gold, _hyps, _keep, _sums, rep = G.run_case(None, f"seed{first + k}", ns, w, rho, rand50=rand50, antipodal=antipodal,
+                                                               self_all=not (antipodal or rand50))
     rep.setdefault("self", {})
     if antipodal:
         rep["antipodal_set"] = [int(_hyps["half_antipodal"].sum()), int(_hyps["full_antipodal"].sum())]
