@@ -774,7 +774,10 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       next_tile();
     }
   }
+  // (no work-group barrier here either: a wave writes the records and image planes of its own two orientations)
+#ifdef AGH_DEBUG_HOOKS
   __syncthreads();
+#endif
   AGH_STAMP(5);
   if (debug_stop == 5)
     return;
