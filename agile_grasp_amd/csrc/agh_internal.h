@@ -366,6 +366,7 @@ struct RowTable
 {
   int begin[kMaxRows];
   int prefix[kMaxRows + 1];
+  int seg_row[64];  // the row that holds flat candidate 128 j, for the first 64 segments of 128 candidates (FlatRows)
   int nrows;
   int total;
   int bad;
@@ -480,11 +481,15 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
     {
       rt.begin[c0 - 1] = b0;
       rt.prefix[c0] = i0;
+      for (int jj = (i0 - v0 + 127) >> 7; (jj << 7) < i0 && jj < 64; jj++)  // the segment starts inside this row (mostly none or one)
+        rt.seg_row[jj] = c0 - 1;
     }
     if (f1)
     {
       rt.begin[c1 - 1] = b1;
       rt.prefix[c1] = i1;
+      for (int jj = (i1 - v1 + 127) >> 7; (jj << 7) < i1 && jj < 64; jj++)
+        rt.seg_row[jj] = c1 - 1;
     }
     const int tot = __shfl(i1, 63), nkept = __shfl(c1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the totals
     if (tid == 0)
@@ -530,6 +535,7 @@ struct FlatRows
 {
   int pre_lo, pre_hi;  // prefix[k + 1], prefix[k + 65]: the flat index at which row k (k + 64) ENDS
   int adj_lo, adj_hi;  // begin[k] - prefix[k] (rows k, k + 64): position in the sorted array = flat index + adj
+  int seg_v;           // lane j: the first row of segment j (j < 64)
   int nrows, total;
 
   __device__ __forceinline__ void init(const RowTable& rt, int lane)
@@ -540,6 +546,7 @@ struct FlatRows
     pre_hi = lane + 64 < nrows ? rt.prefix[lane + 65] : total;
     adj_lo = lane < nrows ? rt.begin[lane] - rt.prefix[lane] : 0;
     adj_hi = lane + 64 < nrows ? rt.begin[lane + 64] - rt.prefix[lane + 64] : 0;
+    seg_v = (lane << 7) < total ? rt.seg_row[lane] : 0;
   }
   __device__ __forceinline__ int row_end(int r) const  // r wave-uniform; (two reads and a scalar select: no branch)
   {
@@ -565,8 +572,16 @@ struct FlatRows
     const int i0 = start + lane, i1 = i0 + 64;
     h0 = i0 < tot;
     h1 = i1 < tot;
-    while (r0 + 1 < nrows && row_end(r0) <= start)
-      r0++;
+    if (start >= tot)  // (the read-ahead past the last segment)
+    {
+      a0 = a1 = 0;
+      return;
+    }
+    if (j < 64)  // the segment's first row comes from the table build_rows left; later segments walk on from the cursor
+      r0 = __builtin_amdgcn_readlane(seg_v, j);
+    else
+      while (r0 + 1 < nrows && row_end(r0) <= start)
+        r0++;
     int adj = row_adj(r0);
     a0 = adj;
     a1 = adj;
