@@ -345,10 +345,13 @@ __device__ __forceinline__ GridView grid_of_cloud(GridView gv, int k)
 }
 __device__ __forceinline__ int cloud_of_point(const GridView& gv, int p)
 {
-  int k = 0;
-  for (int j = 1; j < gv.n_clouds; j++)
-    k += p >= gv.cloud_off[j] ? 1 : 0;
-  return k;
+  // (p wave-uniform; the offsets of the <= 64 clouds are compared a lane each: one load and a ballot, where a loop over the clouds
+  // was a chain of dependent scalar loads -- 0.6 us per work-group with a batch of eight)
+  if (gv.n_clouds == 1)
+    return 0;
+  const int lane = threadIdx.x & 63;
+  const int off = (lane >= 1 && lane < gv.n_clouds) ? gv.cloud_off[lane] : 0x7fffffff;
+  return __popcll(__ballot(p >= off));
 }
 
 // Squared distance exactly as FLANN's L2_Simple<float> accumulates it (see oracle a2): ((0+dx*dx)+dy*dy)+dz*dz.
