@@ -364,6 +364,20 @@ __device__ __forceinline__ float flann_d2(float qx, float qy, float qz, float px
   return d2;
 }
 
+// Inclusive sum scan over the 64 lanes of a wave by DPP: row_shr 1, 2, 4, 8 inside each 16-lane row (a lane without a source
+// adds zero), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- six v_add_u32_dpp, where a
+// __shfl_up loop is six dependent ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 // Row table of one ball query, built cooperatively in LDS.
 struct RowTable
 {
@@ -465,18 +479,7 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
     const int b0 = tid < nr ? rt.begin[tid] : 0;
     const int b1 = (64 + tid) < nr ? rt.begin[64 + tid] : 0;
     const int f0 = v0 > 0 ? 1 : 0, f1 = v1 > 0 ? 1 : 0;
-    int i0 = v0, i1 = v1, c0 = f0, c1 = f1;
-    for (int o = 1; o < 64; o <<= 1)
-    {
-      const int a = __shfl_up(i0, o), b = __shfl_up(i1, o), c = __shfl_up(c0, o), d = __shfl_up(c1, o);
-      if (tid >= o)
-      {
-        i0 += a;
-        i1 += b;
-        c0 += c;
-        c1 += d;
-      }
-    }
+    int i0 = wave_incl_scan_i32(v0), i1 = wave_incl_scan_i32(v1), c0 = wave_incl_scan_i32(f0), c1 = wave_incl_scan_i32(f1);
     i1 += __shfl(i0, 63);
     c1 += __shfl(c0, 63);
     // (all reads of the table above precede these writes in the wave's program order; a row only moves down)

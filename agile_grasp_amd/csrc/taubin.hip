@@ -194,13 +194,7 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   {
     const int lane_ = tid & 63, w_ = tid >> 6;
     const int v = hist[tid];  // kSortBins == blockDim.x
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1)
-    {
-      const int t = __shfl_up(inc, o);
-      if (lane_ >= o)
-        inc += t;
-    }
+    const int inc = wave_incl_scan_i32(v);
     if (lane_ == 63)
       wsum[w_] = inc;
     __syncthreads();
