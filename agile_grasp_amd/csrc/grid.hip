@@ -217,13 +217,7 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total)
   // 256 threads: wave scan + cross-wave
   __shared__ int wsum[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-  for (int o = 1; o < 64; o <<= 1)
-  {
-    const int t = __shfl_up(inc, o);
-    if (lane >= o)
-      inc += t;
-  }
+  const int inc = wave_incl_scan_i32(v);
   if (lane == 63)
     wsum[w] = inc;
   __syncthreads();

@@ -417,12 +417,7 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
   for (int k = 0; k < per; k++)
     loc += hist[tid * per + k];
   int incl = loc;
-  for (int o = 1; o < 64; o <<= 1)
-  {
-    const int y = __shfl_up(incl, o);
-    if (lane >= o)
-      incl += y;
-  }
+  incl = wave_incl_scan_i32(incl);
   if (lane == 63)
     wave_tot[wave] = incl;
   __syncthreads();
@@ -475,13 +470,7 @@ __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t
       v[u] = (i0 + u < S && nt[i0 + u] > 50) ? 50 : 0;
       sum += v[u];
     }
-    int inc = sum;
-    for (int o = 1; o < 64; o <<= 1)
-    {
-      const int t = __shfl_up(inc, o);
-      if (lane >= o)
-        inc += t;
-    }
+    const int inc = wave_incl_scan_i32(sum);
     int run = carry + inc - sum;
 #pragma unroll
     for (int u = 0; u < kPer; u++)
