@@ -378,6 +378,52 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v)
   return v;
 }
 
+// The value lane (l ^ O) holds, for a double, without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) for
+// O = 32 / 16, DPP moves inside a 16-lane row for O = 8 (row_ror:8), 4 (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and
+// 3), 2 and 1 (quad_perm).  A __shfl_xor of a double is two ds_bpermute round trips (~130 cycles of latency in a dependent
+// butterfly); these are two to four VALU moves.
+template <int O>
+__device__ __forceinline__ int xor_partner_i32(int x)
+{
+  static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "a single bit of the lane index");
+  if (O == 32)
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0] = {x[0..31], x[0..31]}, r[1] = {x[32..63], x[32..63]}
+    return (threadIdx.x & 32) ? (int) r[0] : (int) r[1];
+  }
+  if (O == 16)
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0] = rows {0, 0, 2, 2}, r[1] = rows {1, 1, 3, 3}
+    return (threadIdx.x & 16) ? (int) r[0] : (int) r[1];
+  }
+  if (O == 8)
+    return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+  if (O == 4)
+  {
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);  // row_shl:4 -> lanes 0-3, 8-11 of a row take l + 4
+    return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);         // row_shr:4 -> lanes 4-7, 12-15 take l - 4
+  }
+  if (O == 2)
+    return __builtin_amdgcn_update_dpp(0, x, 0x4e, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+  return __builtin_amdgcn_update_dpp(0, x, 0xb1, 0xf, 0xf, false);    // quad_perm [1, 0, 3, 2]
+}
+template <int O>
+__device__ __forceinline__ double xor_partner_f64(double x)
+{
+  return __hiloint2double(xor_partner_i32<O>(__double2hiint(x)), xor_partner_i32<O>(__double2loint(x)));
+}
+// The butterfly of the oracle's LaneSum64: v + v(l ^ 32), then ^ 16, 8, 4, 2, 1; every lane ends with the same total.
+__device__ __forceinline__ double wave_allsum_f64(double v)
+{
+  v = v + xor_partner_f64<32>(v);
+  v = v + xor_partner_f64<16>(v);
+  v = v + xor_partner_f64<8>(v);
+  v = v + xor_partner_f64<4>(v);
+  v = v + xor_partner_f64<2>(v);
+  v = v + xor_partner_f64<1>(v);
+  return v;
+}
+
 // Row table of one ball query, built cooperatively in LDS.
 struct RowTable
 {

@@ -698,8 +698,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
 #pragma unroll
     for (int k = 0; k < 6; k++)
     {
-      for (int o = 32; o > 0; o >>= 1)
-        m[k] = m[k] + __shfl_xor(m[k], o);
+      m[k] = wave_allsum_f64(m[k]);
       if (lane == 0)
         sM3[k] = m[k];
     }
@@ -1014,9 +1013,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
 #pragma unroll
       for (int u = 0; u < 4; u++)
       {
-        double a = acc[u];
-        for (int o = 32; o > 0; o >>= 1)
-          a = a + __shfl_xor(a, o);
+        const double a = wave_allsum_f64(acc[u]);
         if (c + u < ncnd && (a > best || (a == best && jj[u] < best_j) || best_j == 0x7fffffff))
         {
           best = a;
@@ -1041,8 +1038,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       const double g2 = gdot * gdot;
       acc += (g2 * g2) * g2;
     }
-    for (int o = 32; o > 0; o >>= 1)
-      acc = acc + __shfl_xor(acc, o);
+    acc = wave_allsum_f64(acc);
     if (acc > best || (acc == best && j < best_j) || best_j == 0x7fffffff)
     {
       best = acc;
