@@ -424,6 +424,18 @@ __device__ __forceinline__ double wave_allsum_f64(double v)
   return v;
 }
 
+// Wave-wide integer sum, the same on every lane.
+__device__ __forceinline__ int wave_allsum_i32(int v)
+{
+  v += xor_partner_i32<32>(v);
+  v += xor_partner_i32<16>(v);
+  v += xor_partner_i32<8>(v);
+  v += xor_partner_i32<4>(v);
+  v += xor_partner_i32<2>(v);
+  v += xor_partner_i32<1>(v);
+  return v;
+}
+
 // Row table of one ball query, built cooperatively in LDS.
 struct RowTable
 {
@@ -526,8 +538,8 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
     const int b1 = (64 + tid) < nr ? rt.begin[64 + tid] : 0;
     const int f0 = v0 > 0 ? 1 : 0, f1 = v1 > 0 ? 1 : 0;
     int i0 = wave_incl_scan_i32(v0), i1 = wave_incl_scan_i32(v1), c0 = wave_incl_scan_i32(f0), c1 = wave_incl_scan_i32(f1);
-    i1 += __shfl(i0, 63);
-    c1 += __shfl(c0, 63);
+    i1 += __builtin_amdgcn_readlane(i0, 63);  // (a v_readlane, where __shfl is a ds_bpermute round trip)
+    c1 += __builtin_amdgcn_readlane(c0, 63);
     // (all reads of the table above precede these writes in the wave's program order; a row only moves down)
     if (f0)
     {
@@ -543,7 +555,7 @@ __device__ __forceinline__ void build_rows(const GridView& gv, float qx, float q
       for (int jj = (i1 - v1 + 127) >> 7; (jj << 7) < i1 && jj < 64; jj++)
         rt.seg_row[jj] = c1 - 1;
     }
-    const int tot = __shfl(i1, 63), nkept = __shfl(c1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the totals
+    const int tot = __builtin_amdgcn_readlane(i1, 63), nkept = __builtin_amdgcn_readlane(c1, 63);  // lanes past nr hold zeros, so lane 63 of the second half has the totals
     if (tid == 0)
     {
       rt.prefix[0] = 0;

@@ -118,9 +118,7 @@ __device__ __forceinline__ int cvt_i32_f64_sat(double v)
 
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-  for (int o = 32; o > 0; o >>= 1)
-    v += __shfl_xor(v, o);
-  return v;
+  return wave_allsum_i32(v);  // (v_permlane swaps and DPP moves, no ds_bpermute)
 }
 
 // Cropped points staged in LDS at a time: 2176 x double2 (34 KiB) for the online path, 1728 x (double2 + point id)

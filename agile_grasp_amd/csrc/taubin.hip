@@ -479,7 +479,7 @@ __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t
         draw_ofs[i0 + u] = run;
       run += v[u];
     }
-    carry += __shfl(inc, 63);
+    carry += __builtin_amdgcn_readlane(inc, 63);
   }
   if (lane == 0)
     *total_io = carry;
@@ -541,8 +541,12 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_max_f64_(double v)
 {
-  for (int o = 32; o > 0; o >>= 1)
-    v = fmax(v, __shfl_xor(v, o));
+  v = fmax(v, xor_partner_f64<32>(v));
+  v = fmax(v, xor_partner_f64<16>(v));
+  v = fmax(v, xor_partner_f64<8>(v));
+  v = fmax(v, xor_partner_f64<4>(v));
+  v = fmax(v, xor_partner_f64<2>(v));
+  v = fmax(v, xor_partner_f64<1>(v));
   return v;
 }
 
@@ -644,8 +648,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     cam1 += (int) (__float_as_uint(p.w) & 1u);
   }
   // one LDS atomic per wave (one per neighbour put up to 64 lanes on two addresses, and an LDS atomic serialises them)
-  for (int o = 32; o > 0; o >>= 1)
-    cam1 += __shfl_xor(cam1, o);
+  cam1 = wave_allsum_i32(cam1);
   if (lane == 0 && cam1)
     atomicAdd(&camcnt[1], cam1);
   __syncthreads();
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
         int base = 0;
         if (lane == 0 && mk)
           base = atomicAdd(&ncand, __popcll(mk));
-        base = __shfl(base, 0);
+        base = __builtin_amdgcn_readfirstlane(base);
         if (is_c)
           cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short) j;
       }
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
       int c = 0;
       if (lane == 0)
         c = atomicAdd(&next_col, 4);
-      c = __shfl(c, 0);
+      c = __builtin_amdgcn_readfirstlane(c);
       if (c >= ncnd)
         break;
       int jj[4];
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     int c = 0;
     if (lane == 0)
       c = atomicAdd(&next_col, 1);
-    c = __shfl(c, 0);
+    c = __builtin_amdgcn_readfirstlane(c);
     if (c >= ncnd)
       break;
     const int j = cand[c];
