@@ -1056,7 +1056,10 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   AGH_FSTAMP(6, 0);
   if (debug_stop == 4)
     return;
-  // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum)
+  // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum).  Only the one-column-per-lane path has a
+  // different (best, best_j) in every lane; the column queues leave the same pair in all lanes of a wave (the sums are
+  // butterfly totals), and reducing it again was eighteen ds_bpermute round trips on the work-group's tail.
+  if (small_cols && wave == NW - 1)
   for (int o = 32; o > 0; o >>= 1)
   {
     const double ob = __shfl_down(best, o);
