@@ -539,6 +539,9 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // K1c
 // ---------------------------------------------------------------------------------------------------------------
+// 6! / (a! b! c!) in the order the 28 moments are kept (a = 6 .. 0, b = 6 - a .. 0, c = 6 - a - b): exact small integers
+__device__ const double kMultinomial6[28] = { 1.0, 6.0, 6.0, 15.0, 30.0, 15.0, 20.0, 60.0, 60.0, 20.0, 15.0, 60.0, 90.0, 60.0, 15.0, 6.0, 30.0, 60.0, 60.0, 30.0, 6.0, 1.0, 6.0, 15.0, 20.0, 15.0, 6.0, 1.0 };
+
 __device__ __forceinline__ double wave_max_f64_(double v)
 {
   v = fmax(v, xor_partner_f64<32>(v));
@@ -816,6 +819,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     m3_and_axis();
   else
   {
+    const double mult_et = kMultinomial6[et < 28 ? et : 0];  // (a table read issued here, used two barriers later)
     {
       double T[28];
   #pragma unroll
@@ -870,24 +874,12 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     }
     AGH_FSTAMP(3, 64);
     ebar();
-    if (et < 28)  // multinomial-weighted moments, once per block
+    if (et < 28)  // multinomial-weighted moments, once per block (the weight was fetched before the moments were summed)
     {
-      const double fact[7] = { 1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0 };
-      int k = 0, ea = 0, eb = 0;
-      for (int a = 6; a >= 0; a--)
-        for (int b = 6 - a; b >= 0; b--)
-        {
-          if (k == et)
-          {
-            ea = a;
-            eb = b;
-          }
-          k++;
-        }
       double tsum = sT[0][et];
       for (int w = 1; w < ENW; w++)
         tsum = tsum + sT[w][et];
-      sW[et] = tsum * (fact[6] / ((fact[ea] * fact[eb]) * fact[6 - ea - eb]));
+      sW[et] = tsum * mult_et;
     }
     ebar();
     constexpr int EST = (CAP + ET - 1) / ET;
