@@ -221,8 +221,20 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     const int b = min(kSortBins - 1, (int) (d2 * binscale));
     const int bs = hist[b], be = hist[b + 1];
     int rank = bs;
-    for (int g2 = bs; g2 < be; g2++)
-      rank += (key[perm[g2]] < mine) ? 1 : 0;
+    for (int g2 = bs; g2 < be; g2 += 4)  // four members of the bucket at a time: two LDS round trips per four, not per member
+    {
+      unsigned short pk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        pk[u] = perm[min(g2 + u, be - 1)];
+      unsigned long long kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        kk[u] = key[pk[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        rank += (g2 + u < be && kk[u] < mine) ? 1 : 0;
+    }
     slot[rank] = (unsigned short) k;
   }
   __syncthreads();
