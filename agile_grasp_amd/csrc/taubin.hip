@@ -206,11 +206,28 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
       hist[kSortBins] = n;
     __syncthreads();
   }
-  for (int k = tid; k < n; k += 256)
   {
-    const float d2 = __uint_as_float((unsigned) (key[k] >> 32));
-    const int b = min(kSortBins - 1, (int) (d2 * binscale));
-    perm[hist[b] + atomicAdd(&fillc[b], 1)] = (unsigned short) k;
+    // (a thread's <= CAP / 256 elements together: key reads, then the reservations, then the writes -- three LDS round trips in all
+    // instead of three per element)
+    constexpr int kPerThread = CAP <= 1152 ? (CAP + 255) / 256 : 1;
+    for (int k0 = tid; k0 < n; k0 += 256 * kPerThread)
+    {
+      int bb[kPerThread], pos[kPerThread];
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+      {
+        const int k = k0 + 256 * u;
+        const float d2 = __uint_as_float((unsigned) (key[k < n ? k : k0] >> 32));
+        bb[u] = min(kSortBins - 1, (int) (d2 * binscale));
+      }
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+        pos[u] = (k0 + 256 * u < n) ? hist[bb[u]] + atomicAdd(&fillc[bb[u]], 1) : 0;
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+        if (k0 + 256 * u < n)
+          perm[pos[u]] = (unsigned short) (k0 + 256 * u);
+    }
   }
   __syncthreads();
   for (int g = tid; g < n; g += 256)
@@ -242,19 +259,40 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     return;
   AGH_MSTAMP(3);
   // ---- sorted neighbour list to global (consumed by k_taubin_frame) ----
-  for (int i = tid; i < n; i += 256)
-    nbr[(int64_t) s * nbr_stride + i] = stage[slot[i]];
+  {
+    constexpr int kPerThread = CAP <= 1152 ? (CAP + 255) / 256 : 1;
+    for (int i0 = tid; i0 < n; i0 += 256 * kPerThread)
+    {
+      unsigned short sl[kPerThread];
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+        sl[u] = slot[min(i0 + 256 * u, n > 0 ? n - 1 : 0)];
+      float4 pv[kPerThread];
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+        pv[u] = stage[sl[u]];
+#pragma unroll
+      for (int u = 0; u < kPerThread; u++)
+        if (i0 + 256 * u < n)
+          nbr[(int64_t) s * nbr_stride + i0 + 256 * u] = pv[u];
+    }
+  }
   // ---- 37 sequential sums (quadric.cpp:40-131) ----
   double acc = 0.0;
 #ifdef AGH_DEBUG_HOOKS
   mt_last = wall_clock64();
 #endif
+  // (the chunk's point is fetched a chunk ahead: the two-deep look-up stage[slot[.]] then hides behind the chain of the
+  // chunk before instead of opening every chunk)
+  const int n_last = n > 0 ? n - 1 : 0;
+  float4 p_next = stage[slot[min(lane, n_last)]];
   for (int c0 = 0; c0 < n; c0 += kChunk)
   {
     const int rows = min(kChunk, n - c0);
+    const float4 p = p_next;
+    p_next = stage[slot[min(c0 + kChunk + lane, n_last)]];
     if (lane < rows)
     {
-      const float4 p = stage[slot[c0 + lane]];
       const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
       const double x2 = x * x, y2 = y * y, z2 = z * z;
       const double xy = x * y, yz = y * z, xz = x * z;
