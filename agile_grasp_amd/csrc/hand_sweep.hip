@@ -441,17 +441,20 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
       double ymin = ymin_w[oo], ymax = ymax_w[oo];
       const double ylo = G.ylut_lo, ysc = G.ylut_scale, xlo = G.xlut_lo, xsc = G.xlut_scale;
+      // (the four points of the NEXT pass are read while this pass classifies: one LDS round trip less on every pass)
+      double2 pn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        pn[u] = pts[(lane + 64 * u) < nc ? lane + 64 * u : 0];
       for (int t0 = lane; t0 < nc; t0 += 256)
       {
-        const bool full = (t0 - lane) + 256 <= nc;  // wave-uniform: every lane has its four points
         double xr[4], yr[4];
-        bool act[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
-          const int t = t0 + 64 * u;
-          act[u] = full || t < nc;
-          const double2 p = pts[act[u] ? t : 0];
+          const double2 p = pn[u];
+          const int tn = t0 + 256 + 64 * u;
+          pn[u] = pts[tn < nc ? tn : 0];
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
           yr[u] = sn * p.x + cs * p.y;
         }
