@@ -85,7 +85,7 @@ EXPORTS = [
     "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
     "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images", "agh_comm_rccl_origin",
-    "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_set_segment_records",
+    "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_last_exchange", "agh_comm_set_segment_records",
     "agh_shard_slice", "agh_find_hands_sharded_device", "agh_find_hands_sharded", "agh_classify_sharded_device",
     "agh_classify_sharded",
 ]
@@ -448,6 +448,12 @@ class Context:
         r, n = C.c_int32(0), C.c_int32(0)
         self._check(self.lib.agh_comm_rank(self._h, C.byref(r), C.byref(n)))
         return r.value, n.value
+
+    def comm_last_exchange(self):
+        """(bytes one rank contributed, ranks, True if RCCL moved them) of the last sharded search's hypothesis all-gather."""
+        b, n, v = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.agh_comm_last_exchange(self._h, C.byref(b), C.byref(n), C.byref(v)))
+        return b.value, n.value, bool(v.value)
 
     def find_hands_sharded(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
         samples = np.ascontiguousarray(samples, np.int32)

@@ -566,6 +566,7 @@ int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_
     for (int k = 0; k <= kMaxClouds; k++)
       a.v[k] = c->cloud_off_i32[(size_t) k];
     hipLaunchKernelGGL(k_set_cloud_off, dim3(1), dim3(128), 0, st, a, c->d_cloud_off);
+    HIPCHK(c, hipGetLastError());
     c->cloud_off_on_device = true;
   }
   if (n > c->grid_cap)

@@ -379,6 +379,7 @@ int exchange_and_merge(Ctx* c, uint8_t* d_keep, hipStream_t st)
   int rc = all_gather(c, c->d_xbuf, (size_t) c->shard_seg_bytes, st);
   if (rc != AGH_OK)
     return rc;
+  timing_mark(c, "shard_allgather", st);
   hipLaunchKernelGGL(k_shard_merge, dim3(256), dim3(256), 0, st, (const uint8_t*) c->d_xbuf, c->shard_seg_bytes, c->shard_seg_records,
     cm->n_ranks, c->shard_S, c->shard_out, c->shard_cap, c->shard_nout, d_keep, c->d_flags, c->epoch);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
@@ -510,6 +511,21 @@ int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp)
   return AGH_OK;
 }
 
+int agh_comm_last_exchange(const agh_ctx* ctx, int64_t* segment_bytes, int32_t* n_ranks, int32_t* via_rccl)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (!ctx->c.comm || !ctx->c.shard_out)
+    return AGH_ERR_STATE;
+  if (segment_bytes)
+    *segment_bytes = ctx->c.shard_seg_bytes;
+  if (n_ranks)
+    *n_ranks = ctx->c.comm->n_ranks;
+  if (via_rccl)
+    *via_rccl = ctx->c.comm->nccl ? 1 : 0;
+  return AGH_OK;
+}
+
 int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks)
 {
   if (!ctx)
@@ -521,22 +537,33 @@ int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks)
   return AGH_OK;
 }
 
+// A rank that fails ON ITS OWN (out of memory, a launch error) after the argument checks has left -- or will leave -- the others
+// inside a collective: release them with an error instead of letting them wait for ever.  (In-process communicator; across
+// processes RCCL's own watchdog applies.)  Errors every rank returns alike BEFORE any collective (bad arguments, no cloud, no
+// communicator, an unsupported mode: everything the *_impl functions return while *entered is still false) leave the
+// communicator usable.  After an abort the communicator stays unusable, like an aborted ncclComm: agh_comm_destroy and a
+// new agh_comm_init_local.
+static void shard_release_peers(agh_ctx* ctx, int rc, bool entered)
+{
+  if (rc != AGH_OK && entered && ctx && ctx->c.comm && ctx->c.comm->local)
+    ctx->c.comm->local->abort();
+}
+
 static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
-  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream);
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered);
 
 int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
 {
-  const int rc = find_hands_sharded_device_impl(ctx, d_sample_idx, n_samples, calculates_antipodal, d_out, cap, d_n_out, hip_stream);
-  // A rank that fails on its own (out of memory, a launch error) has left the others inside a collective: release them with
-  // an error instead of letting them wait for ever.  (In-process communicator; across processes RCCL's own watchdog applies.)
-  if (rc != AGH_OK && ctx && ctx->c.comm && ctx->c.comm->local && rc != AGH_ERR_INVALID_ARGUMENT && rc != AGH_ERR_NO_CLOUD)
-    ctx->c.comm->local->abort();
+  bool entered = false;
+  const int rc = find_hands_sharded_device_impl(ctx, d_sample_idx, n_samples, calculates_antipodal, d_out, cap, d_n_out, hip_stream,
+    &entered);
+  shard_release_peers(ctx, rc, entered);
   return rc;
 }
 
 static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
-  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
@@ -564,6 +591,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
              "through all N points in order); use deterministic normals or one GPU for this offline pass";
     return AGH_ERR_STATE;
   }
+  *entered = true;  // from here on a failure is this rank's own
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   const int G = c->comm->n_ranks, r = c->comm->rank;
@@ -702,14 +730,27 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   }
   else  // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must
         // learn of a capacity-class retry from EVERY rank, or this one would repeat the collective alone)
+  {
     hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags);
+    HIPCHK(c, hipGetLastError());
+  }
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
     return rc;
-  timing_mark(c, "shard_exchange", st);
+  timing_mark(c, "shard_merge", st);
   return AGH_OK;
 }
 
+static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered);
+
 int agh_classify_sharded_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream)
+{
+  bool entered = false;
+  const int rc = classify_sharded_device_impl(ctx, d_keep, hip_stream, &entered);
+  shard_release_peers(ctx, rc, entered);
+  return rc;
+}
+
+static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
@@ -724,13 +765,17 @@ int agh_classify_sharded_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream)
     c->err = "agh_classify_sharded: no SVM loaded";
     return AGH_ERR_NO_SVM;
   }
+  *entered = true;
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   // K3 on my own hypotheses: their images are here, svm_keep lands in my segment's records
   int rc = hog_svm(c, std::min<int64_t>(c->last_s * 8, c->shard_seg_records), nullptr, st);
   if (rc != AGH_OK)
     return rc;
-  return exchange_and_merge(c, d_keep, st);
+  if ((rc = exchange_and_merge(c, d_keep, st)) != AGH_OK)
+    return rc;
+  timing_mark(c, "shard_merge", st);
+  return AGH_OK;
 }
 
 static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
@@ -768,13 +813,36 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
   return AGH_OK;
 }
 
+static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out, bool* entered);
+
 int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* out, int64_t cap, int64_t* n_out)
+{
+  bool entered = false;
+  const int rc = find_hands_sharded_host_impl(ctx, sample_idx, n_samples, calculates_antipodal, out, cap, n_out, &entered);
+  shard_release_peers(ctx, rc, entered);  // (the buffer set-up below can fail on one rank alone, before the device variant runs)
+  return rc;
+}
+
+static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
+  agh_hypothesis* out, int64_t cap, int64_t* n_out, bool* entered)
 {
   if (!ctx || !n_out)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
   *n_out = 0;
+  if (!c->comm)
+  {
+    c->err = "agh_find_hands_sharded: no communicator (agh_comm_init)";
+    return AGH_ERR_STATE;
+  }
+  if (c->p.normals_mode == AGH_NORMALS_RAND50 && calculates_antipodal && c->comm->n_ranks > 1)
+  {
+    c->err = "agh_find_hands_sharded: calculates_antipodal with AGH_NORMALS_RAND50 is not sharded (the rand() stream runs "
+             "through all N points in order); use deterministic normals or one GPU for this offline pass";
+    return AGH_ERR_STATE;
+  }
   if (!c->has_cloud)
   {
     c->err = "agh_find_hands_sharded: no cloud set";
@@ -791,6 +859,7 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
       c->err = "agh_find_hands_sharded: sample index out of range";
       return AGH_ERR_INVALID_ARGUMENT;
     }
+  *entered = true;  // every rank passed the same checks on the same arguments: what fails from here on fails on this rank alone
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
   if (rc != AGH_OK)
@@ -845,7 +914,17 @@ int agh_find_hands_sharded(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_sa
   return AGH_OK;
 }
 
+static int classify_sharded_host_impl(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64_t cap, int64_t* n_kept, bool* entered);
+
 int agh_classify_sharded(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64_t cap, int64_t* n_kept)
+{
+  bool entered = false;
+  const int rc = classify_sharded_host_impl(ctx, out, keep, cap, n_kept, &entered);
+  shard_release_peers(ctx, rc, entered);
+  return rc;
+}
+
+static int classify_sharded_host_impl(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64_t cap, int64_t* n_kept, bool* entered)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
@@ -857,6 +936,12 @@ int agh_classify_sharded(agh_ctx* ctx, agh_hypothesis* out, uint8_t* keep, int64
     c->err = "agh_classify_sharded: needs a preceding agh_find_hands_sharded (host variant)";
     return AGH_ERR_STATE;
   }
+  if (!c->has_svm)
+  {
+    c->err = "agh_classify_sharded: no SVM loaded";
+    return AGH_ERR_NO_SVM;
+  }
+  *entered = true;
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t room = c->s_cap * 8;
   if (room > c->keep_cap)

@@ -137,28 +137,34 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
                          "note": "HIP events of an untimed pass of the same steps"}}
 
 
-def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label):
-    """One more single-GPU measurement of the same step on another scene / normals mode (extra keys of the N = 1 line):
-    device-resident cloud and samples, `steps` // 2 timed steps after the same settling and warm-up."""
+def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=None, steps=None):
+    """One more single-GPU measurement of the same step on another scene / normals mode / BASELINE config (extra keys of the
+    N = 1 line): device-resident cloud and samples, `steps` // 2 timed steps after the same settling and warm-up; with `svm`
+    the step ends with Learning::classify (config C3)."""
     from agile_grasp_amd import binding, synthetic
 
     sc = synthetic.config(scene_name)
     ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    if svm is not None:
+        ctx.load_svm(*svm)
     xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
     s_t = torch.from_numpy(sc.samples).to(dev)
     S = sc.samples.size
     out_t = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
     nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    keep_t = torch.zeros(8 * S, dtype=torch.uint8, device=dev)
 
     def step():
         ctx.set_cloud_torch(xyz_t, cam_t, stream=stream)
         ctx.find_hands_torch(s_t, out_t, nout_t, stream=stream)
+        if svm is not None:
+            ctx.classify_torch(keep_t, stream=stream)
 
     settle(ctx, step, torch.cuda.synchronize)
     for _ in range(max(args.warmup, 5)):
         step()
     torch.cuda.synchronize()
-    steps = max(10, args.steps // 2)
+    steps = steps or max(10, args.steps // 2)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -167,7 +173,8 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label):
     ctx.synchronize()
     n_hyp = int(nout_t.item())
     valid = int((ctx.frames()["valid"] != 0).sum())
-    k_ms = {}
+    kept = int(keep_t[:n_hyp].sum().item()) if svm is not None else None
+    k_ms, roof = {}, None
     if not args.no_events:  # per-kernel HIP events of a second, untimed pass
         ctx.set_profile(1)
         ctx.timing()
@@ -175,9 +182,21 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label):
             step()
         torch.cuda.synchronize()
         k_ms = {k: v / steps for k, v in ctx.timing().items()}
+        nt, nh = ctx.neighbor_counts()
+        sweep_bytes = 16.0 * float(nh.sum()) + 200.0 * S + (160.0 + 1000.0) * n_hyp
+        sweep_s = k_ms.get("hand_sweep", 0.0) * 1e-3
+        if sweep_s > 0:
+            roof = {"kernel": "k_hand_sweep", "achieved": sweep_bytes / sweep_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": sweep_bytes / sweep_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": sweep_bytes,
+                    "launch_ms": k_ms["hand_sweep"], "note": "HIP events of an untimed pass of the same steps"}
     ctx.close()
-    return {"workload": label, "points": sc.n, "samples": S, "frames": valid, "hypotheses": n_hyp, "steps": steps,
-            "ms_per_step": dt * 1e3, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_step": k_ms}
+    res = {"workload": label, "points": sc.n, "samples": S, "frames": valid, "hypotheses": n_hyp, "steps": steps,
+           "ms_per_step": dt * 1e3, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_step": k_ms}
+    if kept is not None:
+        res["svm_kept"] = kept
+    if roof is not None:
+        res["roofline"] = roof
+    return res
 
 
 def host_api_extra(args, dev, sc, normals_mode):
@@ -341,6 +360,54 @@ def sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, cfg):
             "unit": "hypotheses/s", "hypotheses": n_hyp}
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks -- one process per GPU, the way the contract's
+    own command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...) -- with
+    this command line, and hand their output (rank 0's JSON line) and exit code through."""
+    import subprocess
+
+    if not args.launch_only:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, {have} visible on this node", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_only_report(args, rank: int, world: int) -> None:
+    """--launch-only: the ranks the launcher started meet over gloo and rank 0 prints who came (one JSON line).  What the
+    CPU test of the launcher drives: no GPU, no library, nothing measured."""
+    import socket
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+                                  "host": socket.gethostname(), "gpus_arg": args.gpus})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "ranks": seen,
+                          "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "external/none"}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -361,12 +428,33 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the extra keys untilted / rand50 / host_api")
     ap.add_argument("--spin-seconds", type=float, default=0.5,
                     help="untimed run of the same step before the warm-up steps, so that the clocks are at their steady state")
+    ap.add_argument("--dist", action="store_true",
+                    help="N = 1: run the sharded entry points on a communicator of ONE rank (RCCL with one rank), the same code "
+                         "path as N > 1")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="start the N ranks, let them meet (gloo, no GPU needed) and report who came; measures nothing")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        sys.exit(launch_ranks(args))  # start the N ranks (torch.distributed.run) and pass their line and exit code through
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if launched and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the two must agree "
+                 f"(python bench.py --gpus N starts its own N ranks when no launcher did)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("AGH_BENCH_FORCE_DIST") == "1"  # (the override exercises the RCCL path on 1 GPU)
+    if args.launch_only:
+        return launch_only_report(args, rank, world)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs HIP device {local_rank}, {torch.cuda.device_count()} visible -- there is no CPU path to "
+              f"fall back to (--gpus {args.gpus})", file=sys.stderr)
+        sys.exit(2)
+    distributed = world > 1 or args.dist
+    if distributed and not launched:  # --dist at N = 1 without a launcher: the rendezvous of one rank, in this process
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     if distributed:
         import torch.distributed as dist
 
@@ -541,8 +629,23 @@ def main():
         dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
         dt = float(tvals[0].item())
 
+    # what the communicator itself says it is, and what its hypothesis all-gather moved (HIP events of the untimed pass above)
+    comm_info = None
+    if distributed:
+        comm_info = {"torch_world_size": world, "launcher": "torch.distributed.run" if launched else "in-process (--dist)"}
+        if lib_comm:
+            seg_b, n_r, via = ctx.comm_last_exchange()
+            ag_ms = kern_all.get("shard_allgather")
+            comm_info.update({"library_comm_ranks": n_r, "library_comm_rank0": ctx.comm_rank()[0], "via_rccl": via,
+                              "rccl_origin": binding.comm_rccl_origin(), "allgather_bytes_per_rank": seg_b,
+                              "allgather_bytes_total": seg_b * n_r,
+                              "allgather_us": (ag_ms / args.steps * 1e3) if ag_ms is not None else None,
+                              "merge_us": (kern_all["shard_merge"] / args.steps * 1e3) if "shard_merge" in kern_all else None})
+            if n_r != world:
+                raise RuntimeError(f"the library's communicator has {n_r} ranks, torch.distributed {world}")
+
     secondary, secondary_c4, hung = None, None, False
-    if distributed and (world > 1 or os.environ.get("AGH_BENCH_FORCE_SECONDARY") == "1") and lib_comm and base == "C2" and not classify:
+    if distributed and lib_comm and base == "C2" and not classify:
         # never at the price of the headline line: the extra measurements run on a watched thread
         import threading
 
@@ -623,10 +726,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: two-view {sc.n}-point tabletop cloud, {S} samples"
-                                   f"{' per GPU' if by_cloud else ''}, {'rand50' if normals_mode else 'deterministic'} normals"
-                                   f"{', + HOG/linear SVM' if classify else ''}",
-                       "points": sc.n, "samples": S, "hypotheses": int(total_hyp), "parallelism": par},
+            "config": {"workload": f"{args.config}: two-view {sc.n}-point tabletop cloud, TILTED scene variant (the scene and both "
+                                   f"camera origins rotated 33 / -19 degrees about the scene pivot before the 3 mm voxel snap, as in a camera "
+                                   f"optical frame: no exactly planar neighbourhoods; the axis-aligned variant of SURVEY 8d is the extra key "
+                                   f"'untilted'), {S} samples{' per GPU' if by_cloud else ''}, "
+                                   f"{'rand50' if normals_mode else 'deterministic'} normals{', + HOG/linear SVM' if classify else ''}",
+                       "scene_variant": "tilted", "points": sc.n, "samples": S, "hypotheses": int(total_hyp), "parallelism": par},
             "samples_per_s": S * (world if by_cloud else 1) * args.steps / dt,
             "roofline": {"bound": "hbm", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
@@ -659,6 +764,7 @@ def main():
         if distributed:
             res["config"]["exchange"] = exchange
             res["config"]["segment_records"] = seg[0] if not lib_comm else None
+            res["comm"] = comm_info
         if classify:
             res["config"]["svm_kept"] = n_kept
         if not distributed and args.batch_clouds > 1 and base == "C2":
@@ -675,6 +781,14 @@ def main():
                 res["untilted_rand50"] = single_cloud_extra(args, dev, stream, "C2u", binding.NORMALS_RAND50,
                                                             "C2u (axis-aligned) in the reference's production mode")
             res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
+            # the other single-GPU BASELINE configs, on the same clock as the headline
+            z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
+            res["c3"] = single_cloud_extra(args, dev, stream, "C2", normals_mode,
+                                           "C3: the C2 cloud (tilted variant) + HOG descriptor + linear SVM "
+                                           "(svm_032015_linear_20_20_same) on every hypothesis", svm=(z["w"], float(z["rho"])))
+            res["c4"] = single_cloud_extra(args, dev, stream, "C4", normals_mode,
+                                           "C4: dense two-view 1000000-point cloud (tilted variant), 8000 samples",
+                                           steps=max(5, args.steps // 4))
         if not args.no_cpu_baseline and not distributed:
             res["cpu_baseline"] = cpu_baseline(sc, min(args.cpu_samples, S), normals_mode, classify, svm)
         elif not args.no_cpu_baseline:

@@ -275,12 +275,18 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks);
 int agh_comm_destroy(agh_ctx* ctx);
 int agh_comm_rank(const agh_ctx* ctx, int32_t* rank, int32_t* n_ranks); /* 0 / 1 without a communicator */
 /* Which RCCL image the library bound ("already mapped: <path>" -- the copy the process had loaded, e.g. PyTorch's --, or
- * "loaded: <name>"); "" before the first agh_comm_unique_id / agh_comm_init, or an error text if none was found.  RCCL is
- * bound at run time: building the library needs neither its headers nor the library itself. */
+ * "loaded: <name>"), or an error text if none was found.  Calling it BINDS RCCL if that has not happened yet (the same one-time
+ * dlopen agh_comm_unique_id / agh_comm_init perform).  RCCL is bound at run time: building the library needs neither its headers
+ * nor the library itself. */
 const char* agh_comm_rccl_origin(void);
 /* Length of the merged list of the last agh_find_hands_sharded (host variant) of this context; AGH_ERR_STATE if the context
  * has no communicator or has not run a sharded search. */
 int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp);
+/* What the hypothesis all-gather of the last agh_find_hands_sharded* call of this context moved: *segment_bytes = bytes every
+ * rank contributed (header + record slots), *n_ranks = ranks of the communicator it ran on (so n_ranks x segment_bytes land in
+ * every rank's exchange buffer), *via_rccl = 1 for ncclAllGather, 0 for the in-process communicator's device copies.  Any of
+ * the three may be NULL.  AGH_ERR_STATE without a communicator or before the first sharded search. */
+int agh_comm_last_exchange(const agh_ctx* ctx, int64_t* segment_bytes, int32_t* n_ranks, int32_t* via_rccl);
 /* Tuning: record slots of one rank's exchange segment (0 = the default described at agh_find_hands_sharded_device; values
  * above 8 per sample are clipped).  Every rank must use the same value. */
 int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records);

@@ -146,6 +146,15 @@ def test_sharded_rand50_mode(small_scene):
     with pytest.raises(binding.AghError) as e:  # the offline all-points pass is not sharded in this mode: loud
         _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples, calculates_antipodal=True))
     assert e.value.code == -8
+    # ... and recoverable: every rank returned the same error before any collective, so the communicator is still usable
+    # (the abort wrapper used to poison the in-process group on this return)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        assert len(hyps) == len(ref)
+    with pytest.raises(binding.AghError) as e:  # classify without a model: the same on every rank, the same recoverable kind
+        _run_ranks(ctxs, lambda r, c: c.classify_sharded())
+    assert e.value.code == -6
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        assert len(hyps) == len(ref)
 
 
 def test_segment_overflow_switches_every_rank_to_full_segments(small_scene):
