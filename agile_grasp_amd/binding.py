@@ -311,7 +311,9 @@ class Context:
     def find_hands(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
         samples = np.ascontiguousarray(samples, np.int32)
         cap = max(8 * samples.shape[0], 1)
-        out = np.zeros(cap, HYP_DTYPE)
+        out = getattr(self, "_out_buf", None)  # (a fresh 2.5 MB numpy array per call is an mmap / munmap pair and page faults)
+        if out is None or out.shape[0] < cap:
+            out = self._out_buf = np.zeros(cap, HYP_DTYPE)
         n = C.c_int64(0)
         self._check(self.lib.agh_find_hands(self._h, _p(samples, C.c_int32), C.c_int64(samples.shape[0]),
                                             C.c_int(1 if calculates_antipodal else 0), out.ctypes.data_as(C.c_void_p),

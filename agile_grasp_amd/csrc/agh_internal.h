@@ -115,12 +115,24 @@ struct VoxWorkspace
 
 struct Comm;  // shard.hip
 
+// Host-buffer entry points: the concatenation kernel (K4) writes every record a second time, straight into pinned host
+// memory of the context, and the count and the error word into a header there -- the list is on the host when the stream
+// drains, with no read-back copies behind the kernels.  rec == nullptr: no mirror (device-resident callers).
+struct HostMirror
+{
+  agh_hypothesis* rec;  // room for `cap` records (list positions beyond it stay on the device only)
+  int64_t cap;
+  int64_t* hdr;         // [0] hypotheses found, [1] flags[0] as the kernel saw it
+};
+
 struct Ctx
 {
   agh_params p;
   HandGeom geom;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t copy_done = nullptr;
+  hipStream_t copy_stream = nullptr;  // host-buffer agh_set_cloud: the camera ids go up here while the grid build's first kernels run
   std::string err;
 
   // cloud
@@ -134,6 +146,15 @@ struct Ctx
   int64_t own_cap_floats = 0;
   int32_t* d_idx_own = nullptr;  // device copy of a host sample list
   int64_t idx_cap = 0;
+  // pinned staging of the host-buffer entry points (hipHostMalloc, device-visible): [256-byte header | sample indices |
+  // records]; the caller's pageable buffers are copied from / to it by the CPU, the GPU reads and writes it directly
+  uint8_t* h_pin = nullptr;
+  int64_t h_pin_samples = 0, h_pin_records = 0;
+  HostMirror mirror{ nullptr, 0, nullptr };  // set by agh_find_hands around its device call
+  uint8_t* h_pin_handles = nullptr;  // agh_find_handles: [256-byte header | hands in | handles out | inlier indices out]
+  int64_t h_pin_handles_cap = 0;     // in hands
+  uint8_t* h_pin_keep = nullptr;     // agh_classify: the keep flags, written by K3 itself
+  int64_t h_pin_keep_cap = 0;
 
   // preprocessing (K-1)
   VoxDesc* d_vox_desc = nullptr;
@@ -142,7 +163,8 @@ struct Ctx
   int* d_vox_blk2 = nullptr;       // popcounts per 4096 bitmap words
   long long* d_vox_total = nullptr;
   unsigned* d_vox_bitmap = nullptr;
-  int64_t vox_bitmap_cap = 0;      // words
+  int64_t vox_bitmap_cap = 0;      // words (a multiple of the popcount block)
+  VoxDesc* h_vox_desc = nullptr;   // pinned host mirror of the descriptor, written by k_vox_lattice / k_vox_totals
   float* d_vox_xyz = nullptr;      // voxelised cloud (packed xyz) and camera ids
   int32_t* d_vox_cam = nullptr;
   int64_t vox_cap = 0;
@@ -181,6 +203,10 @@ struct Ctx
   float4* d_sorted = nullptr;   // n
   int64_t grid_cap = 0;
   bool has_cloud = false;
+  const int32_t* pending_cam_host = nullptr;  // host-buffer agh_set_cloud: camera ids still to upload (grid_build does it while
+  int64_t pending_cam_n = 0;                  // its first three kernels run: only k_scatter reads them)
+  bool cloud_async = false;     // agh_set_cloud (host buffers) left the grid build running on `stream`; a search on ANOTHER
+                                // stream must first wait for it (order_after_cloud)
 
   // per-call buffers (sized for s_cap samples)
   int64_t s_cap = 0;
@@ -280,11 +306,32 @@ struct Ctx
   agh_timing timing;
 };
 
+// a search about to run on `st`: if the host-buffer agh_set_cloud left its grid build running on the context's stream and `st`
+// is another stream, wait for the build first (streams the caller brings may be non-blocking ones)
+inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
+{
+  if (!c->cloud_async)
+    return hipSuccess;
+  c->cloud_async = false;
+  return st == c->stream ? hipSuccess : hipStreamSynchronize(c->stream);
+}
+
 // ---- kernel launchers (defined in the .hip files) ----
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
-  const double workspace[6], double cell, hipStream_t st);
-int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st);
-int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st);
+  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc);
+int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
+  VoxDesc* host_desc);
+// host mirror of the handle search's results (pinned memory of the context; all nullptr / 0: none)
+struct HandleMirror
+{
+  agh_handle* handles;
+  int handle_cap;
+  int* idx;
+  int idx_cap;
+  int* counts;  // [0] handles, [1] inlier indices, [2] error
+};
+int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
+  const HandleMirror& hm);
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);

@@ -241,6 +241,31 @@ int ensure_call_buffers(Ctx* c, int64_t S)
   return AGH_OK;
 }
 
+// pinned staging of the host-buffer entry points: [header | sample indices | records]
+constexpr int64_t kPinHeaderBytes = 256;
+constexpr int64_t kMirrorMaxRecords = 1 << 16;  // 10 MB of pinned memory at most; longer lists finish from the device copy
+static inline int64_t pin_round(int64_t b) { return (b + 255) & ~(int64_t) 255; }
+int ensure_host_staging(Ctx* c, int64_t samples, int64_t records)
+{
+  if (c->h_pin && samples <= c->h_pin_samples && records <= c->h_pin_records)
+    return AGH_OK;
+  const int64_t ns = std::max<int64_t>(std::max<int64_t>(samples, c->h_pin_samples), 1024);
+  const int64_t nr = std::max<int64_t>(std::max<int64_t>(records, c->h_pin_records), 1024);
+  if (c->h_pin)
+  {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void) hipHostFree(c->h_pin);
+    c->h_pin = nullptr;
+    c->h_pin_samples = c->h_pin_records = 0;
+  }
+  void* p = nullptr;
+  HIPCHK(c, hipHostMalloc(&p, (size_t) (kPinHeaderBytes + pin_round(ns * 4) + nr * (int64_t) sizeof(agh_hypothesis)), hipHostMallocDefault));
+  c->h_pin = static_cast<uint8_t*>(p);
+  c->h_pin_samples = ns;
+  c->h_pin_records = nr;
+  return AGH_OK;
+}
+
 // per-cloud grid tables for a batch of C clouds
 int ensure_clouds(Ctx* c, int C)
 {
@@ -496,8 +521,20 @@ void agh_destroy(agh_ctx* ctx)
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
+  if (c->h_pin)
+    (void) hipHostFree(c->h_pin);
+  if (c->h_pin_handles)
+    (void) hipHostFree(c->h_pin_handles);
+  if (c->h_pin_keep)
+    (void) hipHostFree(c->h_pin_keep);
+  if (c->h_vox_desc)
+    (void) hipHostFree(c->h_vox_desc);
   for (hipEvent_t e : c->ev)
     (void) hipEventDestroy(e);
+  if (c->copy_done)
+    (void) hipEventDestroy(c->copy_done);
+  if (c->copy_stream)
+    (void) hipStreamDestroy(c->copy_stream);
   if (c->stream)
     (void) hipStreamDestroy(c->stream);
   delete ctx;
@@ -541,6 +578,7 @@ int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_
   }
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  HIPCHK(c, order_after_cloud(c, st));  // (a build an earlier host-buffer agh_set_cloud left running writes the same tables)
   int rc = ensure_clouds(c, n_clouds);
   if (rc != AGH_OK)
     return rc;
@@ -643,16 +681,26 @@ int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, co
     else
       HIPCHK(c, hipMemcpy2DAsync(c->own_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
                   c->stream));
-    if (cam_source)
-      HIPCHK(c, hipMemcpyAsync(c->own_cam, cam_source, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    if (cam_source)  // (uploaded by grid_build, overlapped with its coordinate-only kernels)
+    {
+      c->pending_cam_host = cam_source;
+      c->pending_cam_n = n;
+    }
     else
       HIPCHK(c, hipMemsetAsync(c->own_cam, 0, sizeof(int32_t) * n, c->stream));
   }
-  int rc = agh_set_cloud_batch_device(ctx, c->own_xyz, dev_stride, c->own_cam, offsets, n_clouds, nullptr);
-  if (rc != AGH_OK)
-    return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return AGH_OK;
+  // (The pageable copies above return when the caller's buffers have been read, so they may be reused at once; the grid
+  // build is left running on the context's stream -- whatever uses the cloud next is ordered behind it there, and an
+  // asynchronous failure surfaces at that call's synchronisation.  Waiting here cost every cloud ~17 us plus the build.)
+  const int rc = agh_set_cloud_batch_device(ctx, c->own_xyz, dev_stride, c->own_cam, offsets, n_clouds, nullptr);
+  if (c->pending_cam_host)  // the build did not get as far as the upload (an early error return)
+  {
+    c->pending_cam_host = nullptr;
+    if (rc == AGH_OK)
+      HIPCHK(c, hipMemcpyAsync(c->own_cam, cam_source, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  }
+  c->cloud_async = rc == AGH_OK;
+  return rc;
 }
 
 // ---- f1: preprocessing (NaN removal, workspace box, per-camera voxelisation), then the grid build ----
@@ -684,35 +732,61 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
       return rc;
     c->vox_cap = n;
   }
-  timing_begin(c, st);
-  if ((rc = vox_stage1(c, d_xyz, stride_bytes / 4, n, size_left, dense, workspace, cell_size, st)) != AGH_OK)
+  if (!c->h_vox_desc)
   {
-    c->err = "preprocessing launch failed";
-    return rc;
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, sizeof(VoxDesc), hipHostMallocDefault));
+    c->h_vox_desc = static_cast<VoxDesc*>(p);
   }
+  timing_begin(c, st);
+  // Round trips: the lattice's size (which sizes the bitmap) is only known after stage 1, the voxel count (which sizes the
+  // search grid) after stage 2.  The second one stays: every launch of the grid build and of the search is sized by it on
+  // the host.  The first is avoided from the second cloud on: stage 2 runs at once for the bitmap the context already has
+  // (a stream of captures of one workspace keeps its lattice within a few per cent), the blocks beyond the lattice are
+  // empty, and a lattice that does not fit raises error 2 -- the bitmap is enlarged and both stages are repeated.  The
+  // descriptor reaches the host through a pinned mirror the kernels write (a pageable read-back cost ~45 us each).
   VoxDesc h;
-  HIPCHK(c, hipMemcpyAsync(&h, c->d_vox_desc, sizeof(h), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));  // the lattice size decides the bitmap allocation: one host round trip
+  for (int attempt = 0;; attempt++)
+  {
+    const bool speculative = c->d_vox_bitmap && c->vox_bitmap_cap > 0;
+    if ((rc = vox_stage1(c, d_xyz, stride_bytes / 4, n, size_left, dense, workspace, cell_size, st,
+           speculative ? c->vox_bitmap_cap : (int64_t) kVoxMaxWords, c->h_vox_desc)) != AGH_OK)
+    {
+      c->err = "preprocessing launch failed";
+      return rc;
+    }
+    if (!speculative)
+    {
+      HIPCHK(c, hipStreamSynchronize(st));  // the first cloud of the context: the lattice size decides the bitmap allocation
+      h = *c->h_vox_desc;
+      if (h.error)
+        break;
+      const int64_t want = (((int64_t) h.n_words + (int64_t) h.n_words / 4) / 4096 + 1) * 4096;  // a quarter of headroom
+      if ((rc = dev_alloc(c, &c->d_vox_bitmap, (size_t) want + 4096)))
+        return rc;
+      c->vox_bitmap_cap = want;
+    }
+    if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, c->vox_bitmap_cap, st, c->h_vox_desc)) != AGH_OK)
+    {
+      c->err = "preprocessing launch failed";
+      return rc;
+    }
+    timing_mark(c, "preprocess", st);
+    HIPCHK(c, hipStreamSynchronize(st));  // the voxel count sizes the search structure
+    h = *c->h_vox_desc;
+    if (h.error != 2 || attempt >= 1)
+      break;
+    // the lattice outgrew the bitmap: drop it, so that the next pass sizes a new one from this cloud's lattice
+    (void) hipFree(c->d_vox_bitmap);
+    c->d_vox_bitmap = nullptr;
+    c->vox_bitmap_cap = 0;
+  }
   if (h.error)
   {
     c->err = "the voxel lattice of the kept points exceeds 2^33 cells (1 GiB bitmap): set a workspace "
              "(Localization::setWorkspace) that bounds the scene";
     return AGH_ERR_CAPACITY;
   }
-  if ((int64_t) h.n_words > c->vox_bitmap_cap || !c->d_vox_bitmap)
-  {
-    if ((rc = dev_alloc(c, &c->d_vox_bitmap, (size_t) h.n_words + 4096)))
-      return rc;
-    c->vox_bitmap_cap = (int64_t) h.n_words;
-  }
-  if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, (int64_t) h.n_words, st)) != AGH_OK)
-  {
-    c->err = "preprocessing launch failed";
-    return rc;
-  }
-  timing_mark(c, "preprocess", st);
-  HIPCHK(c, hipMemcpyAsync(&h, c->d_vox_desc, sizeof(h), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));  // the voxel count sizes the search structure
   const int64_t nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
   if (n_voxels_out)
     *n_voxels_out = nv;
@@ -750,12 +824,11 @@ int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t
       HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
                   c->stream));
   }
-  int rc = agh_preprocess_device(ctx, c->d_raw_xyz, dev_stride, n, size_left, dense, workspace, cell_size, n_voxels_out,
+  // (the grid build is left running on the context's stream, as after agh_set_cloud)
+  const int rc = agh_preprocess_device(ctx, c->d_raw_xyz, dev_stride, n, size_left, dense, workspace, cell_size, n_voxels_out,
     nullptr);
-  if (rc != AGH_OK)
-    return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return AGH_OK;
+  c->cloud_async = rc == AGH_OK;
+  return rc;
 }
 
 // ---- f2: handle search ----
@@ -837,19 +910,45 @@ int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands,
       return rc;
     c->h_cap = (int64_t) cap;
   }
+  // pinned staging (as in agh_find_hands): the hands go up with an asynchronous copy, the handles, the inlier lists and the
+  // counts are written to host memory by the kernels themselves -- one synchronisation, no read-back copies
+  if (n_hands > c->h_pin_handles_cap || !c->h_pin_handles)
+  {
+    const int64_t cap = std::max<int64_t>(n_hands, 1024);
+    if (c->h_pin_handles)
+    {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void) hipHostFree(c->h_pin_handles);
+      c->h_pin_handles = nullptr;
+      c->h_pin_handles_cap = 0;
+    }
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, (size_t) (256 + cap * (int64_t) (sizeof(agh_hypothesis) + sizeof(agh_handle) + sizeof(int32_t))),
+                hipHostMallocDefault));
+    c->h_pin_handles = static_cast<uint8_t*>(p);
+    c->h_pin_handles_cap = cap;
+  }
+  int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
+  agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
+  agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
+  int32_t* h_idx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
+  h_counts[0] = h_counts[1] = h_counts[2] = 0;
   if (n_hands > 0)
-    HIPCHK(c, hipMemcpyAsync(c->d_h_hands, hands, sizeof(agh_hypothesis) * n_hands, hipMemcpyHostToDevice, c->stream));
+  {
+    std::memcpy(h_hands, hands, sizeof(agh_hypothesis) * (size_t) n_hands);
+    HIPCHK(c, hipMemcpyAsync(c->d_h_hands, h_hands, sizeof(agh_hypothesis) * n_hands, hipMemcpyHostToDevice, c->stream));
+  }
   timing_begin(c, c->stream);
-  int rc = handle_search(c, n_hands, x1, x2, min_inliers, min_length, c->stream);
+  const HandleMirror hm{ h_handles, (int) c->h_pin_handles_cap, h_idx, (int) c->h_pin_handles_cap, h_counts };
+  int rc = handle_search(c, n_hands, x1, x2, min_inliers, min_length, c->stream, hm);
   timing_mark(c, "handle_search", c->stream);
   if (rc != AGH_OK)
   {
     c->err = "handle search launch failed";
     return rc;
   }
-  int counts[4] = { 0, 0, 0, 0 };
-  HIPCHK(c, hipMemcpyAsync(counts, c->d_h_counts, sizeof(int) * 3, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int* counts = h_counts;
   if (counts[2])
   {
     c->err = "agh_find_handles: a seed hand has more than 2048 inliers";
@@ -863,8 +962,8 @@ int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands,
   }
   if (counts[0] > 0)
   {
-    HIPCHK(c, hipMemcpy(handles_out, c->d_h_handles, sizeof(agh_handle) * counts[0], hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(inlier_idx_out, c->d_h_idx, sizeof(int32_t) * counts[1], hipMemcpyDeviceToHost));
+    std::memcpy(handles_out, h_handles, sizeof(agh_handle) * (size_t) counts[0]);
+    std::memcpy(inlier_idx_out, h_idx, sizeof(int32_t) * (size_t) counts[1]);
   }
   return AGH_OK;
 }
@@ -912,6 +1011,7 @@ int agh_find_hands_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_s
   }
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  HIPCHK(c, order_after_cloud(c, st));
   const int64_t S = n_samples;
   const int64_t chunk = kNormalsChunk;  // all-points pass batch
   int rc = ensure_call_buffers(c, std::max<int64_t>(S, calculates_antipodal ? std::min<int64_t>(c->n, chunk) : 0));
@@ -1077,19 +1177,44 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
     c->idx_cap = std::max<int64_t>(n_samples, 1024);
   }
   int32_t* d_idx = c->d_idx_own;
+  // Pinned staging owned by the context: the sample list goes up with an asynchronous copy (a pageable hipMemcpyAsync blocks
+  // the host for ~9 us and puts a staging kernel on the stream), and the list comes back WITHOUT read-back copies: K4 writes
+  // every record and the [count | error word] header a second time, into this buffer, so one stream synchronisation is all
+  // the call waits for (round 3 paid three pageable read-backs behind the last kernel: ~0.1 ms of a 0.31 ms call,
+  // profiles/r04_host_timeline_api.txt).
+  if ((rc = ensure_host_staging(c, n_samples, std::min<int64_t>(c->s_cap * 8, kMirrorMaxRecords))) != AGH_OK)
+    return rc;
+  int64_t* hdr = reinterpret_cast<int64_t*>(c->h_pin);
+  int32_t* h_idx = reinterpret_cast<int32_t*>(c->h_pin + kPinHeaderBytes);
+  agh_hypothesis* h_rec = reinterpret_cast<agh_hypothesis*>(c->h_pin + kPinHeaderBytes + pin_round(c->h_pin_samples * 4));
   if (n_samples > 0)
-    HIPCHK(c, hipMemcpyAsync(d_idx, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
+  {
+    std::memcpy(h_idx, sample_idx, sizeof(int32_t) * (size_t) n_samples);
+    HIPCHK(c, hipMemcpyAsync(d_idx, h_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
+  }
   int64_t n = 0;
   for (int attempt = 0; attempt < 2; attempt++)  // (AGH_ERR_RETRY: the context has enabled the larger classes)
   {
+    hdr[0] = -1;  // (stays -1 if no concatenation kernel ran: empty input, a debug stop)
+    hdr[1] = 0;
+    c->mirror = HostMirror{ h_rec, c->h_pin_records, hdr };
     rc = agh_find_hands_device(ctx, d_idx, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
       c->stream);
+    c->mirror = HostMirror{ nullptr, 0, nullptr };
     if (rc == AGH_OK)
     {
-      int32_t flags[8];  // error flags and the count come back with one synchronisation
-      HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      int32_t flags[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+      if (hdr[0] >= 0)
+      {
+        n = hdr[0];
+        flags[0] = (int32_t) hdr[1] | (n > c->s_cap * 8 ? 2 : 0);
+      }
+      else  // no header was written: read the count and the error word the slow way
+      {
+        HIPCHK(c, hipMemcpy(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&n, c->d_nout, sizeof(int64_t), hipMemcpyDeviceToHost));
+      }
       rc = flags_to_status(c, flags);
     }
     else
@@ -1106,8 +1231,11 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
     c->err = "output buffer too small for the hypotheses found";
     return AGH_ERR_CAPACITY;
   }
-  if (n > 0)
-    HIPCHK(c, hipMemcpy(out, c->d_out_own, sizeof(agh_hypothesis) * n, hipMemcpyDeviceToHost));
+  const int64_t from_pin = hdr[0] >= 0 ? std::min<int64_t>(n, c->h_pin_records) : 0;
+  if (from_pin > 0)
+    std::memcpy(out, h_rec, sizeof(agh_hypothesis) * (size_t) from_pin);
+  if (n > from_pin)  // (lists beyond the mirror's room: the rest comes from the device copy)
+    HIPCHK(c, hipMemcpy(out + from_pin, c->d_out_own + from_pin, sizeof(agh_hypothesis) * (size_t) (n - from_pin), hipMemcpyDeviceToHost));
   return AGH_OK;
 }
 

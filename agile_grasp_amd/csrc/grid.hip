@@ -365,6 +365,33 @@ int grid_build(Ctx* c, hipStream_t st)
     c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count, (const float*) c->d_bbox_part, nparts, base_cell);
   hipLaunchKernelGGL(k_cell_scan, dim3(C == 1 ? 256 : 64, C), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_tile_state,
     c->build_gen, c->d_cell_start, (const int*) c->d_cloud_off);
+  if (c->pending_cam_host)
+  {
+    // host-buffer agh_set_cloud: the camera ids (a blocking pageable copy, ~1.2 MB for 300k points) go up while the three
+    // kernels above run -- they read coordinates only.  On a stream of its own: on `st` the transfer would queue behind those
+    // kernels.  A pageable copy returns when the SOURCE has been read (into the runtime's staging buffers), not necessarily
+    // when the data is on the device, so k_scatter waits for an event behind the copy; the coordinates' copy, which was
+    // ordered behind everything earlier on the context's stream, has already returned when this one is issued.
+    if (!c->copy_stream && (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess))
+    {
+      if (c->copy_stream)
+        (void) hipStreamDestroy(c->copy_stream);
+      c->copy_stream = nullptr;
+    }
+    hipStream_t cs = c->copy_stream ? c->copy_stream : st;
+    hipError_t e = hipMemcpyAsync(c->own_cam, c->pending_cam_host, sizeof(int32_t) * (size_t) c->pending_cam_n,
+      hipMemcpyHostToDevice, cs);
+    c->pending_cam_host = nullptr;
+    if (e == hipSuccess && cs != st)
+    {
+      e = hipEventRecord(c->copy_done, cs);
+      if (e == hipSuccess)
+        e = hipStreamWaitEvent(st, c->copy_done, 0);
+    }
+    if (e != hipSuccess)
+      return AGH_ERR_HIP;
+  }
   if (nmax > 0)
     hipLaunchKernelGGL(k_scatter, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, c->d_cam,
       (const int*) c->d_cloud_off, c->d_cell_of, c->d_rank_of, c->d_cell_start, c->d_sorted);

@@ -872,7 +872,8 @@ __global__ __launch_bounds__(256) void k_compact_sums(const agh_hypothesis* __re
     block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sums, int nb, int64_t* __restrict__ n_out)
+__global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sums, int nb, int64_t* __restrict__ n_out,
+  const int32_t* __restrict__ flags_in, HostMirror mir)
 {
   // nb <= 4096: serial chunks of 256 with a wave scan
   __shared__ int ws[4];
@@ -902,12 +903,19 @@ __global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sum
     __syncthreads();
   }
   if (threadIdx.x == 0)
+  {
     *n_out = carry;
+    if (mir.hdr)
+    {
+      mir.hdr[0] = carry;
+      mir.hdr[1] = flags_in[0];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __restrict__ slots, int n,
   const int* __restrict__ block_sums, agh_hypothesis* __restrict__ out, int64_t cap, int32_t* __restrict__ slot_of_hyp,
-  int32_t* __restrict__ flags, int32_t epoch)
+  int32_t* __restrict__ flags, int32_t epoch, HostMirror mir)
 {
   __shared__ int ws[4];
   const int i0 = blockIdx.x * 1024 + threadIdx.x * 4;
@@ -939,6 +947,11 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
         out[pos] = slots[i0 + k];
         out[pos].epoch = epoch;
         slot_of_hyp[pos] = i0 + k;
+        if (mir.rec && pos < mir.cap)
+        {
+          mir.rec[pos] = slots[i0 + k];
+          mir.rec[pos].epoch = epoch;
+        }
       }
       else
         atomicOr(&flags[0], 2);
@@ -950,7 +963,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
 // one work-group scans the S popcounts (output offset of every sample, total count), then 10 threads copy each record
 // (16 bytes per thread, coalesced).
 __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restrict__ vmask, int S, int* __restrict__ offs,
-  int64_t* __restrict__ n_out, const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out)
+  int64_t* __restrict__ n_out, const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out, HostMirror mir)
 {
   // thread t owns the samples [t per, (t + 1) per), per a multiple of 16: its masks arrive as 16-byte loads, all in flight
   // together (one byte per load and iteration made this kernel 15 us for the 16 000 samples of a batch; the buffer is
@@ -997,6 +1010,11 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restr
     *n_out = total;
     if (hdr_flags_out)  // sharded search: this rank's "a neighbourhood beyond the launched capacity classes" travels in its
       *hdr_flags_out = flags_in[0] & 1;  // segment header, so that every rank learns it from the same all-gather
+    if (mir.hdr)
+    {
+      mir.hdr[0] = total;
+      mir.hdr[1] = flags_in[0];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 4; c++)
@@ -1018,7 +1036,7 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restr
 
 __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __restrict__ slots,
   const uint8_t* __restrict__ vmask, const int* __restrict__ offs, int n_slots, agh_hypothesis* __restrict__ out,
-  int64_t cap, int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch)
+  int64_t cap, int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch, HostMirror mir)
 {
   static_assert(sizeof(agh_hypothesis) == 160, "10 x 16 bytes per record");
   static_assert(offsetof(agh_hypothesis, epoch) == 156, "the stamp is the last word of the record");
@@ -1040,6 +1058,8 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
   if (part == 9)
     v.w = (unsigned) epoch;
   reinterpret_cast<uint4*>(out + pos)[part] = v;
+  if (mir.rec && pos < mir.cap)
+    reinterpret_cast<uint4*>(mir.rec + pos)[part] = v;
   if (part == 0)
     slot_of_hyp[pos] = slot;
 }
@@ -1050,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
 __global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __restrict__ slots,
   const uint8_t* __restrict__ vmask, int S, int n_slots, agh_hypothesis* __restrict__ out, int64_t cap,
   int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch, int64_t* __restrict__ n_out,
-  int64_t* __restrict__ hdr_flags_out)
+  int64_t* __restrict__ hdr_flags_out, HostMirror mir)
 {
   __shared__ int wsum[2][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1094,6 +1114,11 @@ __global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __r
     *n_out = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
     if (hdr_flags_out)  // sharded search: see k_compact_offsets
       *hdr_flags_out = flags[0] & 1;
+    if (mir.hdr)  // (bit 1 of the word, "list longer than cap", may still be raised by other work-groups of this launch:
+    {             // the host derives it from the count)
+      mir.hdr[0] = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
+      mir.hdr[1] = flags[0];
+    }
   }
   const int slot = blockIdx.x * 25 + tid / 10, part = tid % 10;
   if (tid >= 250 || slot >= n_slots)
@@ -1115,6 +1140,8 @@ __global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __r
   if (part == 9)
     v.w = (unsigned) epoch;
   reinterpret_cast<uint4*>(out + pos)[part] = v;
+  if (mir.rec && pos < mir.cap)
+    reinterpret_cast<uint4*>(mir.rec + pos)[part] = v;
   if (part == 0)
     slot_of_hyp[pos] = slot;
 }
@@ -1248,22 +1275,23 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
     hipMemsetAsync(d_nout, 0, sizeof(int64_t), st);
     return AGH_OK;
   }
+  const HostMirror mir = c->mirror;
   if (S <= 4096)
     hipLaunchKernelGGL(k_compact_fused, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
-      (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags);
+      (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags, mir);
   else if (S <= 65536)
   {
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
-      d_nout, (const int32_t*) c->d_flags, d_hdr_flags);
+      d_nout, (const int32_t*) c->d_flags, d_hdr_flags, mir);
     hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
-      (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch);
+      (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, mir);
   }
   else
   {
     hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
-    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout);
+    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout, (const int32_t*) c->d_flags, mir);
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
-      c->d_slot_index, c->d_flags, c->epoch);
+      c->d_slot_index, c->d_flags, c->epoch, mir);
   }
   timing_mark(c, "compact", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;

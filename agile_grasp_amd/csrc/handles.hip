@@ -75,10 +75,20 @@ constexpr int kHandleLdsWords = kHandleLdsHands / 64;
 // SMALL: H <= kHandleLdsHands.  The loop is a chain of dependent look-ups per seed (seed row -> inliers -> their
 // positions): the small variant keeps every hand's axis and grasp bottom AND the pair matrix in LDS (106 KiB of the
 // CU's 160), so a seed costs LDS latency only; the general variant prefetches the next seed's row from global memory.  The general variant reads both from global memory.
+// (wave-local ordering of LDS traffic: the loop below is run by ONE wave, whose DS instructions execute in order; this only
+// keeps the compiler from moving them across the point)
+#define AGH_WAVE_SYNC()                                      \
+  do                                                         \
+  {                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
+__global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
   const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
-  int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts)
+  int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts,
+  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts)
 {
   constexpr int kCap = SMALL ? 1024 : kHandleListCap;
   __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
@@ -89,7 +99,8 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
   __shared__ unsigned long long lbits[SMALL ? kHandleLdsHands * kHandleLdsWords : 1];  // the pair matrix (51 KiB)
   __shared__ int s_gap, s_nh, s_nidx;
   const int tid = threadIdx.x;
-  for (int t = tid; t < 128; t += 64)
+  // set-up by the whole work-group (four waves: the tables are ~100 KB of dependent global reads); the walk itself is one wave's
+  for (int t = tid; t < 128; t += 256)
   {
     alive[t] = 0ull;
     elig[t] = 0ull;
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
     s_nidx = 0;
   }
   __syncthreads();
-  for (int j = tid; j < H; j += 64)
+  for (int j = tid; j < H; j += 256)
   {
     if (hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
       atomicOr(&alive[j >> 6], 1ull << (j & 63));
@@ -114,9 +125,11 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
       }
   }
   if (SMALL)
-    for (int k = tid; k < H * W; k += 64)
+    for (int k = tid; k < H * W; k += 256)
       lbits[k] = bits[k];
   __syncthreads();
+  if (tid >= 64)
+    return;
   auto next_seed = [&](int from) -> int {  // first available, eligible seed >= from (H if none)
     for (int w = from >> 6; w < W; w++)
     {
@@ -189,11 +202,87 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
     if (accept && n > kCap)
     {
       if (tid == 0)
+      {
         counts->error = 1;
+        if (host_counts)
+          host_counts[2] = 1;
+      }
       break;
     }
     int kept = 0;
-    if (accept)
+    int out_j = 0;  // n <= 64: lane k holds the k-th inlier of the sorted list
+    if (accept && n <= 64)
+    {
+      // Everything in registers (round 4): one inlier per lane, no LDS list, no barrier.  The members' indices reach the lanes by a
+      // scalar walk over the set bits of the (wave-uniform) non-empty words -- n short iterations; the LDS version paid a
+      // serial loop per WORD lane (most lanes idle) with three dependent LDS reads and two LDS writes per member, then three
+      // work-group barriers and LDS atomics for the gap: ~1.8 us per seed, 343 us for the 184 such seeds of the pipeline's
+      // 499 hands (profiles/r04_host_timeline_pipeline.txt).
+      int my_j = 0, cnt = 0;
+      for (int half = 0; half < (W > 64 ? 2 : 1); half++)
+      {
+        const unsigned long long mm = half ? m1 : m0;
+        unsigned long long nz = __ballot(mm != 0ull);
+        const int lo32 = (int) (unsigned) (mm & 0xffffffffull), hi32 = (int) (unsigned) (mm >> 32);
+        while (nz)
+        {
+          const int w = __ffsll((long long) nz) - 1;
+          nz &= nz - 1ull;
+          unsigned long long mw = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(hi32, w) << 32) |
+                                  (unsigned long long) (unsigned) __builtin_amdgcn_readlane(lo32, w);
+          const int jbase = (half * 64 + w) * 64;
+          while (mw)
+          {
+            const int b = __ffsll((long long) mw) - 1;
+            mw &= mw - 1ull;
+            if (tid == cnt)
+              my_j = jbase + b;
+            cnt++;
+          }
+        }
+      }
+      double de = 0.0;
+      if (tid < n)
+      {
+        double ia[3], d[3];
+        for (int r = 0; r < 3; r++)
+        {
+          ia[r] = SMALL ? hpos[i][r] : hands[i].axis[r];
+          const double ibr = SMALL ? hpos[i][3 + r] : hands[i].bottom[r];
+          d[r] = (SMALL ? hpos[my_j][3 + r] : hands[my_j].bottom[r]) - ibr;
+        }
+        de = dot3d(ia, d);  // dist_along_line (:34)
+      }
+      // rank by (distance, index): std::sort's order, ties by index (the oracle's stated choice); the other entries arrive as
+      // wave-uniform scalars (v_readlane)
+      const int dlo = __double2loint(de), dhi = __double2hiint(de);
+      int rank = 0;
+      for (int k = 0; k < n; k++)
+      {
+        const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+        const int jk = __builtin_amdgcn_readlane(my_j, k);
+        rank += (dk < de || (dk == de && jk < my_j)) ? 1 : 0;
+      }
+      // the sorted list, one entry per lane: lane e sends its entry to lane rank(e) (the ranks of the n active lanes are a
+      // permutation of 0 .. n - 1); idle lanes park theirs on themselves
+      const int dst = (tid < n ? rank : tid) * 4;
+      const int slo = __builtin_amdgcn_ds_permute(dst, dlo), shi = __builtin_amdgcn_ds_permute(dst, dhi);
+      out_j = __builtin_amdgcn_ds_permute(dst, my_j);
+      const double sdv = __hiloint2double(shi, slo);
+      const double nx_d = __hiloint2double(__shfl_down(shi, 1), __shfl_down(slo, 1));
+      const unsigned long long gm = __ballot(tid + 1 < n && nx_d - sdv > 0.02);  // shortenHandle: first gap > 2 cm (:95-99)
+      kept = gm ? __ffsll((long long) gm) - 1 : n;  // the elements before the gap position (:111)
+      accept = kept >= min_inliers && kept > 0;
+      if (accept)
+      {
+        const double s0 = __hiloint2double(__builtin_amdgcn_readlane(shi, 0), __builtin_amdgcn_readlane(slo, 0));
+        const double s1 = __hiloint2double(__builtin_amdgcn_readlane(shi, kept - 1), __builtin_amdgcn_readlane(slo, kept - 1));
+        const double mn = s0 < 10000000 ? s0 : 10000000;      // :62-72, the reference's +-1e7 start values
+        const double mx = s1 > -10000000 ? s1 : -10000000;
+        accept = (mx - mn > min_length);
+      }
+    }
+    else if (accept)
     {
       {
         double ia[3], ib[3];
@@ -220,50 +309,27 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
           }
         }
       }
-      __syncthreads();
-      // rank sort by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
-      if (n <= 64)
+      AGH_WAVE_SYNC();
+      // rank sort by (distance, index)
+      for (int e = tid; e < n; e += 64)
       {
-        // one list entry per lane; the other entries arrive as wave-uniform scalars (v_readlane), so a rank costs n
-        // compares and no LDS round trip
-        const double de = tid < n ? ld[tid] : 0.0;
-        const int je = tid < n ? lj[tid] : 0;
-        const int dlo = __double2loint(de), dhi = __double2hiint(de);
+        const double de = ld[e];
+        const int je = lj[e];
         int rank = 0;
         for (int k = 0; k < n; k++)
-        {
-          const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
-          const int jk = __builtin_amdgcn_readlane(je, k);
-          rank += (dk < de || (dk == de && jk < je)) ? 1 : 0;
-        }
-        if (tid < n)
-        {
-          sd[rank] = de;
-          sj[rank] = je;
-        }
+          rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
+        sd[rank] = de;
+        sj[rank] = je;
       }
-      else
-        for (int e = tid; e < n; e += 64)
-        {
-          const double de = ld[e];
-          const int je = lj[e];
-          int rank = 0;
-          for (int k = 0; k < n; k++)
-            rank += (ld[k] < de || (ld[k] == de && lj[k] < je)) ? 1 : 0;
-          sd[rank] = de;
-          sj[rank] = je;
-        }
-      __syncthreads();
+      AGH_WAVE_SYNC();
       for (int k = tid; k + 1 < n; k += 64)  // shortenHandle: first gap > 2 cm (:95-99)
         if (sd[k + 1] - sd[k] > 0.02)
           atomicMin(&s_gap, k);
-      __syncthreads();
+      AGH_WAVE_SYNC();
       kept = s_gap == 0x7fffffff ? n : s_gap;  // the elements before the gap position (:111)
       accept = kept >= min_inliers && kept > 0;
       if (accept)
       {
-        // :62-72: minimum and maximum over the kept list with the reference's +-1e7 start values (the list is sorted,
-        // so they are its ends)
         const double mn = sd[0] < 10000000 ? sd[0] : 10000000;
         const double mx = sd[kept - 1] > -10000000 ? sd[kept - 1] : -10000000;
         accept = (mx - mn > min_length);
@@ -274,10 +340,12 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
       const int h = s_nh, base = s_nidx;
       for (int k = tid; k < kept; k += 64)
       {
-        inlier_idx[base + k] = sj[k];
-        atomicAnd(&alive[sj[k] >> 6], ~(1ull << (sj[k] & 63)));  // :75-78
+        const int j = n <= 64 ? out_j : sj[k];
+        inlier_idx[base + k] = j;
+        if (host_idx && base + k < host_idx_cap)
+          host_idx[base + k] = j;  // (the host-buffer entry point: the list is on the host when the stream drains)
+        atomicAnd(&alive[j >> 6], ~(1ull << (j & 63)));  // :75-78
       }
-      __syncthreads();
       if (tid == 0)
       {
         h_first[h] = base;
@@ -286,7 +354,7 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
         s_nidx = base + kept;
       }
     }
-    __syncthreads();
+    AGH_WAVE_SYNC();
     const int nxt = next_seed(i + 1);  // (retiring the members may have removed the guessed seed)
     if (nxt == guess)
     {
@@ -297,17 +365,22 @@ __global__ __launch_bounds__(64) void k_handle_greedy(const agh_hypothesis* __re
       load_row(nxt, row0, row1);
     i = nxt;
   }
-  __syncthreads();
+  AGH_WAVE_SYNC();
   if (tid == 0)
   {
     counts->n_handles = s_nh;
     counts->n_idx = s_nidx;
+    if (host_counts)
+    {
+      host_counts[0] = s_nh;
+      host_counts[1] = s_nidx;
+    }
   }
 }
 
 __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __restrict__ hands, const int* __restrict__ h_first,
   const int* __restrict__ h_n, const int* __restrict__ inlier_idx, const HandleCounts* __restrict__ counts,
-  agh_handle* __restrict__ out)
+  agh_handle* __restrict__ out, agh_handle* __restrict__ host_out, int host_cap)
 {
   const int h = blockIdx.x, lane = threadIdx.x;
   if (h >= counts->n_handles)
@@ -405,10 +478,13 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
     hd.n_inliers = n;
     hd.first_inlier = h_first[h];
     out[h] = hd;
+    if (host_out && h < host_cap)
+      host_out[h] = hd;
   }
 }
 
-int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st)
+int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
+  const HandleMirror& hm)
 {
   const int Hi = (int) H, W = (Hi + 63) / 64;
   hipMemsetAsync(c->d_h_counts, 0, sizeof(HandleCounts), st);
@@ -417,16 +493,16 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
     c->d_h_bits, W, c->d_h_rowcnt);
   if (Hi <= kHandleLdsHands)
-    hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+    hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts);
   else
-    hipLaunchKernelGGL(k_handle_greedy<false>, dim3(1), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+    hipLaunchKernelGGL(k_handle_greedy<false>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts));
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts);
   hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
     (const int*) c->d_h_first, (const int*) c->d_h_n, (const int*) c->d_h_idx,
-    (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles);
+    (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles, hm.handles, hm.handle_cap);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 

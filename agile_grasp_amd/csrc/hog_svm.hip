@@ -694,11 +694,23 @@ int agh_classify(agh_ctx* ctx, uint8_t* keep, int64_t cap, int64_t* n_kept)
   }
   if (n == 0)
     return AGH_OK;
-  int rc = agh_classify_device(ctx, c->d_keep, nullptr);
+  // K3 writes the flags straight into pinned host memory of the context: no read-back copy behind the kernel
+  if (n > c->h_pin_keep_cap || !c->h_pin_keep)
+  {
+    if (c->h_pin_keep)
+      (void) hipHostFree(c->h_pin_keep);
+    c->h_pin_keep = nullptr;
+    c->h_pin_keep_cap = 0;
+    void* p = nullptr;
+    HIPCHK2(c, hipHostMalloc(&p, (size_t) std::max<int64_t>(n, 16384), hipHostMallocDefault));
+    c->h_pin_keep = static_cast<uint8_t*>(p);
+    c->h_pin_keep_cap = std::max<int64_t>(n, 16384);
+  }
+  int rc = agh_classify_device(ctx, c->h_pin_keep, nullptr);
   if (rc != AGH_OK)
     return rc;
   HIPCHK2(c, hipStreamSynchronize(c->stream));
-  HIPCHK2(c, hipMemcpy(keep, c->d_keep, n, hipMemcpyDeviceToHost));
+  std::memcpy(keep, c->h_pin_keep, (size_t) n);
   int64_t k = 0;
   for (int64_t i = 0; i < n; i++)
     k += keep[i] ? 1 : 0;

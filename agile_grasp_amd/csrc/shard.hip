@@ -594,6 +594,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   *entered = true;  // from here on a failure is this rank's own
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
+  HIPCHK(c, order_after_cloud(c, st));
   const int G = c->comm->n_ranks, r = c->comm->rank;
   const int64_t S = n_samples;
   const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = hi - lo;

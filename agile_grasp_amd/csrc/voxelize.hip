@@ -208,7 +208,9 @@ __device__ __forceinline__ long long vox_index(float p, double mn, double cell)
   return (long long) floor(((double) p - mn) / cell);
 }
 
-__global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_words)
+// error: 1 = the lattice exceeds max_words (the hard limit), 2 = it exceeds cap_words, the bitmap the host has allocated from an
+// earlier cloud (stage 2 was launched speculatively for that size and does nothing; the host enlarges and repeats).
+__global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_words, unsigned long long cap_words, VoxDesc* host_desc)
 {
   unsigned long long ofs = 0;
   for (int c = 0; c < 2; c++)
@@ -251,6 +253,10 @@ __global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_wo
   d->n_words = ofs;
   if (ofs > max_words)
     d->error = 1;
+  else if (!d->error && ofs > cap_words)
+    d->error = 2;
+  if (host_desc)
+    *host_desc = *d;
 }
 
 __global__ __launch_bounds__(256) void k_vox_mark(const float* __restrict__ xyz, int64_t stride, int64_t n,
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void k_vox_mark(const float* __restrict__ xyz,
   if (i >= n)
     return;
   const unsigned cd = code[i];
-  if (!cd)
+  if (!cd || d->error)
     return;
   const int c = (int) (cd >> 1);
   const float* p = xyz + i * stride;
@@ -290,13 +296,22 @@ __global__ __launch_bounds__(256) void k_vox_popcount(const unsigned* __restrict
     blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__global__ void k_vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, const long long* total)
+__global__ void k_vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, const long long* total, VoxDesc* host_desc)
 {
+  if (d->error)
+  {
+    d->n_vox[0] = d->n_vox[1] = 0;
+    if (host_desc)
+      *host_desc = *d;
+    return;
+  }
   const long long first1 = d->word_ofs[1] / kWordsPerBlock < d->n_words / kWordsPerBlock
                              ? (long long) blk_prefix[d->word_ofs[1] / kWordsPerBlock]
                              : *total;
   d->n_vox[0] = first1;
   d->n_vox[1] = *total - first1;
+  if (host_desc)
+    *host_desc = *d;
 }
 
 // Emit the voxels in bitmap order = (camera, x, y, z) lexicographic order; coordinates as localization.cpp:313-324.
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ b
   int64_t k = (int64_t) blk_prefix[blockIdx.x] + incl - cnt;
   for (int q = 0; q < (int) (threadIdx.x >> 6); q++)
     k += wsum[q];
-  if (!cnt)
+  if (!cnt || d->error)
     return;
   const int c = w0 >= d->word_ofs[1] ? 1 : 0;
   const unsigned long long ny = (unsigned long long) d->dim[c][1], nz = (unsigned long long) d->dim[c][2];
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ b
 }
 
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
-  const double workspace[6], double cell, hipStream_t st)
+  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc)
 {
   VoxWorkspace ws;
   for (int a = 0; a < 3; a++)
@@ -375,11 +390,15 @@ int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int
     hipLaunchKernelGGL(k_vox_classify, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n,
       dense ? (const int*) nullptr : (const int*) c->d_vox_blk, size_left, ws, c->d_vox_code, c->d_vox_desc);
   }
-  hipLaunchKernelGGL(k_vox_lattice, dim3(1), dim3(1), 0, st, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords);
+  hipLaunchKernelGGL(k_vox_lattice, dim3(1), dim3(1), 0, st, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords,
+    (unsigned long long) cap_words, host_desc);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
-int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st)
+// n_words: the lattice's size, or any multiple of kWordsPerBlock above it that the bitmap has room for (the blocks beyond the
+// lattice hold no bits and emit nothing)
+int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
+  VoxDesc* host_desc)
 {
   const int64_t nb2 = n_words / kWordsPerBlock;
   if (hipMemsetAsync(c->d_vox_bitmap, 0, (size_t) n_words * 4, st) != hipSuccess)
@@ -393,7 +412,7 @@ int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, dou
   }
   hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk2, nb2, c->d_vox_total);
   hipLaunchKernelGGL(k_vox_totals, dim3(1), dim3(1), 0, st, c->d_vox_desc, (const int*) c->d_vox_blk2,
-    (const long long*) c->d_vox_total);
+    (const long long*) c->d_vox_total, host_desc);
   if (n > 0 && n_words > 0)
     hipLaunchKernelGGL(k_vox_emit, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
       (const int*) c->d_vox_blk2, (const VoxDesc*) c->d_vox_desc, cell, c->d_vox_xyz, c->d_vox_cam);
