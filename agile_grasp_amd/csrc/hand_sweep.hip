@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   __shared__ double dep_s[24];
   __shared__ OriState ori[8];
   __shared__ unsigned regmask[8][44];
-  __shared__ unsigned pre_s[4][88], suf_s[4][88];
+  __shared__ __attribute__((aligned(16))) unsigned pre_s[4][88];
+  __shared__ unsigned suf_s[4][88];
   __shared__ unsigned img[kImgPlanes][kImageWords + 2];
   // Pass A sets its (region, depth) bits in kRmCopies copies of the table, one per lane & 3, and the finger phase ORs them
   // together: neighbouring lanes hold neighbouring points, which mostly fall into the same table word, and an LDS atomic
@@ -191,14 +192,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   const agh_frame F = frames[s];
   if (!F.valid)
   {
-    if (tid < 8)
-    {
-      agh_hypothesis h;
-      memset(&h, 0, sizeof(h));
-      h.sample = s;
-      h.orientation = tid;
-      slots[(int64_t) s * 8 + tid] = h;
-    }
+    // (no records for orientations without a hypothesis: the concatenation reads vmask, never a dead slot)
     if (tid == 0)
     {
       status[s] = kStatusDegenerate;
@@ -787,16 +781,12 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   {
     const int o = wave + 4 * oo;
     const OriState& O = ori[o];
+    if (O.rejected || !O.has_hand)
+      continue;  // (dead slots are not written: vmask tells the concatenation which are live -- 2.4 MB of stores less at C2)
     agh_hypothesis h;
     memset(&h, 0, sizeof(h));
     h.sample = s;
     h.orientation = o;
-    if (O.rejected || !O.has_hand)
-    {
-      if (lane == 0)
-        slots[(int64_t) s * 8 + o] = h;
-      continue;
-    }
     const double wmin = wave_min_f64(wmin_w[oo]), wmax = wave_max_f64(wmax_w[oo]);
     const int nbox = wave_sum_i32(nbox_w[oo]), numl = wave_sum_i32(numl_w[oo]), numr = wave_sum_i32(numr_w[oo]);
     for (int i = 0; i < 3; i++)
@@ -817,10 +807,17 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     h.valid = 1;
     h.finger_index = O.e;
     h.depth_index = O.last;
+    // the record leaves as ONE 160-byte store of ten lanes (staged through the wave's prefix table, dead since the finger
+    // phase): ten 16-byte stores of one lane were ten partial-line write transactions (WRITE_SIZE 19.8 MB per launch at C2
+    // against 3.4 MB of payload, profiles/r03_pmc_traffic.json)
+    static_assert(sizeof(agh_hypothesis) <= sizeof(pre_s[0]) && sizeof(pre_s[0]) % 16 == 0, "record staging");
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0)
-      slots[(int64_t) s * 8 + o] = h;
+      *reinterpret_cast<agh_hypothesis*>(&pre_s[wave][0]) = h;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    if (lane < 10)
+      reinterpret_cast<uint4*>(slots + ((int64_t) s * 8 + o))[lane] = reinterpret_cast<const uint4*>(&pre_s[wave][0])[lane];
     for (int k = lane; k < kImageWords; k += 64)
     {
       if (TRAIN)  // ins.pts of cam = -1 is the union of the two cameras' points
@@ -855,7 +852,8 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
 // ---------------------------------------------------------------------------------------------------------------
 // K4: concatenate the per-sample lists in sample order (hand_search.cpp:194-200): scan of the slot valid flags.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact_sums(const agh_hypothesis* __restrict__ slots, int n,
+// (slot i is live iff bit (i & 7) of vmask[i >> 3] is set: the sweep does not write the records of dead slots)
+__global__ __launch_bounds__(256) void k_compact_sums(const uint8_t* __restrict__ vmask, int n,
   int* __restrict__ block_sums)
 {
   __shared__ int ws[4];
@@ -863,7 +861,7 @@ __global__ __launch_bounds__(256) void k_compact_sums(const agh_hypothesis* __re
   int sum = 0;
   for (int k = 0; k < 4; k++)
     if (i0 + k < n)
-      sum += slots[i0 + k].valid ? 1 : 0;
+      sum += (vmask[(i0 + k) >> 3] >> ((i0 + k) & 7)) & 1;
   sum = wave_sum_i32(sum);
   if ((threadIdx.x & 63) == 0)
     ws[threadIdx.x >> 6] = sum;
@@ -913,8 +911,8 @@ __global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sum
   }
 }
 
-__global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __restrict__ slots, int n,
-  const int* __restrict__ block_sums, agh_hypothesis* __restrict__ out, int64_t cap, int32_t* __restrict__ slot_of_hyp,
+__global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __restrict__ slots,
+  const uint8_t* __restrict__ vmask, int n, const int* __restrict__ block_sums, agh_hypothesis* __restrict__ out, int64_t cap, int32_t* __restrict__ slot_of_hyp,
   int32_t* __restrict__ flags, int32_t epoch, HostMirror mir)
 {
   __shared__ int ws[4];
@@ -922,7 +920,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
   int v[4], sum = 0;
   for (int k = 0; k < 4; k++)
   {
-    v[k] = (i0 + k < n && slots[i0 + k].valid) ? 1 : 0;
+    v[k] = (i0 + k < n && ((vmask[(i0 + k) >> 3] >> ((i0 + k) & 7)) & 1)) ? 1 : 0;
     sum += v[k];
   }
   int inc = sum;
@@ -1288,9 +1286,9 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
   }
   else
   {
-    hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp);
+    hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp);
     hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout, (const int32_t*) c->d_flags, mir);
-    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, n, c->d_scan_tmp, d_out, cap,
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp, d_out, cap,
       c->d_slot_index, c->d_flags, c->epoch, mir);
   }
   timing_mark(c, "compact", st);

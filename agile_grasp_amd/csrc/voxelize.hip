@@ -400,6 +400,8 @@ int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
   VoxDesc* host_desc)
 {
+  if (n == 0)
+    n_words = 0;  // (no point, no bit: nothing to clear, count or emit; the block counts are not even written)
   const int64_t nb2 = n_words / kWordsPerBlock;
   if (hipMemsetAsync(c->d_vox_bitmap, 0, (size_t) n_words * 4, st) != hipSuccess)
     return AGH_ERR_HIP;
