@@ -179,6 +179,7 @@ struct Ctx
   int* d_h_n = nullptr;
   int* d_h_idx = nullptr;
   int* d_h_counts = nullptr;  // HandleCounts
+  int* d_h_tmp = nullptr;     // h_cap: scratch of k_handle_batch (inlier lists in commit order)
   agh_handle* d_h_handles = nullptr;
   int64_t h_cap = 0;
 

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void k_handle_pairs(const agh_hypothesis* __re
 struct HandleCounts
 {
   int n_handles, n_idx, error;
+  int sequential;  // set by k_handle_batch when it declines (a seed with more than 64 potential inliers): k_handle_greedy runs
 };
 
 constexpr int kHandleLdsHands = 640;  // hands whose axis, bottom and pair-matrix rows fit the LDS of the small variant
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __r
   int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts)
 {
   constexpr int kCap = SMALL ? 1024 : kHandleListCap;
+  if (!counts->sequential)  // (k_handle_batch has done the search)
+    return;
   __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
   __shared__ unsigned long long elig[128];   // rows with at least min_inliers inliers at all (no global load per seed)
   __shared__ double ld[kCap], sd[kCap];
@@ -378,6 +381,375 @@ __global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __r
   }
 }
 
+
+// K5b', the walk of handle_search.cpp:11-80 with its seeds evaluated SIXTEEN AT A TIME (round 4).  The walk is sequential in its
+// seeds, but a seed only ever interacts with the hands of its own row of the pair matrix: a REJECTED seed changes nothing, an
+// accepted one retires members of its row.  So the next sixteen open seeds (in index order) are evaluated in parallel against
+// the availability at the start of the round, one wave each, everything in registers (one inlier per lane: this kernel serves
+// pair matrices whose rows hold at most 64 hands, k_handle_greedy the others), and then committed AS IF in index order:
+//   * a seed that shares a hand with an EARLIER seed of the batch which was accepted in this round (its evaluation may be
+//     stale, or the seed itself is gone) or which stays open itself (whatever that one may yet retire must not be judged
+//     before it) stays open: it is evaluated again next round, after everything it depends on;
+//   * every other seed's evaluation is exactly what the sequential walk would have computed at its turn: it is committed
+//     (rejected for good, or accepted: members retired).  "Shares a hand" is a test on the rows & availability (every row
+//     holds its own seed), a 16 x 16 relation built by the waves in parallel; the open / committed decision is then a
+//     sixteen-step recurrence on two scalar masks.
+// Seeds committed out of index order belong to disjoint rows, so the handles they produce are the sequential walk's handles;
+// only their ORDER of discovery differs, and the epilogue sorts the accepted handles by seed index and lays the inlier
+// lists out in that order (handle_search.cpp:79 appends in seed order).  One work-group of 16 waves; the sequential kernel
+// spent ~1.5 us per seed in one wave's dependent LDS / cross-lane chain (305 us for the 192 seeds of the pipeline's 499 hands).
+template <bool SMALL>
+__global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __restrict__ hands, int H,
+  const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
+  int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts,
+  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts, int* __restrict__ tmp)
+{
+  constexpr int kBatch = 16;
+  __shared__ unsigned long long alive[128], elig[128], done[128];  // W <= 128 (H <= 8192)
+  __shared__ double hpos[SMALL ? kHandleLdsHands : 1][6];  // axis, bottom
+  __shared__ unsigned long long lbits[SMALL ? kHandleLdsHands * kHandleLdsWords : 1];
+  __shared__ int cand[kBatch], res_acc[kBatch], res_kept[kBatch];
+  __shared__ unsigned long long rowm[kBatch][128];  // row & availability of the round's candidates
+  __shared__ unsigned imask[kBatch];
+  __shared__ int c_open[kBatch], c_h[kBatch], c_base[kBatch];
+  __shared__ unsigned short mlist[kBatch][64];
+  __shared__ int n_cand, s_nh, s_nidx, s_maxrow, tot_nh, tot_nidx;
+  // per accepted handle, in commit order: seed, offset of its list in tmp_idx, length; then the handles by ascending seed
+  // (in LDS: the epilogue's rank and prefix loops would otherwise be chains of dependent global loads)
+  // All in LDS, as 16-bit words (H <= 8192): a global store in the commit phase makes the round's closing barrier wait for
+  // the memory system (~2 us per round, measured), and the epilogue's loops would be chains of dependent global loads.
+  constexpr int kHandlesCap = SMALL ? kHandleLdsHands : 8192;
+  __shared__ unsigned short tmp_seed[kHandlesCap], tmp_base[kHandlesCap], tmp_n[kHandlesCap], tmp_order[kHandlesCap];
+  __shared__ unsigned short tmp_idx[kHandlesCap];  // inlier lists in commit order
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  (void) tmp;
+  for (int t = tid; t < 128; t += 1024)
+  {
+    alive[t] = 0ull;
+    elig[t] = 0ull;
+    done[t] = 0ull;
+  }
+  if (tid == 0)
+  {
+    s_nh = 0;
+    s_nidx = 0;
+    s_maxrow = 0;
+  }
+  __syncthreads();
+  for (int j = tid; j < H; j += 1024)
+  {
+    if (hands[j].width != -1.0)  // handle_search.cpp:13,25: width -1 marks a retired hand
+      atomicOr(&alive[j >> 6], 1ull << (j & 63));
+    const int rc = rowcnt[j];
+    if (rc >= min_inliers)
+    {
+      atomicOr(&elig[j >> 6], 1ull << (j & 63));
+      atomicMax(&s_maxrow, rc);
+    }
+    if (SMALL)
+      for (int r = 0; r < 3; r++)
+      {
+        hpos[j][r] = hands[j].axis[r];
+        hpos[j][3 + r] = hands[j].bottom[r];
+      }
+  }
+  if (SMALL)
+    for (int k = tid; k < H * W; k += 1024)
+      lbits[k] = bits[k];
+  __syncthreads();
+  if (s_maxrow > 64)  // a row longer than a wave: the sequential kernel (launched next) does this search
+  {
+    if (tid == 0)
+      counts->sequential = 1;
+    return;
+  }
+  auto load_row = [&](int seed, unsigned long long& r0, unsigned long long& r1) {  // lane t: words t and 64 + t of the row
+    if (SMALL)
+    {
+      r0 = lane < W ? lbits[seed * W + lane] : 0ull;
+      r1 = 0ull;  // (W <= 10)
+    }
+    else
+    {
+      r0 = lane < W ? bits[(int64_t) seed * W + lane] : 0ull;
+      r1 = 64 + lane < W ? bits[(int64_t) seed * W + 64 + lane] : 0ull;
+    }
+  };
+#ifdef AGH_DEBUG_HOOKS
+  __shared__ long long stamps[64][6];
+  int dbg_round = 0;
+#define AGH_HSTAMP(i) do { if (tid == 0 && dbg_round < 64) stamps[dbg_round][i] = wall_clock64(); } while (0)
+  if (tid == 0)
+    stamps[63][5] = wall_clock64();
+#else
+#define AGH_HSTAMP(i) do { } while (0)
+#endif
+  for (;;)
+  {
+    AGH_HSTAMP(0);
+    // ---- the next open seeds, in index order (wave 0) ----
+    if (wave == 0)
+    {
+      int nc = 0, my_cand = 0;
+      for (int half = 0; half < (W > 64 ? 2 : 1) && nc < kBatch; half++)
+      {
+        const int wi = half * 64 + lane;
+        const unsigned long long todo = wi < W ? (alive[wi] & elig[wi] & ~done[wi]) : 0ull;
+        unsigned long long nz = __ballot(todo != 0ull);
+        const int lo32 = (int) (unsigned) (todo & 0xffffffffull), hi32 = (int) (unsigned) (todo >> 32);
+        while (nz && nc < kBatch)
+        {
+          const int w = __ffsll((long long) nz) - 1;
+          nz &= nz - 1ull;
+          unsigned long long mw = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(hi32, w) << 32) |
+                                  (unsigned long long) (unsigned) __builtin_amdgcn_readlane(lo32, w);
+          while (mw && nc < kBatch)
+          {
+            const int b = __ffsll((long long) mw) - 1;
+            mw &= mw - 1ull;
+            if (lane == nc)
+              my_cand = (half * 64 + w) * 64 + b;
+            nc++;
+          }
+        }
+      }
+      if (lane < nc)
+        cand[lane] = my_cand;
+      if (lane == 0)
+        n_cand = nc;
+    }
+    __syncthreads();
+    const int nc = n_cand;
+    if (nc == 0)
+      break;
+    AGH_HSTAMP(1);
+    // ---- evaluation: wave k takes candidate k against the availability as it stands now ----
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    int kept = 0, out_j = 0;
+    bool accept = false;
+    if (wave < nc)
+    {
+      const int i = cand[wave];
+      unsigned long long row0, row1;
+      load_row(i, row0, row1);
+      m0 = lane < W ? (row0 & alive[lane]) : 0ull;
+      m1 = 64 + lane < W ? (row1 & alive[64 + lane]) : 0ull;
+      if (lane < W)
+        rowm[wave][lane] = m0;
+      if (64 + lane < W)
+        rowm[wave][64 + lane] = m1;
+      const int n = wave_allsum_i32(__popcll(m0) + __popcll(m1));  // <= 64 (s_maxrow)
+      accept = n >= min_inliers;  // handle_search.cpp:47-48
+      if (accept)
+      {
+        // one inlier per lane.  The holder of bit b of word w is member number base(w) + popcount(bits below b): it drops its
+        // index into the wave's list at that position, and lane e picks up entry e (a scalar walk over the set bits, n steps
+        // per seed, kept the CU's one scalar unit busy for all sixteen waves: the evaluation phase was 2.6 us)
+        int my_j = 0, cnt = 0;
+        for (int half = 0; half < (W > 64 ? 2 : 1); half++)
+        {
+          const unsigned long long mm = half ? m1 : m0;
+          unsigned long long nz = __ballot(mm != 0ull);
+          const int lo32 = (int) (unsigned) (mm & 0xffffffffull), hi32 = (int) (unsigned) (mm >> 32);
+          while (nz)
+          {
+            const int w = __ffsll((long long) nz) - 1;
+            nz &= nz - 1ull;
+            const unsigned long long mw = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(hi32, w) << 32) |
+                                          (unsigned long long) (unsigned) __builtin_amdgcn_readlane(lo32, w);
+            if ((mw >> lane) & 1ull)
+              mlist[wave][cnt + __popcll(mw & ((1ull << lane) - 1ull))] = (unsigned short) ((half * 64 + w) * 64 + lane);
+            cnt += __popcll(mw);
+          }
+        }
+        AGH_WAVE_SYNC();
+        my_j = lane < n ? (int) mlist[wave][lane] : 0;
+        double de = 0.0;
+        if (lane < n)
+        {
+          double ia[3], d[3];
+          for (int r = 0; r < 3; r++)
+          {
+            ia[r] = SMALL ? hpos[i][r] : hands[i].axis[r];
+            const double ibr = SMALL ? hpos[i][3 + r] : hands[i].bottom[r];
+            d[r] = (SMALL ? hpos[my_j][3 + r] : hands[my_j].bottom[r]) - ibr;
+          }
+          de = dot3d(ia, d);  // dist_along_line (:34)
+        }
+        // rank by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
+        const int dlo = __double2loint(de), dhi = __double2hiint(de);
+        int rank = 0;
+        for (int k = 0; k < n; k++)
+        {
+          const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+          const int jk = __builtin_amdgcn_readlane(my_j, k);
+          rank += (dk < de || (dk == de && jk < my_j)) ? 1 : 0;
+        }
+        const int dst = (lane < n ? rank : lane) * 4;  // the sorted list, one entry per lane
+        const int slo = __builtin_amdgcn_ds_permute(dst, dlo), shi = __builtin_amdgcn_ds_permute(dst, dhi);
+        out_j = __builtin_amdgcn_ds_permute(dst, my_j);
+        const double sdv = __hiloint2double(shi, slo);
+        const double nx_d = __hiloint2double(__shfl_down(shi, 1), __shfl_down(slo, 1));
+        const unsigned long long gm = __ballot(lane + 1 < n && nx_d - sdv > 0.02);  // shortenHandle: first gap > 2 cm (:95-99)
+        kept = gm ? __ffsll((long long) gm) - 1 : n;  // the elements before the gap position (:111)
+        accept = kept >= min_inliers && kept > 0;
+        if (accept)
+        {
+          const double s0 = __hiloint2double(__builtin_amdgcn_readlane(shi, 0), __builtin_amdgcn_readlane(slo, 0));
+          const double s1 = __hiloint2double(__builtin_amdgcn_readlane(shi, kept - 1), __builtin_amdgcn_readlane(slo, kept - 1));
+          const double mn = s0 < 10000000 ? s0 : 10000000;  // :62-72, the reference's +-1e7 start values
+          const double mx = s1 > -10000000 ? s1 : -10000000;
+          accept = (mx - mn > min_length);
+        }
+      }
+      if (lane == 0)
+      {
+        res_acc[wave] = accept ? 1 : 0;
+        res_kept[wave] = accept ? kept : 0;
+      }
+    }
+    __syncthreads();
+    AGH_HSTAMP(2);
+    // ---- which earlier candidates of the batch does mine share a hand with?  (every row holds its own seed, so shared hands
+    // cover "is retired by", "retires a member of" and "depends on the same hands as" alike) ----
+    if (wave < nc)
+    {
+      unsigned im = 0u;
+      for (int w0 = 0; w0 < W; w0 += 4)  // lane = earlier candidate (16) x word of the chunk (4)
+      {
+        const int kq = lane & 15, w = w0 + (lane >> 4);
+        const bool hit = kq < wave && w < W && (rowm[kq][w] & rowm[wave][w]) != 0ull;
+        const unsigned long long b = __ballot(hit);
+        im |= (unsigned) ((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull);
+      }
+      if (lane == 0)
+        imask[wave] = im;
+    }
+    __syncthreads();
+    AGH_HSTAMP(3);
+    // ---- commit: candidate k stays open iff it shares a hand with an earlier candidate that stays open itself (whatever that
+    // one may yet retire must not be judged first) or that was accepted (its evaluation may be stale, or it is gone).  Sixteen
+    // steps on two scalar masks, by wave 0 alone (run by every wave, the CU's single scalar unit made this 3 us); the
+    // accepted commits' handle numbers and list offsets are a 16-lane prefix sum. ----
+    if (wave == 0)
+    {
+      const int v_acc = lane < nc ? res_acc[lane] : 0, v_kept = lane < nc ? res_kept[lane] : 0;
+      const int v_im = lane < nc ? (int) imask[lane] : 0;
+      unsigned pend = 0u, accm = 0u;
+      for (int k = 0; k < nc; k++)
+      {
+        const bool a = __builtin_amdgcn_readlane(v_acc, k) != 0;
+        const bool open = ((unsigned) __builtin_amdgcn_readlane(v_im, k) & (pend | accm)) != 0u;
+        pend |= open ? (1u << k) : 0u;
+        accm |= (a && !open) ? (1u << k) : 0u;
+      }
+      const int mine = ((accm >> lane) & 1u) ? v_kept : 0;
+      int incl = mine;  // inclusive prefix over the first DPP row (16 lanes)
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);  // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);  // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);  // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);  // row_shr:8
+      if (lane < nc)
+      {
+        c_open[lane] = (pend >> lane) & 1u;
+        c_h[lane] = __popc(accm & ((1u << lane) - 1u));
+        c_base[lane] = incl - mine;
+      }
+      if (lane == 15)
+      {
+        tot_nh = __popc(accm);
+        tot_nidx = incl;
+      }
+    }
+    __syncthreads();
+    if (wave < nc && !c_open[wave])
+    {
+      const int t = cand[wave];
+      if (lane == 0)
+        atomicOr(&done[t >> 6], 1ull << (t & 63));
+      if (accept)
+      {
+        const int h = s_nh + c_h[wave], base = s_nidx + c_base[wave];
+        if (lane < kept)
+        {
+          tmp_idx[base + lane] = (unsigned short) out_j;
+          atomicAnd(&alive[out_j >> 6], ~(1ull << (out_j & 63)));  // :75-78
+        }
+        if (lane == 0)
+        {
+          tmp_seed[h] = (unsigned short) t;
+          tmp_base[h] = (unsigned short) base;
+          tmp_n[h] = (unsigned short) kept;
+        }
+      }
+    }
+    __syncthreads();
+    AGH_HSTAMP(4);
+#ifdef AGH_DEBUG_HOOKS
+    if (tid == 0 && dbg_round < 64)
+      stamps[dbg_round][5] = nc;
+    dbg_round++;
+#endif
+    if (tid == 0)
+    {
+      s_nh += tot_nh;
+      s_nidx += tot_nidx;
+    }
+    // (the next round's first barrier orders this update before any reader)
+  }
+  // ---- epilogue: the handles in seed order, their lists laid end to end in that order ----
+  __syncthreads();
+  const int nh = s_nh;
+  for (int h = tid; h < nh; h += 1024)
+  {
+    const int sh = tmp_seed[h];
+    int rank = 0;
+    for (int q = 0; q < nh; q++)
+      rank += tmp_seed[q] < sh ? 1 : 0;
+    tmp_order[rank] = (unsigned short) h;
+  }
+  __syncthreads();
+  for (int r = wave; r < nh; r += 16)
+  {
+    const int h = tmp_order[r];
+    int first = 0;  // lengths of the handles in front of this one
+    for (int q = lane; q < r; q += 64)
+      first += tmp_n[tmp_order[q]];
+    first = wave_allsum_i32(first);
+    const int n = tmp_n[h], base = tmp_base[h];
+    if (lane == 0)
+    {
+      h_first[r] = first;
+      h_n[r] = n;
+    }
+    if (lane < n)
+    {
+      const int j = tmp_idx[base + lane];
+      inlier_idx[first + lane] = j;
+      if (host_idx && first + lane < host_idx_cap)
+        host_idx[first + lane] = j;  // (the host-buffer entry point: the list is on the host when the stream drains)
+    }
+  }
+  if (tid == 0)
+  {
+    counts->n_handles = nh;
+    counts->n_idx = s_nidx;
+    if (host_counts)
+    {
+      host_counts[0] = nh;
+      host_counts[1] = s_nidx;
+    }
+#ifdef AGH_DEBUG_HOOKS
+    const long long t_end = wall_clock64(), t0 = stamps[63][5];
+    printf("k_handle_batch H=%d rounds=%d: setup %lld, total %lld (10 ns ticks)\n", H, dbg_round, stamps[0][0] - t0, t_end - t0);
+    for (int r = 0; r < dbg_round && r < 40; r++)
+      printf("  round %d nc=%lld: select %lld eval %lld share %lld commit %lld\n", r, stamps[r][5], stamps[r][1] - stamps[r][0],
+        stamps[r][2] - stamps[r][1], stamps[r][3] - stamps[r][2], stamps[r][4] - stamps[r][3]);
+#endif
+  }
+}
+#undef AGH_HSTAMP
+
 __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __restrict__ hands, const int* __restrict__ h_first,
   const int* __restrict__ h_n, const int* __restrict__ inlier_idx, const HandleCounts* __restrict__ counts,
   agh_handle* __restrict__ out, agh_handle* __restrict__ host_out, int host_cap)
@@ -456,13 +828,25 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
       best_k = ok;
     }
   }
+  // handle.cpp:66-73 sums the widths in list order: the loads go out together (one per lane), the additions stay sequential
+  double wsum64 = 0.0;
+  if (n <= 64)
+  {
+    const double wl = lane < n ? hands[in[lane]].width : 0.0;
+    const int wlo = __double2loint(wl), whi = __double2hiint(wl);
+    for (int k = 0; k < n; k++)
+      wsum64 += __hiloint2double(__builtin_amdgcn_readlane(whi, k), __builtin_amdgcn_readlane(wlo, k));
+  }
   if (lane == 0)
   {
     const int min_idx = best_k == 0x7fffffff ? 0 : best_k;
     const agh_hypothesis& c = hands[in[min_idx]];
     double wsum = 0.0;
-    for (int k = 0; k < n; k++)  // handle.cpp:66-73: an explicit loop, kept sequential
-      wsum += hands[in[k]].width;
+    if (n > 64)
+      for (int k = 0; k < n; k++)  // handle.cpp:66-73: an explicit loop, kept sequential
+        wsum += hands[in[k]].width;
+    else
+      wsum = wsum64;
     agh_handle hd;
     for (int r = 0; r < 3; r++)
     {
@@ -492,6 +876,15 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
     return AGH_OK;
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
     c->d_h_bits, W, c->d_h_rowcnt);
+  // the walk: sixteen seeds at a time (rows of at most 64 hands), else -- flagged on the device -- the sequential kernel
+  if (Hi <= kHandleLdsHands)
+    hipLaunchKernelGGL(k_handle_batch<true>, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp);
+  else
+    hipLaunchKernelGGL(k_handle_batch<false>, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp);
   if (Hi <= kHandleLdsHands)
     hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
