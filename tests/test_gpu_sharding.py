@@ -214,6 +214,75 @@ def test_full_size_eight_way_sharded_search_against_oracle(svm_model, name):
         assert np.array_equal(keep, okeep)
 
 
+def test_full_size_c5_cloud_per_rank_against_oracle(svm_model):
+    """BASELINE config C5 at full size the way `bench.py --gpus 8` issues it: a communicator of EIGHT ranks,
+    rank r holds cloud C5_r (300 000 points) and searches its own 2000 samples -- its slice of the concatenated 16 000-entry
+    list -- through the sharded call, with the device-resident entry points and the classify exchange bench.py uses.  The
+    merged list of EVERY rank is compared with the ORACLE's eight lists laid end to end, not with a HIP list."""
+    import torch
+
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as O
+
+    G = 8
+    w, rho = svm_model
+    scenes = [synthetic.config(f"C5_{r}") for r in range(G)]
+    S = scenes[0].samples.size
+    assert all(sc.samples.size == S and sc.n == 300_000 for sc in scenes)
+    refs, okeeps = [], []
+    for sc in scenes:
+        ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples, want_images=True)
+        keep, _ = O.classify(ref["images"], w, rho)
+        refs.append(ref["hyps"])
+        okeeps.append(np.asarray(keep, np.uint8))
+    total = sum(len(r) for r in refs)
+    assert total > G * S // 10
+    dev = torch.device("cuda", 0)
+    ctxs = [binding.Context(sc.cam_origins) for sc in scenes]
+    for c in ctxs:
+        c.load_svm(w, rho)
+    binding.comm_init_local(ctxs)
+
+    def search(r, c):
+        sc = scenes[r]
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
+            s_all = torch.zeros(G * S, dtype=torch.int32, device=dev)
+            s_all[r * S:(r + 1) * S] = torch.from_numpy(sc.samples).to(dev)
+            out_t = torch.zeros(8 * S * G * 160, dtype=torch.uint8, device=dev)
+            nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+            keep_t = torch.zeros(8 * S * G, dtype=torch.uint8, device=dev)
+        st.synchronize()
+        for attempt in range(3):  # (AGH_ERR_RETRY: capacity classes / segment size, learnt by every rank from the same headers)
+            c.set_cloud_torch(xyz_t, cam_t, stream=st.cuda_stream)
+            c.find_hands_sharded_torch(s_all, out_t, nout_t, stream=st.cuda_stream)
+            c.classify_sharded_torch(keep_t, stream=st.cuda_stream)
+            st.synchronize()
+            try:
+                c.synchronize()
+                break
+            except binding.AghError as e:
+                if e.code != binding.AGH_ERR_RETRY or attempt == 2:
+                    raise
+        n = int(nout_t.item())
+        recs = np.frombuffer(out_t.cpu().numpy().tobytes(), dtype=binding.HYP_DTYPE)[:n].copy()
+        return recs, keep_t.cpu().numpy()[:n].copy()
+
+    for hyps, keep in _run_ranks(ctxs, search):
+        assert len(hyps) == total
+        at = 0
+        for r, ref in enumerate(refs):
+            part = hyps[at:at + len(ref)]
+            assert np.array_equal(part["sample"], ref["sample"] + r * S), r
+            for f in FIELDS:
+                if f not in ("sample", "valid"):
+                    assert np.array_equal(part[f], ref[f]), (r, f)
+            assert np.array_equal(keep[at:at + len(ref)], okeeps[r]), r
+            assert np.array_equal(part["svm_keep"], okeeps[r]), r
+            at += len(ref)
+
+
 def test_solo_communicator_runs_the_all_points_pass_in_the_production_mode(tiny_scene):
     """A communicator of one may combine RAND50 with calculates_antipodal (the rand() stream runs through all N points, then
     the samples -- ADVICE r2: the draw table was sized for the samples only)."""
