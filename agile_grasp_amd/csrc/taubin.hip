@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   // LDS: the staged neighbours and their sorted order live for the whole kernel; the sort scratch (keys, bucket
   // permutation, histogram) is dead once `slot` is known, so the term tile of the summation phase reuses its space.
   constexpr int kSortBytes = CAP * 8 + CAP * 2 + (kSortBins + 1) * 4 + kSortBins * 4;
-  constexpr int kTermBytes = kChunk * kNumSums * 8;
+  constexpr int kTS = kChunk + 2;  // row stride of the term-major tile (doubles): spreads the chain's lanes over the LDS banks
+  constexpr int kTermBytes = kNumSums * kTS * 8;
   constexpr int kScratch = ((kSortBytes > kTermBytes ? kSortBytes : kTermBytes) + 15) & ~15;
   __shared__ float4 stage[CAP];
   __shared__ unsigned short slot[CAP];
@@ -296,55 +297,55 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
       const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
       const double x2 = x * x, y2 = y * y, z2 = z * z;
       const double xy = x * y, yz = y * z, xz = x * z;
-      double* t = &termbuf[lane * kNumSums];
+      double* t = &termbuf[lane];  // term-major tile: term k of row r at [k * kTS + r]
       if (wave == 0)
       {
-        t[0] = x2 * x2;
-        t[1] = x2 * y2;
-        t[2] = x2 * z2;
-        t[3] = x2 * xy;
-        t[4] = x2 * yz;
-        t[5] = x2 * xz;
-        t[6] = x2 * x;
-        t[7] = x2 * y;
-        t[8] = x2 * z;
-        t[9] = x2;
+        t[0 * kTS] = x2 * x2;
+        t[1 * kTS] = x2 * y2;
+        t[2 * kTS] = x2 * z2;
+        t[3 * kTS] = x2 * xy;
+        t[4 * kTS] = x2 * yz;
+        t[5 * kTS] = x2 * xz;
+        t[6 * kTS] = x2 * x;
+        t[7 * kTS] = x2 * y;
+        t[8 * kTS] = x2 * z;
+        t[9 * kTS] = x2;
       }
       else if (wave == 1)
       {
-        t[10] = y2 * y2;
-        t[11] = y2 * z2;
-        t[12] = y2 * xy;
-        t[13] = y2 * yz;
-        t[14] = y2 * xz;
-        t[15] = y2 * x;
-        t[16] = y2 * y;
-        t[17] = y2 * z;
-        t[18] = y2;
+        t[10 * kTS] = y2 * y2;
+        t[11 * kTS] = y2 * z2;
+        t[12 * kTS] = y2 * xy;
+        t[13 * kTS] = y2 * yz;
+        t[14 * kTS] = y2 * xz;
+        t[15 * kTS] = y2 * x;
+        t[16 * kTS] = y2 * y;
+        t[17 * kTS] = y2 * z;
+        t[18 * kTS] = y2;
       }
       else if (wave == 2)
       {
-        t[19] = z2 * z2;
-        t[20] = z2 * xy;
-        t[21] = z2 * yz;
-        t[22] = z2 * xz;
-        t[23] = z2 * x;
-        t[24] = z2 * y;
-        t[25] = z2 * z;
-        t[26] = z2;
-        t[27] = x * yz;
+        t[19 * kTS] = z2 * z2;
+        t[20 * kTS] = z2 * xy;
+        t[21 * kTS] = z2 * yz;
+        t[22 * kTS] = z2 * xz;
+        t[23 * kTS] = z2 * x;
+        t[24 * kTS] = z2 * y;
+        t[25 * kTS] = z2 * z;
+        t[26 * kTS] = z2;
+        t[27 * kTS] = x * yz;
       }
       else
       {
-        t[28] = xy;
-        t[29] = yz;
-        t[30] = xz;
-        t[31] = x;
-        t[32] = y;
-        t[33] = z;
-        t[34] = x2 + y2;
-        t[35] = y2 + z2;
-        t[36] = x2 + z2;
+        t[28 * kTS] = xy;
+        t[29 * kTS] = yz;
+        t[30 * kTS] = xz;
+        t[31 * kTS] = x;
+        t[32 * kTS] = y;
+        t[33 * kTS] = z;
+        t[34 * kTS] = x2 + y2;
+        t[35 * kTS] = y2 + z2;
+        t[36 * kTS] = x2 + z2;
       }
     }
     __syncthreads();
@@ -353,19 +354,18 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     {
       // full chunk: all 56 loads are issued up front (two register halves), so the dependent add chain -- the critical
       // path of the block -- pays one LDS round trip per chunk instead of one per eight rows
-      double va[kChunk / 2], vb[kChunk / 2];
+      // (term-major tile: a lane's 56 terms are 28 sixteen-byte loads; with the row-major tile they were 56 eight-byte loads
+      // and issuing them was half of the chain's time)
+      double2 va[kChunk / 2];
 #pragma unroll
       for (int u = 0; u < kChunk / 2; u++)
-        va[u] = termbuf[u * kNumSums + lane];
+        va[u] = reinterpret_cast<const double2*>(termbuf + lane * kTS)[u];
 #pragma unroll
       for (int u = 0; u < kChunk / 2; u++)
-        vb[u] = termbuf[(kChunk / 2 + u) * kNumSums + lane];
-#pragma unroll
-      for (int u = 0; u < kChunk / 2; u++)
-        acc += va[u];
-#pragma unroll
-      for (int u = 0; u < kChunk / 2; u++)
-        acc += vb[u];
+      {
+        acc += va[u].x;
+        acc += va[u].y;
+      }
     }
     else if (wave == 0 && lane < kNumSums)
     {
@@ -375,13 +375,13 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
         double v_[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
-          v_[u] = termbuf[(k + u) * kNumSums + lane];
+          v_[u] = termbuf[lane * kTS + k + u];
 #pragma unroll
         for (int u = 0; u < 8; u++)
           acc += v_[u];
       }
       for (; k < rows; k++)
-        acc += termbuf[k * kNumSums + lane];
+        acc += termbuf[lane * kTS + k];
     }
 #ifdef AGH_DEBUG_HOOKS
     if (dbg && acc == 1.2345e300)  // (keeps the adds in front of the clock read)
