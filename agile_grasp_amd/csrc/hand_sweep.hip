@@ -440,6 +440,75 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
 #pragma unroll
       for (int u = 0; u < 4; u++)
         pn[u] = pts[(lane + 64 * u) < nc ? lane + 64 * u : 0];
+#ifdef AGH_DEBUG_HOOKS
+      if (debug_stop == 20)  // EXPERIMENT (wrong results): the same loop on float32 -- what a float pre-classification could save at most
+      {
+        const float csf = (float) cs, msf = (float) ms, snf = (float) sn, ylof = (float) ylo, yscf = (float) ysc, xlof = (float) xlo,
+                    xscf = (float) xsc;
+        float yminf = (float) ymin, ymaxf = (float) ymax;
+        for (int t0 = lane; t0 < nc; t0 += 256)
+        {
+          float xr[4], yr[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            const double2 p = pn[u];
+            const int tn = t0 + 256 + 64 * u;
+            pn[u] = pts[tn < nc ? tn : 0];
+            const float px = (float) p.x, py = (float) p.y;
+            xr[u] = csf * px + msf * py;
+            yr[u] = snf * px + csf * py;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            yminf = fminf(yminf, yr[u]);
+            ymaxf = fmaxf(ymaxf, yr[u]);
+          }
+          int ly[4], lx[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            const int cy = min(max((int) ((yr[u] - ylof) * yscf), 0), 63);
+            const int cx = min(max((int) ((xr[u] - xlof) * xscf), 0), 1023);
+            ly[u] = G.ylut[cy];
+            lx[u] = G.xlut[cx];
+          }
+          float dv[4][PY], tv[4][PX];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+#pragma unroll
+            for (int j = 0; j < PY; j++)
+              dv[u][j] = reinterpret_cast<const float*>(dep_s)[ly[u] + j];
+#pragma unroll
+            for (int j = 0; j < PX; j++)
+              tv[u][j] = reinterpret_cast<const float*>(thr_s)[lx[u] + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            int yk = ly[u];
+#pragma unroll
+            for (int j = 0; j < PY; j++)
+              yk += (dv[u][j] <= yr[u]) ? 1 : 0;
+            int c = lx[u], e = 0;
+#pragma unroll
+            for (int j = 0; j < PX; j++)
+            {
+              c += (tv[u][j] < xr[u]) ? 1 : 0;
+              e |= (tv[u][j] == xr[u]) ? 1 : 0;
+            }
+            const int key = 2 * c + e;
+            if (yk < K && yk >= 0 && key >= 0 && (key >> 1) < 44)
+              atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + (yk & 15)));
+          }
+        }
+        ymin = (double) yminf;
+        ymax = (double) ymaxf;
+      }
+      else
+#endif
       for (int t0 = lane; t0 < nc; t0 += 256)
       {
         double xr[4], yr[4];
