@@ -36,7 +36,7 @@ class AghParams(C.Structure):
 
 
 class AghTiming(C.Structure):
-    _fields_ = [("ms", C.c_float * 16), ("name", C.c_char_p * 16), ("n", C.c_int32), ("total_ms", C.c_float), ("count", C.c_int32 * 16)]
+    _fields_ = [("ms", C.c_float * 16), ("name", C.c_char_p * 16), ("n", C.c_int32), ("total_ms", C.c_float)]
 
 
 HYP_DTYPE = np.dtype(
@@ -82,7 +82,7 @@ EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device", "agh_set_cloud_batch", "agh_set_cloud_batch_device",
     "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
-    "agh_get_normals", "agh_get_timing", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
+    "agh_get_normals", "agh_get_timing", "agh_get_timing_counts", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
     "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images", "agh_comm_rccl_origin",
     "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_last_exchange", "agh_comm_set_segment_records",
@@ -511,7 +511,9 @@ class Context:
         self._check(self.lib.agh_get_timing(self._h, C.byref(t)))
         ms = {t.name[i].decode(): float(t.ms[i]) for i in range(t.n)}
         if counts:
-            return ms, {t.name[i].decode(): int(t.count[i]) for i in range(t.n)}
+            cnt = (C.c_int32 * 16)()
+            self._check(self.lib.agh_get_timing_counts(self._h, cnt, C.c_int32(16)))
+            return ms, {t.name[i].decode(): int(cnt[i]) for i in range(t.n)}
         return ms
 
     def set_profile(self, level: int):

@@ -153,6 +153,7 @@ struct Ctx
   HostMirror mirror{ nullptr, 0, nullptr };  // set by agh_find_hands around its device call
   uint8_t* h_pin_handles = nullptr;  // agh_find_handles: [256-byte header | hands in | handles out | inlier indices out]
   int64_t h_pin_handles_cap = 0;     // in hands
+  bool handles_sequential = false;   // the previous agh_find_handles needed k_handle_greedy: launch it along
   uint8_t* h_pin_keep = nullptr;     // agh_classify: the keep flags, written by K3 itself
   int64_t h_pin_keep_cap = 0;
 
@@ -305,6 +306,7 @@ struct Ctx
   int ev_used = 0;
   unsigned prof_calls = 0;     // profile 3: calls seen; every fourth one is timed
   agh_timing timing;
+  int32_t timing_counts[AGH_TIMING_SLOTS] = { 0 };  // timed launches per slot of the last agh_get_timing (agh_get_timing_counts)
 };
 
 // a search about to run on `st`: if the host-buffer agh_set_cloud left its grid build running on the context's stream and `st`
@@ -319,9 +321,9 @@ inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
 
 // ---- kernel launchers (defined in the .hip files) ----
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
-  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc);
+  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc, bool with_lattice);
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
-  VoxDesc* host_desc);
+  VoxDesc* host_desc, bool with_lattice);
 // host mirror of the handle search's results (pinned memory of the context; all nullptr / 0: none)
 struct HandleMirror
 {
@@ -329,10 +331,10 @@ struct HandleMirror
   int handle_cap;
   int* idx;
   int idx_cap;
-  int* counts;  // [0] handles, [1] inlier indices, [2] error
+  int* counts;  // [0] handles, [1] inlier indices, [2] error, [3] the batched walk declined and no sequential kernel was launched
 };
 int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
-  const HandleMirror& hm);
+  const HandleMirror& hm, bool with_sequential);
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);

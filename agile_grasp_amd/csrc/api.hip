@@ -750,7 +750,7 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
   {
     const bool speculative = c->d_vox_bitmap && c->vox_bitmap_cap > 0;
     if ((rc = vox_stage1(c, d_xyz, stride_bytes / 4, n, size_left, dense, workspace, cell_size, st,
-           speculative ? c->vox_bitmap_cap : (int64_t) kVoxMaxWords, c->h_vox_desc)) != AGH_OK)
+           speculative ? c->vox_bitmap_cap : (int64_t) kVoxMaxWords, c->h_vox_desc, !speculative)) != AGH_OK)
     {
       c->err = "preprocessing launch failed";
       return rc;
@@ -766,7 +766,7 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
         return rc;
       c->vox_bitmap_cap = want;
     }
-    if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, c->vox_bitmap_cap, st, c->h_vox_desc)) != AGH_OK)
+    if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, c->vox_bitmap_cap, st, c->h_vox_desc, speculative)) != AGH_OK)
     {
       c->err = "preprocessing launch failed";
       return rc;
@@ -933,22 +933,30 @@ int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands,
   agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
   agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
   int32_t* h_idx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
-  h_counts[0] = h_counts[1] = h_counts[2] = 0;
   if (n_hands > 0)
   {
     std::memcpy(h_hands, hands, sizeof(agh_hypothesis) * (size_t) n_hands);
     HIPCHK(c, hipMemcpyAsync(c->d_h_hands, h_hands, sizeof(agh_hypothesis) * n_hands, hipMemcpyHostToDevice, c->stream));
   }
-  timing_begin(c, c->stream);
   const HandleMirror hm{ h_handles, (int) c->h_pin_handles_cap, h_idx, (int) c->h_pin_handles_cap, h_counts };
-  int rc = handle_search(c, n_hands, x1, x2, min_inliers, min_length, c->stream, hm);
-  timing_mark(c, "handle_search", c->stream);
-  if (rc != AGH_OK)
+  for (int attempt = 0; attempt < 2; attempt++)
   {
-    c->err = "handle search launch failed";
-    return rc;
+    h_counts[0] = h_counts[1] = h_counts[2] = h_counts[3] = 0;
+    timing_begin(c, c->stream);
+    const bool with_sequential = c->handles_sequential;
+    const int rc = handle_search(c, n_hands, x1, x2, min_inliers, min_length, c->stream, hm, with_sequential);
+    timing_mark(c, "handle_search", c->stream);
+    if (rc != AGH_OK)
+    {
+      c->err = "handle search launch failed";
+      return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool declined = h_counts[3] != 0;  // a row of the pair matrix longer than a wave
+    c->handles_sequential = declined;        // what this set of hands needed is the guess for the next one
+    if (!declined || with_sequential)
+      break;  // (declined without the sequential kernel behind it: once more, with it)
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   const int* counts = h_counts;
   if (counts[2])
   {
@@ -1356,6 +1364,7 @@ int agh_get_timing(agh_ctx* ctx, agh_timing* out)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
   std::memset(out, 0, sizeof(*out));
+  std::memset(c->timing_counts, 0, sizeof(c->timing_counts));
   if (!c->p.profile || c->ev_used < 2)
     return AGH_OK;
   HIPCHK(c, hipEventSynchronize(c->ev[c->ev_used - 1]));
@@ -1379,12 +1388,21 @@ int agh_get_timing(agh_ctx* ctx, agh_timing* out)
       out->name[slot] = c->ev_name[i];
     }
     out->ms[slot] += ms;
-    out->count[slot]++;
+    c->timing_counts[slot]++;
     out->total_ms += ms;
   }
   out->n = k;
   c->ev_used = 0;
   c->ev_name.clear();
+  return AGH_OK;
+}
+
+int agh_get_timing_counts(agh_ctx* ctx, int32_t* counts, int32_t cap)
+{
+  if (!ctx || !counts || cap < 0)
+    return AGH_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < cap && i < AGH_TIMING_SLOTS; i++)
+    counts[i] = ctx->c.timing_counts[i];
   return AGH_OK;
 }
 

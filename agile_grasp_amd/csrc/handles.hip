@@ -434,6 +434,10 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
     s_nh = 0;
     s_nidx = 0;
     s_maxrow = 0;
+    counts->n_handles = 0;  // (this kernel is the first of a search to touch the counters: no memset launch in front of it)
+    counts->n_idx = 0;
+    counts->error = 0;
+    counts->sequential = 0;
   }
   __syncthreads();
   for (int j = tid; j < H; j += 1024)
@@ -460,7 +464,11 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
   if (s_maxrow > 64)  // a row longer than a wave: the sequential kernel (launched next) does this search
   {
     if (tid == 0)
+    {
       counts->sequential = 1;
+      if (host_counts)
+        host_counts[3] = 1;
+    }
     return;
   }
   auto load_row = [&](int seed, unsigned long long& r0, unsigned long long& r1) {  // lane t: words t and 64 + t of the row
@@ -867,13 +875,16 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
   }
 }
 
+// with_sequential: also launch k_handle_greedy, which does the search when k_handle_batch declines it on the device (a row of the
+// pair matrix longer than a wave).  Without it a declined search leaves counts[3] = 1 and no result: the caller repeats the call
+// with the kernel (agh_find_handles remembers what the previous set of hands needed, so a stream of similar clouds pays the
+// ~5 us of an unneeded launch only when it is needed).
 int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
-  const HandleMirror& hm)
+  const HandleMirror& hm, bool with_sequential)
 {
   const int Hi = (int) H, W = (Hi + 63) / 64;
-  hipMemsetAsync(c->d_h_counts, 0, sizeof(HandleCounts), st);
   if (Hi == 0)
-    return AGH_OK;
+    return hipMemsetAsync(c->d_h_counts, 0, sizeof(HandleCounts), st) == hipSuccess ? AGH_OK : AGH_ERR_HIP;
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
     c->d_h_bits, W, c->d_h_rowcnt);
   // the walk: sixteen seeds at a time (rows of at most 64 hands), else -- flagged on the device -- the sequential kernel
@@ -885,7 +896,9 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
     hipLaunchKernelGGL(k_handle_batch<false>, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
       c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp);
-  if (Hi <= kHandleLdsHands)
+  if (!with_sequential)
+    ;
+  else if (Hi <= kHandleLdsHands)
     hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
       c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts);

@@ -21,7 +21,7 @@ constexpr int kPreBlock = 256;
 constexpr int kPrePerBlock = 1024;   // points per block (4 rounds of 256)
 constexpr int kWordsPerBlock = 4096; // bitmap words per block in the popcount passes (16 per thread)
 
-__global__ void k_vox_init(VoxDesc* d)
+__device__ __forceinline__ void vox_desc_init(VoxDesc* d)
 {
   for (int c = 0; c < 2; c++)
     for (int a = 0; a < 3; a++)
@@ -32,6 +32,10 @@ __global__ void k_vox_init(VoxDesc* d)
   d->n_kept[0] = d->n_kept[1] = 0;
   d->n_vox[0] = d->n_vox[1] = 0;
   d->error = 0;
+}
+__global__ void k_vox_init(VoxDesc* d)
+{
+  vox_desc_init(d);
 }
 
 __device__ __forceinline__ bool finite3(float x, float y, float z)
@@ -64,13 +68,22 @@ __global__ __launch_bounds__(kPreBlock) void k_vox_count(const float* __restrict
     blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// Exclusive scan of an int array with one block (in place); total to *total if given.
-__global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t nb, long long* total)
+__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total, VoxDesc* host_desc);
+
+// Exclusive scan of an int array with one block (in place); total to *total if given.  Two one-thread kernels ride along
+// (each was a ~5 us launch of its own: a few dependent global accesses by one thread): init_desc -- the descriptor's
+// reset in front of k_vox_classify --, and totals_desc -- the voxel counts per camera and the host mirror behind the second scan.
+__global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t nb, long long* total, VoxDesc* init_desc,
+  VoxDesc* totals_desc, VoxDesc* host_desc)
 {
   __shared__ long long carry;
   __shared__ int wsum[16];
   if (threadIdx.x == 0)
+  {
     carry = 0;
+    if (init_desc)
+      vox_desc_init(init_desc);
+  }
   __syncthreads();
   for (int64_t b0 = 0; b0 < nb; b0 += 1024)
   {
@@ -98,6 +111,8 @@ __global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t 
   }
   if (total && threadIdx.x == 0)
     *total = carry;
+  if (totals_desc && threadIdx.x == 0)  // (v was written by this work-group: the barriers above order it)
+    vox_totals(totals_desc, v, carry, host_desc);
 }
 
 // Camera id (rank in the NaN-free cloud >= size_left), workspace test, per-camera minimum and maximum.
@@ -210,7 +225,7 @@ __device__ __forceinline__ long long vox_index(float p, double mn, double cell)
 
 // error: 1 = the lattice exceeds max_words (the hard limit), 2 = it exceeds cap_words, the bitmap the host has allocated from an
 // earlier cloud (stage 2 was launched speculatively for that size and does nothing; the host enlarges and repeats).
-__global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_words, unsigned long long cap_words, VoxDesc* host_desc)
+__device__ void vox_lattice(VoxDesc* d, double cell, unsigned long long max_words, unsigned long long cap_words, VoxDesc* host_desc)
 {
   unsigned long long ofs = 0;
   for (int c = 0; c < 2; c++)
@@ -258,6 +273,22 @@ __global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_wo
   if (host_desc)
     *host_desc = *d;
 }
+__global__ void k_vox_lattice(VoxDesc* d, double cell, unsigned long long max_words, unsigned long long cap_words, VoxDesc* host_desc)
+{
+  vox_lattice(d, cell, max_words, cap_words, host_desc);
+}
+// The speculative pass (agh_preprocess_device from the second cloud on): the bitmap of the size the context already has is
+// cleared by all work-groups while one thread computes the lattice -- one launch for what were a runtime fill kernel and a
+// one-thread kernel, ~5 us each.  (k_vox_mark, the next kernel, is the first reader of both.)
+__global__ __launch_bounds__(256) void k_vox_clear_lattice(uint4* __restrict__ bitmap16, int64_t n16, VoxDesc* d, double cell,
+  unsigned long long max_words, unsigned long long cap_words, VoxDesc* host_desc)
+{
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    vox_lattice(d, cell, max_words, cap_words, host_desc);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t) gridDim.x * 256)
+    bitmap16[i] = z;
+}
 
 __global__ __launch_bounds__(256) void k_vox_mark(const float* __restrict__ xyz, int64_t stride, int64_t n,
   const uint8_t* __restrict__ code, const VoxDesc* __restrict__ d, double cell, unsigned* __restrict__ bitmap)
@@ -296,8 +327,9 @@ __global__ __launch_bounds__(256) void k_vox_popcount(const unsigned* __restrict
     blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__global__ void k_vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, const long long* total, VoxDesc* host_desc)
+__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total_v, VoxDesc* host_desc)
 {
+  const long long* total = &total_v;
   if (d->error)
   {
     d->n_vox[0] = d->n_vox[1] = 0;
@@ -350,6 +382,25 @@ __global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ b
   const int c = w0 >= d->word_ofs[1] ? 1 : 0;
   const unsigned long long ny = (unsigned long long) d->dim[c][1], nz = (unsigned long long) d->dim[c][2];
   const double m0 = d->mn[c][0], m1 = d->mn[c][1], m2 = d->mn[c][2];
+  // (ix, iy, iz) of a bit position: two exact integer divisions by way of double reciprocals (positions are below 2^33, the
+  // quotient estimate is off by at most one and is corrected) -- three 64-bit integer divisions per VOXEL, ~100 instructions
+  // each on this part, made the kernel 52 us for 250k voxels
+  const double inv_nz = 1.0 / (double) nz, inv_ny = 1.0 / (double) ny;
+  auto divmod = [](unsigned long long a, unsigned long long b, double inv_b, unsigned long long& q, unsigned long long& r) {
+    q = (unsigned long long) ((double) a * inv_b);
+    long long rr = (long long) a - (long long) (q * b);
+    if (rr < 0)
+    {
+      q--;
+      rr += (long long) b;
+    }
+    else if (rr >= (long long) b)
+    {
+      q++;
+      rr -= (long long) b;
+    }
+    r = (unsigned long long) rr;
+  };
   for (int j = 0; j < 16; j++)
   {
     unsigned bits = w[j];
@@ -358,8 +409,10 @@ __global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ b
       const int b = __ffs(bits) - 1;
       bits &= bits - 1;
       const unsigned long long pos = ((unsigned long long) (w0 + j) - d->word_ofs[c]) * 32ull + (unsigned) b;
-      const unsigned long long t = pos / nz;
-      const long long iz = (long long) (pos - t * nz), iy = (long long) (t % ny), ix = (long long) (t / ny);
+      unsigned long long t, uz, ux, uy;
+      divmod(pos, nz, inv_nz, t, uz);
+      divmod(t, ny, inv_ny, ux, uy);
+      const long long iz = (long long) uz, iy = (long long) uy, ix = (long long) ux;
       out_xyz[3 * k] = (float) ((double) ix * cell + 1.0 * m0);
       out_xyz[3 * k + 1] = (float) ((double) iy * cell + 1.0 * m1);
       out_xyz[3 * k + 2] = (float) ((double) iz * cell + 1.0 * m2);
@@ -370,7 +423,7 @@ __global__ __launch_bounds__(256) void k_vox_emit(const unsigned* __restrict__ b
 }
 
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
-  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc)
+  const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc, bool with_lattice)
 {
   VoxWorkspace ws;
   for (int a = 0; a < 3; a++)
@@ -379,31 +432,40 @@ int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int
     ws.hi[a] = workspace[2 * a + 1];
   }
   const int64_t nb = (n + kPrePerBlock - 1) / kPrePerBlock;
-  hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(1), 0, st, c->d_vox_desc);
+  const bool scan_first = n > 0 && !dense;  // (then the descriptor's reset rides on that one-block scan)
+  if (!scan_first)
+    hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(1), 0, st, c->d_vox_desc);
   if (n > 0)
   {
     if (!dense)
     {
       hipLaunchKernelGGL(k_vox_count, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n, c->d_vox_blk);
-      hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk, nb, (long long*) nullptr);
+      hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk, nb, (long long*) nullptr, c->d_vox_desc,
+        (VoxDesc*) nullptr, (VoxDesc*) nullptr);
     }
     hipLaunchKernelGGL(k_vox_classify, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n,
       dense ? (const int*) nullptr : (const int*) c->d_vox_blk, size_left, ws, c->d_vox_code, c->d_vox_desc);
   }
-  hipLaunchKernelGGL(k_vox_lattice, dim3(1), dim3(1), 0, st, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords,
-    (unsigned long long) cap_words, host_desc);
+  if (with_lattice)  // (the speculative pass computes the lattice inside stage 2's first kernel)
+    hipLaunchKernelGGL(k_vox_lattice, dim3(1), dim3(1), 0, st, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords,
+      (unsigned long long) cap_words, host_desc);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
 
 // n_words: the lattice's size, or any multiple of kWordsPerBlock above it that the bitmap has room for (the blocks beyond the
 // lattice hold no bits and emit nothing)
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
-  VoxDesc* host_desc)
+  VoxDesc* host_desc, bool with_lattice)
 {
+  const int64_t cap_words = n_words;
   if (n == 0)
     n_words = 0;  // (no point, no bit: nothing to clear, count or emit; the block counts are not even written)
   const int64_t nb2 = n_words / kWordsPerBlock;
-  if (hipMemsetAsync(c->d_vox_bitmap, 0, (size_t) n_words * 4, st) != hipSuccess)
+  if (with_lattice)  // speculative pass: clear + lattice in one launch (n_words is a multiple of 4096 words)
+    hipLaunchKernelGGL(k_vox_clear_lattice, dim3((unsigned) std::max<int64_t>(1, std::min<int64_t>(n_words / 4 / 256, 2048))), dim3(256), 0,
+      st, reinterpret_cast<uint4*>(c->d_vox_bitmap), n_words / 4, c->d_vox_desc, cell, (unsigned long long) kVoxMaxWords,
+      (unsigned long long) cap_words, host_desc);
+  else if (hipMemsetAsync(c->d_vox_bitmap, 0, (size_t) n_words * 4, st) != hipSuccess)
     return AGH_ERR_HIP;
   if (n > 0 && n_words > 0)
   {
@@ -412,9 +474,8 @@ int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, dou
     hipLaunchKernelGGL(k_vox_popcount, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
       c->d_vox_blk2);
   }
-  hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk2, nb2, c->d_vox_total);
-  hipLaunchKernelGGL(k_vox_totals, dim3(1), dim3(1), 0, st, c->d_vox_desc, (const int*) c->d_vox_blk2,
-    (const long long*) c->d_vox_total, host_desc);
+  hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk2, nb2, c->d_vox_total, (VoxDesc*) nullptr, c->d_vox_desc,
+    host_desc);  // (+ the voxel counts per camera and the host mirror)
   if (n > 0 && n_words > 0)
     hipLaunchKernelGGL(k_vox_emit, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
       (const int*) c->d_vox_blk2, (const VoxDesc*) c->d_vox_desc, cell, c->d_vox_xyz, c->d_vox_cam);

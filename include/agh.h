@@ -118,8 +118,8 @@ typedef struct agh_timing
   const char* name[AGH_TIMING_SLOTS];
   int32_t n;
   float total_ms;
-  int32_t count[AGH_TIMING_SLOTS]; /* timed launches behind ms[i] (profile 3 times a sample of the calls) */
-} agh_timing;
+} agh_timing; /* (this layout is frozen: a caller built against an earlier header passes a buffer of exactly this size;
+                 what was added later has its own getter, agh_get_timing_counts) */
 
 typedef struct agh_ctx agh_ctx;
 
@@ -325,6 +325,9 @@ int agh_get_normals(agh_ctx* ctx, double* normals, int64_t cap_points);  /* clou
  * AGH_ERR_CAPACITY if n_b > cap.  A lazy getter (one pass over the cloud per call), not part of the hot path. */
 int agh_get_learning_points(agh_ctx* ctx, int64_t hyp, double* points, int32_t* cam_source, int64_t cap, int64_t* n_out);
 int agh_get_timing(agh_ctx* ctx, agh_timing* out);
+/* Timed launches behind ms[i] of the LAST agh_get_timing call of this context (profile 3 times a sample of the calls):
+ * counts[0 .. min(cap, AGH_TIMING_SLOTS) - 1]. */
+int agh_get_timing_counts(agh_ctx* ctx, int32_t* counts, int32_t cap);
 /* Change agh_params::profile of a live context (0 .. 3); pending timings are dropped. */
 int agh_set_profile(agh_ctx* ctx, int32_t level);
 int agh_synchronize(agh_ctx* ctx);
