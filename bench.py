@@ -1,14 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- grasp hypotheses/sec of the MI355X-native HandSearch::findHands path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4] [--normals det|rand50] [--shard samples|clouds]
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4] [--normals det|rand50] [--shard samples|clouds] [--dist]
+
+`--gpus N` with N > 1 and no launcher around it starts its own N ranks (one process per GPU: python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...); under a launcher WORLD_SIZE must equal N.  `--dist` runs the
+sharded entry points on a communicator of one rank at N = 1 (RCCL with one rank).  `--launch-only` lets the ranks meet over
+gloo and report who came (CPU test of the launcher).
 
 One "step" = one pass of the hot path over one cloud whose points and sample indices are already resident in HBM:
 uniform-grid build (the reference's kd-tree build, hand_search.cpp:10-11) -> Taubin moments / eigen / frame
 (findQuadrics) -> hand sweep (findHands) -> compaction [-> HOG + linear SVM for C3].
 
 N = 1 runs BASELINE config C2 (two-view 300k-point cloud, 2000 samples; quadric fit + hand sweep) -- the configuration the
-metric is quoted on.
+metric is quoted on -- on the TILTED variant of the synthetic scene (agile_grasp_amd/synthetic.py; config.workload says so);
+the axis-aligned variant of SURVEY 8d, the production normals mode, configs C3 and C4, the batch of eight clouds in one
+context and the host-buffer entry points (Python binding and plain C++) ride along as extra keys of the same line.
 
 N > 1, default (--shard clouds) = BASELINE config C5, "batch of 300k-point clouds, samples sharded across the GPUs": the
 sample list of the batch is sharded in cloud order, i.e. GPU g owns cloud g of the batch (seeds 10 + g; the same size and
@@ -201,8 +208,9 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
 
 def host_api_extra(args, dev, sc, normals_mode):
     """What a caller of the HOST-buffer entry points pays (agh_set_cloud + agh_find_hands: the C++ adapter's
-    HandSearch::findHands, hand_search.h:101-104 takes a host cloud): upload of the cloud, grid build, search, read-back
-    of flags, count and records, two synchronisations.  SURVEY 8d asks for both figures; this one is never `value`."""
+    HandSearch::findHands, hand_search.h:101-104 takes a host cloud): upload of the cloud, grid build, search, the list written
+    to pinned host memory by the concatenation kernel, one synchronisation -- through the Python binding (ctypes + numpy; the
+    same calls from C++ are the key host_api_c).  SURVEY 8d asks for both figures; this one is never `value`."""
     from agile_grasp_amd import binding
 
     ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
@@ -220,10 +228,48 @@ def host_api_extra(args, dev, sc, normals_mode):
         t_find += time.perf_counter() - t1
     ctx.close()
     dt = (t_set + t_find) / calls
-    return {"what": "agh_set_cloud (H2D of 12 B/point + camera ids, grid build) + agh_find_hands (search, D2H of count, flags and "
-                    "160-byte records), host numpy buffers in and out", "calls": calls, "ms_per_call": dt * 1e3,
+    return {"what": "agh_set_cloud (H2D of 12 B/point + camera ids, grid build) + agh_find_hands (search; count, flags and 160-byte "
+                    "records land in pinned host memory), host numpy buffers in and out, Python binding", "calls": calls,
+            "ms_per_call": dt * 1e3,
             "ms_set_cloud": t_set / calls * 1e3, "ms_find_hands": t_find / calls * 1e3, "value": len(hyps) / dt,
             "unit": "hypotheses/s", "hypotheses": int(len(hyps))}
+
+
+def host_api_c_extra(sc, calls: int):
+    """The same host-buffer entry points called from plain C++ (scripts/micro/host_api_c.cpp, built here with g++ against the
+    in-tree library): what the adapter's HandSearch::findHands pays per cloud without the Python binding between the calls."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+
+    gxx = shutil.which("g++")
+    if not gxx:
+        return {"error": "no g++ on this box"}
+    libdir = os.path.join(ROOT, "agile_grasp_amd", "lib")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe, cloud = os.path.join(tmp, "host_api_c"), os.path.join(tmp, "cloud.bin")
+        cmd = [gxx, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "micro", "host_api_c.cpp"),
+               "-o", exe, "-L" + libdir, "-lagile_grasp_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+        try:
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            with open(cloud, "wb") as f:
+                f.write(struct.pack("<qq", sc.n, sc.samples.size))
+                f.write(np.asarray(sc.cam_origins, np.float64).tobytes())
+                f.write(sc.xyz.astype(np.float32).tobytes())
+                f.write(sc.cam.astype(np.int32).tobytes())
+                f.write(sc.samples.astype(np.int32).tobytes())
+            out = subprocess.run([exe, cloud, str(calls)], capture_output=True, text=True, timeout=120)
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+            if out.returncode != 0 or not line:
+                return {"error": (out.stdout + out.stderr)[-300:]}
+            r = json.loads(line[-1])
+            r["ms_per_call"] = r["us_per_call_median"] / 1e3
+            r["value"] = r["hypotheses"] / (r["us_per_call_median"] * 1e-6)
+            r["unit"] = "hypotheses/s"
+            return r
+        except Exception as e:  # noqa: BLE001
+            return {"error": str(e)[-300:]}
 
 
 def settle(ctx, step, fence):
@@ -781,6 +827,7 @@ def main():
                 res["untilted_rand50"] = single_cloud_extra(args, dev, stream, "C2u", binding.NORMALS_RAND50,
                                                             "C2u (axis-aligned) in the reference's production mode")
             res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
+            res["host_api_c"] = host_api_c_extra(sc, max(20, args.steps))
             # the other single-GPU BASELINE configs, on the same clock as the headline
             z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
             res["c3"] = single_cloud_extra(args, dev, stream, "C2", normals_mode,
