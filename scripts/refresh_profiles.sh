@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 for cfg in C2 C3 C4; do
   rm -rf /tmp/kt_$cfg
   # (--batch-clouds 0: every k_hand_sweep launch of the trace is the single-cloud launch the bench line's roofline describes)
@@ -38,9 +38,17 @@ f=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/pmc_WRITE_SI
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null   # bench.py reads roofline.traffic from here
 cd $R
 timeout 400 python bench.py --config C2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_c2.json 2> /dev/null   # the driver's own command line
-# the sample-sharded path through the library's RCCL communicator, as far as one GPU can show it (a communicator of one)
-(AGH_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
-  bench.py --gpus 1 --shard samples --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c2_sharded_x1.json)
+# the multi-GPU line as far as one GPU can show it: the sharded entry points on an RCCL communicator of ONE rank (--dist), first
+# the default series (C5, one cloud per GPU; c2_ / c4_sample_sharded ride along), then sample sharding as the headline
+timeout 400 python bench.py --gpus 1 --dist --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c5_cloud_per_gpu_x1.json
+timeout 300 python bench.py --gpus 1 --dist --shard samples --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2> /dev/null | grep '^{' > $OUT/${TAG}_bench_c2_sharded_x1.json
+# what one rank of an N-GPU sample-sharded run executes before the exchange
+timeout 300 python scripts/slice_timing.py 2> /dev/null > $OUT/${TAG}_slice_timing.txt
+# the host-buffer entry points from plain C++, and their timeline
+timeout 200 bash scripts/host_api_c.sh C2 50 2> /dev/null | grep '^{' > $OUT/${TAG}_host_api_c.jsonl
+timeout 400 bash scripts/host_timeline.sh ${TAG} > /dev/null 2>&1
+cp $R/gpurun_out/${TAG}_host_timeline_api.txt $R/gpurun_out/${TAG}_host_timeline_pipeline.txt $R/gpurun_out/${TAG}_host_timeline_api.json \
+  $R/gpurun_out/${TAG}_host_timeline_pipeline.json $OUT/ 2> /dev/null
 timeout 300 python bench.py --config C3 > $OUT/${TAG}_bench_c3.json 2> /dev/null
 timeout 300 python bench.py --config C2 --normals rand50 --no-cpu-baseline > $OUT/${TAG}_bench_c2_rand50.json 2> /dev/null
 timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TAG}_bench_c4.json 2> /dev/null
