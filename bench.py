@@ -348,6 +348,78 @@ def cloud_per_gpu_secondary(args, dev, stream, rank, world, normals_mode):
             "ms_per_step": dt / args.steps * 1e3, "value": n_hyp * args.steps / dt, "unit": "hypotheses/s", "hypotheses": n_hyp}
 
 
+def c5_batch_sharded_secondary(args, dev, stream, rank, world, normals_mode):
+    """N ranks, extra key: BASELINE config C5 TO THE LETTER -- the FIXED batch of eight 300k-point clouds (seeds 10..17, 2000 samples
+    each), its cloud-major sample list sharded contiguously over the ranks: with N dividing 8, rank r holds clouds
+    [8 r / N, 8 (r + 1) / N) as one batch in its context (agh_set_cloud_batch_device) and searches all their samples in one
+    launch set; the lists are exchanged by the library's all-gather.  Total work is fixed: "strong".  (N = 8 is one cloud per
+    GPU, the headline's own configuration; N = 1 is the `batched` key of the single-GPU line through the sharded call.)"""
+    import torch.distributed as dist
+
+    from agile_grasp_amd import binding, synthetic
+
+    C = 8
+    if C % world:
+        return {"error": f"{world} ranks do not divide the batch of {C} clouds"}
+    per = C // world
+    scs = [synthetic.config(f"C5_{k}") for k in range(rank * per, (rank + 1) * per)]
+    ctx = binding.Context(scs[0].cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(binding.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    ctx.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+    off = np.zeros(per + 1, np.int64)
+    off[1:] = np.cumsum([s.n for s in scs])
+    xyz_t = torch.from_numpy(np.concatenate([s.xyz for s in scs])).to(dev)
+    cam_t = torch.from_numpy(np.concatenate([s.cam for s in scs])).to(dev)
+    mine = np.concatenate([s.samples + off[k] for k, s in enumerate(scs)]).astype(np.int32)  # positions in MY point array
+    S_all = C * 2000
+    assert mine.size * world == S_all
+    s_all_t = torch.zeros(S_all, dtype=torch.int32, device=dev)
+    s_all_t[rank * mine.size:(rank + 1) * mine.size] = torch.from_numpy(mine).to(dev)
+    out_t = torch.zeros(8 * S_all * 160, dtype=torch.uint8, device=dev)
+    nout_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.set_cloud_batch_torch(xyz_t, cam_t, off, stream=stream)
+        ctx.find_hands_sharded_torch(s_all_t, out_t, nout_t, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    settle(ctx, step, fence)
+    steps = max(5, args.steps // 2)
+    for attempt in range(3):
+        for _ in range(max(args.warmup, 3)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        try:
+            ctx.synchronize()
+            break
+        except binding.AghError as e:
+            if e.code != binding.AGH_ERR_RETRY or attempt == 2:
+                raise
+    tv = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+    dt = float(tv[0].item())
+    n_hyp = int(nout_t.item())
+    ctx.comm_destroy()
+    ctx.close()
+    return {"workload": f"C5 to the letter: the fixed batch of {C} two-view 300000-point clouds (seeds 10..17), {S_all} samples, the "
+                        f"cloud-major sample list sharded over {world} GPUs ({per} cloud{'s' if per > 1 else ''} per GPU in one context), "
+                        "lists all-gathered by the library", "scaling": "strong", "n_gpus": world, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "ms_per_cloud": dt / steps * 1e3 / C, "value": n_hyp * steps / dt, "unit": "hypotheses/s",
+            "hypotheses": n_hyp}
+
+
 def sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, cfg):
     """N > 1, extra keys: ONE cloud with its samples sharded over the GPUs (strong scaling) -- BASELINE config C4 (1M points,
     8000 samples), the smallest configuration whose sample count warrants sharding, and C2, whose 2000
@@ -690,7 +762,7 @@ def main():
             if n_r != world:
                 raise RuntimeError(f"the library's communicator has {n_r} ranks, torch.distributed {world}")
 
-    secondary, secondary_c4, hung = None, None, False
+    secondary, secondary_c4, secondary_c5, hung = None, None, None, False
     if distributed and lib_comm and base == "C2" and not classify:
         # never at the price of the headline line: the extra measurements run on a watched thread
         import threading
@@ -712,13 +784,19 @@ def main():
                     box["c4"] = sample_sharded_secondary(args, dev, stream, rank, world, normals_mode, "C4")
                 except Exception as e:
                     box["c4"] = {"error": str(e)}
+                if 8 % world == 0:  # (the same decision on every rank: the call is a collective)
+                    try:
+                        box["c5"] = c5_batch_sharded_secondary(args, dev, stream, rank, world, normals_mode)
+                    except Exception as e:
+                        box["c5"] = {"error": str(e)}
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        th.join(timeout=420)
+        th.join(timeout=600)
         hung = th.is_alive()
         secondary = {"error": "timed out"} if hung and "res" not in box else box.get("res")
         secondary_c4 = {"error": "timed out"} if hung else box.get("c4")
+        secondary_c5 = {"error": "timed out"} if hung else box.get("c5")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -738,7 +816,7 @@ def main():
         if not distributed:
             import hashlib
 
-            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tf):
                     try:
@@ -794,6 +872,8 @@ def main():
             res["c2_sample_sharded" if by_cloud else "cloud_per_gpu"] = secondary
         if secondary_c4 is not None:
             res["c4_sample_sharded"] = secondary_c4
+        if secondary_c5 is not None:
+            res["c5_batch_sharded"] = secondary_c5
         if distributed and base == "C2":
             res["config"]["note"] = (
                 "BASELINE config C5: the batch of 300k-point clouds with its samples sharded over the GPUs in cloud order -- GPU g "

@@ -113,6 +113,46 @@ def test_cloud_per_rank_is_the_same_sharded_call():
                     assert np.array_equal(part[f], ref[f]), (r, f)
 
 
+def test_batch_per_rank_is_the_same_sharded_call():
+    """BASELINE config C5 to the letter on fewer GPUs than clouds (`bench.py`'s key c5_batch_sharded): the cloud-major sample list
+    of a batch of FOUR clouds sharded over TWO ranks -- rank r holds clouds 2r, 2r + 1 as one batch in its context
+    (agh_set_cloud_batch) and its slice of the list is their samples, as positions in its own point array."""
+    from agile_grasp_amd import binding, synthetic
+
+    G, per, S = 2, 2, 120
+    scenes = [synthetic.make_scene(30_000, S, seed=70 + k, two_view=True, n_objects=5, name=f"batch_{k}") for k in range(G * per)]
+    refs = []
+    for sc in scenes:
+        one = binding.Context(sc.cam_origins)
+        one.set_cloud(sc.xyz, sc.cam)
+        refs.append(one.find_hands(sc.samples))
+    assert all(len(r) > 10 for r in refs)
+    ctxs = [binding.Context(scenes[0].cam_origins) for _ in range(G)]
+    offs = []
+    for r, c in enumerate(ctxs):
+        mine = scenes[r * per:(r + 1) * per]
+        c.set_cloud_batch([sc.xyz for sc in mine], [sc.cam for sc in mine])
+        offs.append(np.concatenate([[0], np.cumsum([sc.n for sc in mine])]))
+    binding.comm_init_local(ctxs)
+
+    def search(r, c):
+        idx = np.zeros(G * per * S, np.int32)
+        mine = scenes[r * per:(r + 1) * per]
+        idx[r * per * S:(r + 1) * per * S] = np.concatenate([sc.samples + offs[r][k] for k, sc in enumerate(mine)])
+        return c.find_hands_sharded(idx)
+
+    for hyps in _run_ranks(ctxs, search):
+        assert len(hyps) == sum(len(r) for r in refs)
+        at = 0
+        for k, ref in enumerate(refs):
+            part = hyps[at:at + len(ref)]
+            at += len(ref)
+            assert np.array_equal(part["sample"], ref["sample"] + k * S)
+            for f in FIELDS:
+                if f != "sample":
+                    assert np.array_equal(part[f], ref[f]), (k, f)
+
+
 def test_sharded_antipodal_pass(tiny_scene):
     """calculates_antipodal: the all-points normals pass sharded by point range, cloud_normals_ and the samples' own
     normals all-gathered before the hand search (hand_search.cpp:13-26, 102)."""
