@@ -292,7 +292,10 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     const int rows = min(kChunk, n - c0);
     const float4 p = p_next;
     p_next = stage[slot[min(c0 + kChunk + lane, n_last)]];
-    if (lane < rows)
+    // TWO waves form the 37 terms of a chunk (19 + 18), not four (10 + 9 + 9 + 9): every producing wave converts the point and
+    // forms the six squares and mixed products for itself, so four producers issue 4 x 9 + 31 fp64 instructions per chunk where
+    // two issue 2 x 9 + 31 -- and the phase is bound by the fp64 issue slots of a CU that runs sixteen such waves.
+    if (lane < rows && wave < 2)
     {
       const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
       const double x2 = x * x, y2 = y * y, z2 = z * z;
@@ -310,9 +313,6 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
         t[7 * kTS] = x2 * y;
         t[8 * kTS] = x2 * z;
         t[9 * kTS] = x2;
-      }
-      else if (wave == 1)
-      {
         t[10 * kTS] = y2 * y2;
         t[11 * kTS] = y2 * z2;
         t[12 * kTS] = y2 * xy;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
         t[17 * kTS] = y2 * z;
         t[18 * kTS] = y2;
       }
-      else if (wave == 2)
+      else
       {
         t[19 * kTS] = z2 * z2;
         t[20 * kTS] = z2 * xy;
@@ -334,9 +334,6 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
         t[25 * kTS] = z2 * z;
         t[26 * kTS] = z2;
         t[27 * kTS] = x * yz;
-      }
-      else
-      {
         t[28 * kTS] = xy;
         t[29 * kTS] = yz;
         t[30 * kTS] = xz;
