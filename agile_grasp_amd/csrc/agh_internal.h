@@ -219,7 +219,10 @@ struct Ctx
   int32_t* d_status = nullptr;
   int* d_weight = nullptr;         // candidate count of each sample's hand-search ball (scheduling weight)
   uint8_t* d_vmask = nullptr;      // per sample: orientations with a hypothesis (k_hand_sweep -> concatenation)
-  int* d_order = nullptr;          // samples by descending weight: blockIdx -> sample of k_hand_sweep
+  int* d_order = nullptr;          // samples by descending n_t: blockIdx -> sample of k_taubin_frame
+  int* d_order_sweep = nullptr;    // blocks of 32 samples, heaviest first: blockIdx -> sample of k_hand_sweep (made by K1b)
+  int order_sweep_s = 0;           // the sample count / list that order was made for (0: none)
+  const int32_t* order_sweep_samples = nullptr;
   float4* d_nbr = nullptr;         // s_cap * nbr_stride sorted neighbour lists
   int64_t nbr_stride = 0;
   double* d_eig = nullptr;         // s_cap * 12 : params[10], eigenvalue, valid

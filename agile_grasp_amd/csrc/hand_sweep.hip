@@ -166,14 +166,8 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   unsigned* const rmc = &img[0][0];
   __shared__ int cnt_crop, any_hand, pending, tile_end;
 
-  // (work-groups in sample order: the caller's samples are spatially sorted, neighbouring work-groups share grid rows in L2,
-  // and since the gather only walks the hand's slab no weight known before the launch predicts a work-group's duration well
-  // enough to beat that -- longest-first by ball candidates: 104 us, by Taubin neighbours: 109, sample order: 102)
-#ifdef AGH_DEBUG_HOOKS  // scripts/sweep_order_experiment.py: an explicit blockIdx -> sample map (AGH_DEBUG_SWEEP_ORDER)
+  // blockIdx -> sample: blocks of 32 samples, heaviest first (K1b's sorter work-group: sweep_order_block), or sample order
   const int s = order ? order[blockIdx.x] : blockIdx.x;
-#else
-  const int s = blockIdx.x;
-#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define AGH_STAMP(i) do { if (dbg && tid == 0) dbg[(int64_t) s * 8 + (i)] = wall_clock64(); } while (0)
   AGH_STAMP(0);
@@ -1271,7 +1265,8 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const int Si = (int) S;
   const HandGeom* dg = c->d_geom;
   const double* nrm = use_normals ? c->d_normals : nullptr;
-  const int* order = nullptr;  // (the kernel runs in sample order; c->d_order serves k_taubin_frame)
+  // the block-wise order K1b's sorter made for exactly this launch (same sample list, same count), else sample order
+  const int* order = (c->order_sweep_s == Si && c->order_sweep_samples == d_samples) ? c->d_order_sweep : nullptr;
 #ifdef AGH_DEBUG_HOOKS
   {
     static int* dbg_order = nullptr;

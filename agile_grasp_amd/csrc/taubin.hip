@@ -497,6 +497,47 @@ __device__ void sample_order_block(const int* __restrict__ weight, int S, int* _
   }
 }
 
+// blockIdx -> sample map of k_hand_sweep (round 4): BLOCKS of 32 consecutive samples, heaviest block first by the sum of the
+// Taubin neighbour counts, order kept inside a block.  A sweep work-group's duration follows the local point density (its
+// correlation with n_t is 0.56 per sample, 0.9 per block of 64); the samples arrive spatially sorted, so dense regions are runs
+// of slow work-groups and a run that is dispatched late is the kernel's tail.  Whole blocks keep what neighbouring
+// work-groups share in L2 (a per-sample longest-first order by n_t is no better than sample order; a random one costs 4 us).
+// C2: 91.5 -> 85.2 us (scripts/sweep_order_experiment.py; longest-first by the MEASURED durations, which nothing known before
+// the launch predicts, would be 76).  At most 1024 blocks (S <= 32768); beyond, the sweep runs in sample order.
+constexpr int kSweepBlock = 32, kSweepBlocksMax = 1024;
+__device__ void sweep_order_block(const int* __restrict__ weight, int S, int* __restrict__ order2, int* bw /* kSweepBlocksMax */)
+{
+  const int B = (S + kSweepBlock - 1) / kSweepBlock;
+  if (B > kSweepBlocksMax)
+    return;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  for (int b = tid; b < B; b += 256)
+  {
+    int w = 0;
+    const int i0 = b * kSweepBlock, i1 = min(S, i0 + kSweepBlock);
+    for (int i = i0; i < i1; i++)
+      w += weight[i];
+    bw[b] = w;
+  }
+  __syncthreads();
+  const int last_size = S - (B - 1) * kSweepBlock;
+  int rank_last = 0;  // rank of the (possibly short) last block
+  for (int q = 0; q < B - 1; q++)
+    rank_last += bw[q] >= bw[B - 1] ? 1 : 0;  // (earlier index wins ties)
+  for (int b = tid; b < B; b += 256)
+  {
+    const int wb = bw[b];
+    int rank = 0;
+    for (int q = 0; q < B; q++)
+      rank += (bw[q] > wb || (bw[q] == wb && q < b)) ? 1 : 0;
+    const int pos = rank * kSweepBlock - (rank > rank_last ? kSweepBlock - last_size : 0);
+    const int size = b == B - 1 ? last_size : kSweepBlock;
+    for (int k = 0; k < size; k++)
+      order2[pos + k] = b * kSweepBlock + k;
+  }
+}
+
 // RAND50: sample i consumes 50 draws iff its neighbourhood has more than 50 points, in sample order (one wave: chunked
 // inclusive scan; *total_io carries the draws consumed by earlier passes of this call).
 __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
@@ -535,14 +576,18 @@ __device__ void draw_offsets_wave(const int32_t* __restrict__ nt, int S, int32_t
 template <int LPS>
 __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__ sums, const int32_t* __restrict__ nt,
   const int32_t* __restrict__ status, int S, double* __restrict__ eig, int32_t* __restrict__ flags,
-  const int* __restrict__ weight, int* __restrict__ order, int32_t* __restrict__ draw_ofs, int32_t* __restrict__ draw_total_io)
+  const int* __restrict__ weight, int* __restrict__ order, int32_t* __restrict__ draw_ofs, int32_t* __restrict__ draw_total_io,
+  int* __restrict__ order_sweep)
 {
   __shared__ int hist[kOrderBins];
   __shared__ int wave_tot[4];
+  static_assert(kSweepBlocksMax <= kOrderBins, "the sweep's block weights reuse the histogram");
   const int n_solver_groups = (S * LPS + 255) / 256;
-  if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling order of the following kernels
+  if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling orders of the following kernels
   {
     sample_order_block(weight, S, order, hist, wave_tot);
+    if (order_sweep)
+      sweep_order_block(weight, S, order_sweep, hist);
     return;
   }
   if ((int) blockIdx.x > n_solver_groups)  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
@@ -1253,12 +1298,17 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   // between the ranks first -- the sharded search)
   int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
   const int eig_grid = eig_groups + (dofs ? 1 : 0);
+  // the hand sweep's block-wise order rides along (hand_sweep() uses it when it was made for exactly its launch)
+  const bool with_sweep_order = radius > 0.015 && (Si + kSweepBlock - 1) / kSweepBlock <= kSweepBlocksMax && Si >= 4 * kSweepBlock;
+  int* sweep_order = with_sweep_order ? c->d_order_sweep : nullptr;
+  c->order_sweep_s = with_sweep_order ? Si : 0;
+  c->order_sweep_samples = with_sweep_order ? d_samples : nullptr;
   if (lps == 8)
     hipLaunchKernelGGL(k_taubin_eigen<8>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2, sweep_order);
   else
     hipLaunchKernelGGL(k_taubin_eigen<1>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2);
+      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2, sweep_order);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
