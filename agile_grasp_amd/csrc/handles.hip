@@ -6,11 +6,14 @@
 //                        acos thresholds become comparisons of the dot products with host-computed constants x1, x2
 //                        (acos is monotone: acos(x) < 0.34 <=> x >= x1, pi - acos(x) < 0.34 <=> x <= x2; the constants
 //                        are found by bisection with the same libm the oracle uses)
-//   K5b k_handle_greedy  the sequential part (:11-19, 47-80): for every still-available seed hand in index order collect
-//                        its available inliers, sort by distance along the seed's axis, cut at the first 2 cm gap
-//                        (shortenHandle, :88-118, with the meaning the oracle states for its out-of-range read), accept
-//                        if long enough, retire the members.  One work-group: the loop is inherently serial, the work
-//                        inside an iteration (mask, compaction, rank sort, gap search) is spread over its 256 threads.
+//   K5b the walk (:11-19, 47-80): for every still-available seed hand in index order collect its available inliers, sort by
+//                        distance along the seed's axis, cut at the first 2 cm gap (shortenHandle, :88-118, with the meaning
+//                        the oracle states for its out-of-range read), accept if long enough, retire the members.
+//       k_handle_batch   (round 4) sixteen open seeds per round, one wave each, everything in registers, committed as if in
+//                        index order -- for pair matrices whose rows hold at most 64 hands (what the search meets on the
+//                        hands Learning::classify keeps); 15 rounds of ~4.7 us for the pipeline's 499 hands
+//       k_handle_greedy  the sequential walk by one wave, for longer rows (launched along only when the previous set of
+//                        hands needed it)
 //   K5c k_handle_build   Handle::Handle per accepted handle, one wave each.
 #include "agh_internal.h"
 

@@ -130,7 +130,11 @@ const char* agh_last_error(const agh_ctx* ctx); /* ctx may be NULL: error of the
 
 /* Upload (host pointers) or adopt (device pointers) a cloud and build the uniform search grid on the GPU.
  * xyz: x,y,z float32 at byte offset 0 of each point; stride_bytes = 12 (packed) or 32 (pcl::PointXYZRGBA).
- * cam_source: 0/1 per point (Eigen::VectorXi pts_cam_source), may be NULL (all 0). */
+ * cam_source: 0/1 per point (Eigen::VectorXi pts_cam_source), may be NULL (all 0).
+ * The host variant returns when xyz and cam_source have been READ (the caller may free or overwrite them at once); the grid
+ * build is then still queued on the context's stream, in front of whatever uses the cloud next -- a search on another stream
+ * waits for it first -- and an asynchronous failure of the build surfaces at that call's synchronisation.  (Upload from pinned
+ * memory, hipHostMalloc / hipHostRegister, if the caller can: a pageable upload is a blocking copy.) */
 int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, int64_t n);
 int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
   int64_t n, void* hip_stream);
@@ -154,7 +158,10 @@ int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_
  * workspace box {xmin,xmax,ymin,ymax,zmin,zmax} (filterWorkspace, :216-245); per-camera voxelisation with cell_size
  * (voxelizeCloud, :247-355; the reference passes 0.003) in lexicographic voxel order, camera 0 block first.  The
  * voxelised cloud becomes the context's cloud (as after agh_set_cloud) and can be read back with agh_get_cloud.
- * The device variant synchronises hip_stream twice (lattice size, voxel count).  AGH_ERR_CAPACITY if the kept points
+ * The device variant synchronises hip_stream once per cloud for the voxel count (which sizes the search grid); the lattice
+ * size, which sizes the voxel bitmap, costs a second synchronisation only for the first cloud of a context or when a cloud's
+ * lattice outgrew the bitmap kept from the previous one.  The host variant returns when the caller's buffer has been read;
+ * the grid build is still queued on the context's stream (as after agh_set_cloud).  AGH_ERR_CAPACITY if the kept points
  * span more than 2^33 lattice cells. */
 int agh_preprocess(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, int64_t size_left, int dense,
   const double workspace[6], double cell_size, int64_t* n_voxels_out);
@@ -182,7 +189,9 @@ int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands,
 int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
 
 /* HandSearch::findHands for explicit sample indices.  out receives <= 8*n_samples records, sample-major and
- * orientation-ascending (the reference's concatenation order, hand_search.cpp:194-200). */
+ * orientation-ascending (the reference's concatenation order, hand_search.cpp:194-200).  The host variant stages the sample
+ * list in pinned memory of the context, the concatenation kernel writes count, flags and records into pinned memory as well,
+ * and the call waits for ONE stream synchronisation (no read-back copies). */
 int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* out, int64_t cap, int64_t* n_out);
 /* Same, everything device-resident and asynchronous on hip_stream (NULL = the context's stream):
