@@ -686,11 +686,19 @@ def main():
     settle(ctx, step, fence)
     # Clocks: a cold GPU runs the first milliseconds below its sustained clock and these kernels are issue bound, so the
     # same step runs untimed for a moment first (the W warm-up steps and the K timed steps follow unchanged).
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spin_seconds:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
+    if distributed:
+        # every step is a collective: all ranks must run the SAME number of them, so the spin is a step count here, not a clock
+        # (a clock would let one rank run a batch more than another and leave it waiting in an all-gather nobody joins)
+        for _ in range(max(1, int(args.spin_seconds * 4000 / 20))):
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+    else:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spin_seconds:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
     fence()
     while True:
         for _ in range(args.warmup):
