@@ -597,7 +597,9 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   HIPCHK(c, order_after_cloud(c, st));
   const int G = c->comm->n_ranks, r = c->comm->rank;
   const int64_t S = n_samples;
-  const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = hi - lo;
+  // (a rank whose cloud is EMPTY -- possible when every rank searches a cloud of its own -- takes part with an empty slice: it
+  // must still join every collective of the call, or the others wait for it for ever)
+  const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = c->n == 0 ? 0 : hi - lo;
   const int64_t Smax = (S + G - 1) / G;
   if (Smax > 65536)  // the same on every rank: slices this long launch every capacity class from the start
     c->big_classes = true;
@@ -642,7 +644,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   c->last_cap = seg_records;
   c->d_out_last = my_out;
   c->d_nout_last = my_count;
-  if (S == 0 || c->n == 0)
+  if (S == 0)  // (the same on every rank: nobody starts a collective)
   {
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
     c->zero_flags_pending = false;
@@ -854,13 +856,19 @@ static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx,
     c->err = "agh_find_hands_sharded: bad arguments";
     return AGH_ERR_INVALID_ARGUMENT;
   }
-  for (int64_t i = 0; i < n_samples; i++)
-    if (sample_idx[i] < 0 || sample_idx[i] >= c->n)
-    {
-      c->err = "agh_find_hands_sharded: sample index out of range";
-      return AGH_ERR_INVALID_ARGUMENT;
-    }
   *entered = true;  // every rank passed the same checks on the same arguments: what fails from here on fails on this rank alone
+  {
+    // a rank reads only ITS slice of the list (when every rank searches a cloud of its own the other slices index other clouds):
+    // only that slice is checked, and a bad index in it is this rank's own failure
+    const int G = c->comm->n_ranks, r = c->comm->rank;
+    const int64_t lo = shard_lo(n_samples, r, G), hi = c->n == 0 ? lo : shard_lo(n_samples, r + 1, G);
+    for (int64_t i = lo; i < hi; i++)
+      if (sample_idx[i] < 0 || sample_idx[i] >= c->n)
+      {
+        c->err = "agh_find_hands_sharded: sample index out of range";
+        return AGH_ERR_INVALID_ARGUMENT;
+      }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
   if (rc != AGH_OK)

@@ -113,6 +113,44 @@ def test_cloud_per_rank_is_the_same_sharded_call():
                     assert np.array_equal(part[f], ref[f]), (r, f)
 
 
+def test_cloud_per_rank_with_an_empty_cloud_on_one_rank():
+    """A rank whose own cloud is empty still joins every collective of the call (it used to return early and leave the others
+    waiting in the all-gather): it contributes an empty slice."""
+    from agile_grasp_amd import binding, synthetic
+
+    G, S = 3, 64
+    scenes = [synthetic.make_scene(30_000, S, seed=80 + r, two_view=True, n_objects=5, name=f"e_{r}") for r in range(G)]
+    refs = []
+    for r, sc in enumerate(scenes):
+        one = binding.Context(sc.cam_origins)
+        one.set_cloud(sc.xyz, sc.cam)
+        refs.append(one.find_hands(sc.samples) if r != 1 else one.find_hands(sc.samples)[:0])
+    ctxs = [binding.Context(sc.cam_origins) for sc in scenes]
+    for r, (c, sc) in enumerate(zip(ctxs, scenes)):
+        if r == 1:
+            c.set_cloud(np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        else:
+            c.set_cloud(sc.xyz, sc.cam)
+    binding.comm_init_local(ctxs)
+
+    def search(r, c):
+        idx = np.zeros(G * S, np.int32)
+        if r != 1:
+            idx[r * S:(r + 1) * S] = scenes[r].samples
+        return c.find_hands_sharded(idx)
+
+    for hyps in _run_ranks(ctxs, search):
+        assert len(hyps) == sum(len(r) for r in refs) > 0
+        at = 0
+        for r, ref in enumerate(refs):
+            part = hyps[at:at + len(ref)]
+            at += len(ref)
+            assert np.array_equal(part["sample"], ref["sample"] + r * S)
+            for f in FIELDS:
+                if f != "sample":
+                    assert np.array_equal(part[f], ref[f]), (r, f)
+
+
 def test_batch_per_rank_is_the_same_sharded_call():
     """BASELINE config C5 to the letter on fewer GPUs than clouds (`bench.py`'s key c5_batch_sharded): the cloud-major sample list
     of a batch of FOUR clouds sharded over TWO ranks -- rank r holds clouds 2r, 2r + 1 as one batch in its context
