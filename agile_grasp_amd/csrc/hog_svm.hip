@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   __shared__ __attribute__((aligned(4))) uint8_t code[kCodeH * kCodeW];
   __shared__ uint8_t nzk[kNBlocks][256];  // per block: pixData entries with a non-zero gradient, in order
   __shared__ int nzc[kNBlocks];
+  __shared__ uint8_t border[kNBlocks + 3];  // blocks by descending list length
   __shared__ float hist[kNBlocks][36];
   __shared__ float grp[882];
   __shared__ __attribute__((aligned(16))) HogTablesDev Ts;  // the 11 KiB of tables are hit on every vote: keep them in LDS
@@ -274,9 +275,26 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   // block histograms (HOGCache::getBlock): one (block, cell) per work item, votes in pixData order.  The nine bins live
   // in registers; every listed pixel adds mag * weight to its two bins and +0.0f (exact) to the others, and a pixel
   // that does not vote for this cell has weight 0 -- so there is no data-dependent branch and no LDS read-modify-write.
-  for (int wi = tid; wi < kNBlocks * 4; wi += 256)
+  // 308 (block, cell) items on 256 threads: a thread's time is the number of listed pixels of its items, and the work-group
+  // waits for its slowest thread.  Items in plain order gave the threads 0..51 two items each, whatever their length; now the
+  // blocks are ranked by their list length (border: longest first) and the 52 second items are the SHORTEST lists, handed to the
+  // threads whose first item is the shortest of the first 256.
+  if (tid < kNBlocks)
   {
-    const int b = wi >> 2, cell = wi & 3;
+    const int mine = nzc[tid];
+    int r = 0;
+    for (int q = 0; q < kNBlocks; q++)
+      r += (nzc[q] > mine || (nzc[q] == mine && q < tid)) ? 1 : 0;
+    border[r] = (uint8_t) tid;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 2; pass++)
+  {
+    // second items: ranks 256 .. 307; the longest of them (256) goes to the thread with the shortest first item (255)
+    const int wi = pass == 0 ? tid : 256 + (255 - tid);
+    if (pass == 1 && wi >= kNBlocks * 4)
+      break;
+    const int b = border[wi >> 2], cell = wi & 3;
     const int x0 = (b / 7) * 8, y0 = (b % 7) * 8;
     float hh[9];
 #pragma unroll
@@ -350,28 +368,38 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   __syncthreads();
   if (debug_stop == 5 || !svm_w)  // (no model: descriptors only)
     return;
-  if (tid == 0)
+  if (wave == 0)
   {
+    // CvSVM::predict's accumulation: the 882 four-product partials (floats) are added to a double IN INDEX ORDER.  One lane
+    // doing it alone issued 882 x (LDS read, conversion, add): 11.6 us.  Now lane l holds entries 14 l .. 14 l + 13 as doubles
+    // (fetched and converted side by side), and the RUNNING SUM travels: in step l every lane adds its own fourteen to the sum
+    // that came in -- only lane l's result is the real one -- and that one is handed on as a scalar (two v_readlane per
+    // fourteen adds).  Same additions in the same order; the chain is the 882 adds and nothing else.
+    double gd[14];
+#pragma unroll
+    for (int u = 0; u < 14; u++)
+      gd[u] = lane < 63 ? (double) grp[lane * 14 + u] : 0.0;
     double s = 0;
-    for (int m0 = 0; m0 < 882; m0 += 14)  // 882 = 63 x 14: loads in flight, adds in index order
+    for (int l = 0; l < 63; l++)
     {
-      float g_[14];
+      double t = s;
 #pragma unroll
       for (int u = 0; u < 14; u++)
-        g_[u] = grp[m0 + u];
-#pragma unroll
-      for (int u = 0; u < 14; u++)
-        s += g_[u];
+        t += gd[u];
+      s = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), l), __builtin_amdgcn_readlane(__double2loint(t), l));
     }
-    const float res = (float) (s * 1.0 + 0.0);
-    const double sum = -rho + 1.0 * res;  // CvSVM::predict: class_labels[sum > 0 ? 0 : 1] = {-1, +1}
-    const uint8_t k = (sum > 0) ? 0 : 1;  // the reference keeps prediction == 1 (learning.cpp:225-227)
-    if (keep)
-      keep[h] = k;
-    if (sums)
-      sums[h] = sum;
-    if (out)
-      out[h].svm_keep = k;
+    if (lane == 0)
+    {
+      const float res = (float) (s * 1.0 + 0.0);
+      const double sum = -rho + 1.0 * res;  // CvSVM::predict: class_labels[sum > 0 ? 0 : 1] = {-1, +1}
+      const uint8_t k = (sum > 0) ? 0 : 1;  // the reference keeps prediction == 1 (learning.cpp:225-227)
+      if (keep)
+        keep[h] = k;
+      if (sums)
+        sums[h] = sum;
+      if (out)
+        out[h].svm_keep = k;
+    }
   }
 }
 
