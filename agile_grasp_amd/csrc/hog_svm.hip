@@ -247,17 +247,20 @@ __global__ __launch_bounds__(256) void k_hog_svm(const uint32_t* __restrict__ im
   if (debug_stop == 1)  // (AGH_DEBUG_STOP_HOG: phase-timing aid, like the other kernels' debug stops)
     return;
   // per block: ordered list of the pixData entries with a non-zero gradient (all other pixels vote +0.0f: nothing)
+  // (a lane's four pixData entries are the same for every block: their in-block offsets are read once, not once per block --
+  // the stores to nzk keep the compiler from hoisting the table reads itself)
+  int pofs[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+    pofs[c] = T->pix_y[c * 64 + lane] * kCodeW + T->pix_x[c * 64 + lane];
   for (int b = wave; b < kNBlocks; b += 4)
   {
     const int x0 = (b / 7) * 8, y0 = (b % 7) * 8;
     int cnt = 0;
     bool nzq[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++)  // the four chained look-ups (pixel position -> gradient code) are issued together
-    {
-      const int k = c * 64 + lane;
-      nzq[c] = code[(y0 + T->pix_y[k]) * kCodeW + x0 + T->pix_x[k]] != 4;
-    }
+    for (int c = 0; c < 4; c++)  // the four look-ups (pixel position -> gradient code) are issued together
+      nzq[c] = code[y0 * kCodeW + x0 + pofs[c]] != 4;
 #pragma unroll
     for (int c = 0; c < 4; c++)
     {

@@ -364,3 +364,30 @@ def test_model_loader_shapes_and_refusals(tiny_scene, tmp_path, svm_model):
     ctx.load_svm(w, rho)
     okeep, _ = O.classify(images, w, rho)
     assert np.array_equal(ctx.classify(), okeep) and len(hyps) == len(okeep)
+
+
+@pytest.mark.gpu
+def test_descriptor_of_dense_images_bit_exact(svm_model):
+    """Images far denser than any hand's: stripes whose horizontal (vertical) gradient is non-zero at EVERY pixel, so that every
+    block's list of voting pixData entries is full, half-density noise (three quarters of the pixels vote), a blank image and a
+    full one.  Descriptor, decision value and label against the oracle, bit for bit."""
+    from agile_grasp_amd import binding, synthetic
+
+    rng = np.random.default_rng(11)
+    imgs = np.zeros((6, 80, 100), np.uint8)
+    imgs[0][:, (np.arange(100) % 4) < 2] = 255                      # 1100 1100 ... : sx != 0 everywhere
+    imgs[1][(np.arange(80) % 4) < 2, :] = 255                       # the same in y
+    imgs[2] = (rng.random((80, 100)) < 0.5) * 255
+    imgs[3] = imgs[0] ^ ((rng.random((80, 100)) < 0.03) * 255).astype(np.uint8)
+    imgs[5][:] = 255
+    flat = imgs.reshape(6, 8000)
+    sc = synthetic.config("tiny")
+    ctx = binding.Context(sc.cam_origins)
+    packed = binding.pack_images(flat)
+    desc = ctx.hog_images(packed)
+    assert np.array_equal(desc, O.hog_many(flat))
+    assert np.abs(desc[0]).max() > 0 and not desc[4].any()
+    ctx.load_svm(*svm_model)
+    keep, sums = ctx.classify_images(packed)
+    okeep, osums = O.classify(flat, *svm_model)
+    assert np.array_equal(keep, np.asarray(okeep, np.uint8)) and np.array_equal(sums, osums)
