@@ -11,6 +11,7 @@ SRC = ["voxelize.hip", "grid.hip", "taubin.hip", "hand_sweep.hip", "hog_svm.hip"
 LIB = os.path.join(HERE, "lib", "libagile_grasp_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
          "-fno-gpu-rdc"]
+FLAGS += os.environ.get("AGH_EXTRA_FLAGS", "").split()  # experiments (e.g. -DAGH_FRAME_PAD=2048: one work-group less per CU)
 if os.environ.get("AGH_DEBUG_BUILD") == "1":  # phase-timing hooks (AGH_DEBUG_STOP_*, AGH_DEBUG_CLOCKS) for scripts/
     FLAGS.append("-DAGH_DEBUG_HOOKS")
 

@@ -675,6 +675,11 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   __shared__ unsigned short cand[CAP];
   __shared__ int ncand;
   __shared__ int bar3cnt;  // arrivals at the barriers of the estimate phase (waves 1..3 of the four-wave variant)
+#ifdef AGH_FRAME_PAD  // occupancy experiment: pad the LDS so that one work-group less fits a CU
+  __shared__ int pad_[AGH_FRAME_PAD / 4];
+  if (threadIdx.x == 0 && nmin == -12345)
+    pad_[blockIdx.x % (AGH_FRAME_PAD / 4)] = 1;
+#endif
 
   const int s = order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
