@@ -53,7 +53,7 @@ struct OriState
   double T[3][3];  // frame_ * rot^T
   double approach[3], binormal[3];
   double cs, sn;
-  double ymin, ymax;
+  double ymin;  // min of y over all cropped points (written after pass A)
   int rejected;
   int has_hand;
   int e;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   constexpr int kRmCopies = 4, kRmOriStride = 48, kRmCopyStride = 8 * kRmOriStride + 8;
   static_assert(kRmCopies * kRmCopyStride <= kImgPlanes * (kImageWords + 2), "the table copies must fit the image planes");
   unsigned* const rmc = &img[0][0];
+  __shared__ double ypart[4][8];  // a wave's minimum of y over its quarter of the tile, per orientation (screening)
   __shared__ int cnt_crop, any_hand, pending, tile_end;
 
   // blockIdx -> sample: blocks of 32 samples, heaviest first (K1b's sorter work-group: sweep_order_block), or sample order
@@ -278,7 +279,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     O.e = -1;
     O.last = 0;
     O.ymin = 0.0;
-    O.ymax = 0.0;
   }
   if (debug_stop == 1)
     return;
@@ -414,115 +414,86 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   };
 
   const int K = G.n_depths;
-  // ---- pass A: classify every cropped point once per orientation ----
-  double ymin_w[2] = { INFINITY, INFINITY }, ymax_w[2] = { -INFINITY, -INFINITY };
+  // ---- pass A: classify every cropped point once per orientation that can still produce a hand ----
+  // SCREENING.  FingerHand::evaluateFingers returns "no finger" as soon as one point with y < bite also has y < back
+  // (finger_hand.cpp:29-42); at the initial bite that is `ymin < depths[0] && ymin < backs[0]`, and an orientation without
+  // a hand at the initial bite has no hypothesis (rotating_hand.cpp:111).  So the minimum of y alone -- 4 instructions per
+  // point against the ~36 of the (region, depth) classification -- decides most orientations: 73 % of those the camera test
+  // leaves at C2 (a table's points reach 8 cm behind a hand that approaches along it).  The minimum only falls from tile to
+  // tile, so an orientation that is out stays out, and a work-group whose orientations are all out stops gathering.
+  // Every wave screens a quarter of the tile for all orientations still in, the partial minima meet in LDS, and lanes
+  // 0..7 of EVERY wave form the same running minima: `live` is uniform over the work-group without a second barrier.
+  unsigned classified = 0;  // orientations with bits in the table copies
+  unsigned live = 0;  // (set after the first tile's closing barrier: the camera test's flags are visible from there on)
+  double run_ymin = INFINITY;  // lane o < 8: min of y over the tiles so far in orientation o
+  auto screen = [&](int nc) {
+    double m[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+      m[o] = INFINITY;
+    double2 pn = pts[tid < nc ? tid : 0];
+    for (int b0 = 0; b0 < nc; b0 += 256)
+    {
+      // (a lane past the end of the tile holds point 0 once more: the minimum is idempotent)
+      const double2 p = pn;
+      const int tn = b0 + 256 + tid;
+      pn = pts[tn < nc ? tn : 0];
+#pragma unroll
+      for (int o = 0; o < 8; o++)
+        if ((live >> o) & 1u)  // (uniform)
+          m[o] = min_f64_raw(m[o], geom_p->sin_a[o] * p.x + geom_p->cos_a[o] * p.y);  // row y of rot * points_ (rotating_hand.cpp:91)
+    }
+    double mine = INFINITY;
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+      if ((live >> o) & 1u)
+      {
+        const double v = wave_min_f64(m[o]);
+        mine = lane == o ? v : mine;
+      }
+    if (lane < 8)
+      ypart[wave][lane] = mine;
+    __syncthreads();
+    bool out = false;
+    if (lane < 8)
+    {
+      run_ymin = min_f64_raw(run_ymin, min_f64_raw(min_f64_raw(ypart[0][lane], ypart[1][lane]), min_f64_raw(ypart[2][lane], ypart[3][lane])));
+      out = (run_ymin < G.depths[0]) && (run_ymin < G.backs[0]);  // finger_hand.cpp:29-42 at the initial bite
+    }
+    live &= ~(unsigned) __ballot(out);
+  };
+  // CLASSIFICATION of the orientations still in, every wave a quarter of the tile's points (all four waves set bits in the
+  // same table copies: LDS atomics; the finger phase waits for a barrier).
   // The inner loop is written in STAGES over four points per lane -- rotate, y look-up, x look-up, table update -- with no
   // control flow between the stages: each look-up is a chain of two dependent LDS reads, and with a branch per point (the
   // earlier form) the compiler waited for every read before issuing the next point's, sixteen exposed LDS round trips per
   // iteration instead of four.  Points beyond the deepest bite depth take the x look-up along and are masked at the update.
   auto classify = [&](int nc) {
-    for (int oo = 0; oo < 2; oo++)
+    for (int o = 0; o < 8; o++)
     {
-      const int o = wave + 4 * oo;
-      if (ori[o].rejected)
+      if (!((live >> o) & 1u))
         continue;
       const double cs = ori[o].cs, ms = -1.0 * ori[o].sn, sn = ori[o].sn;
-      double ymin = ymin_w[oo], ymax = ymax_w[oo];
       const double ylo = G.ylut_lo, ysc = G.ylut_scale, xlo = G.xlut_lo, xsc = G.xlut_scale;
       // (the four points of the NEXT pass are read while this pass classifies: one LDS round trip less on every pass)
       double2 pn[4];
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        pn[u] = pts[(lane + 64 * u) < nc ? lane + 64 * u : 0];
-#ifdef AGH_DEBUG_HOOKS
-      if (debug_stop == 20)  // EXPERIMENT (wrong results): the same loop on float32 -- what a float pre-classification could save at most
-      {
-        const float csf = (float) cs, msf = (float) ms, snf = (float) sn, ylof = (float) ylo, yscf = (float) ysc, xlof = (float) xlo,
-                    xscf = (float) xsc;
-        float yminf = (float) ymin, ymaxf = (float) ymax;
-        for (int t0 = lane; t0 < nc; t0 += 256)
-        {
-          float xr[4], yr[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            const double2 p = pn[u];
-            const int tn = t0 + 256 + 64 * u;
-            pn[u] = pts[tn < nc ? tn : 0];
-            const float px = (float) p.x, py = (float) p.y;
-            xr[u] = csf * px + msf * py;
-            yr[u] = snf * px + csf * py;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            yminf = fminf(yminf, yr[u]);
-            ymaxf = fmaxf(ymaxf, yr[u]);
-          }
-          int ly[4], lx[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            const int cy = min(max((int) ((yr[u] - ylof) * yscf), 0), 63);
-            const int cx = min(max((int) ((xr[u] - xlof) * xscf), 0), 1023);
-            ly[u] = G.ylut[cy];
-            lx[u] = G.xlut[cx];
-          }
-          float dv[4][PY], tv[4][PX];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-#pragma unroll
-            for (int j = 0; j < PY; j++)
-              dv[u][j] = reinterpret_cast<const float*>(dep_s)[ly[u] + j];
-#pragma unroll
-            for (int j = 0; j < PX; j++)
-              tv[u][j] = reinterpret_cast<const float*>(thr_s)[lx[u] + j];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            int yk = ly[u];
-#pragma unroll
-            for (int j = 0; j < PY; j++)
-              yk += (dv[u][j] <= yr[u]) ? 1 : 0;
-            int c = lx[u], e = 0;
-#pragma unroll
-            for (int j = 0; j < PX; j++)
-            {
-              c += (tv[u][j] < xr[u]) ? 1 : 0;
-              e |= (tv[u][j] == xr[u]) ? 1 : 0;
-            }
-            const int key = 2 * c + e;
-            if (yk < K && yk >= 0 && key >= 0 && (key >> 1) < 44)
-              atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + (yk & 15)));
-          }
-        }
-        ymin = (double) yminf;
-        ymax = (double) ymaxf;
-      }
-      else
-#endif
-      for (int t0 = lane; t0 < nc; t0 += 256)
+        pn[u] = pts[(tid + 256 * u) < nc ? tid + 256 * u : 0];
+      for (int b0 = 0; b0 < nc; b0 += 1024)
       {
         double xr[4], yr[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
           const double2 p = pn[u];
-          const int tn = t0 + 256 + 64 * u;
+          const int tn = b0 + 1024 + 256 * u + tid;
           pn[u] = pts[tn < nc ? tn : 0];
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
           yr[u] = sn * p.x + cs * p.y;
         }
-        // (a lane past the end of the tile holds point 0 once more: min, max and the table bits are idempotent, so nothing
-        // below needs to know -- no selects, no predicate besides the depth test)
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-        {
-          ymin = min_f64_raw(ymin, yr[u]);
-          ymax = max_f64_raw(ymax, yr[u]);
-        }
+        // (a lane past the end of the tile holds point 0 once more: the table bits are idempotent, so nothing below needs
+        // to know -- no selects, no predicate besides the depth test)
         // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
         int ly[4], lx[4];
 #pragma unroll
@@ -564,8 +535,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
             atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + yk));
         }
       }
-      ymin_w[oo] = ymin;
-      ymax_w[oo] = ymax;
     }
   };
   // A neighbourhood that needs more than one tile would have to be gathered again for pass B (filter, rotation and
@@ -594,19 +563,27 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
       else
         spill_ok = false;
     }
+    if (ntiles == 0)
+      for (int o = 0; o < 8; o++)
+        live |= ori[o].rejected ? 0u : (1u << o);
+    screen(nc);
+    classified |= live;
     classify(nc);
     ntiles++;
     ncrop_all += nc;
-    if (all_done)
+    if (all_done || live == 0)  // (no orientation left: the rest of the neighbourhood cannot change the result)
       break;
     next_tile();
   }
-  // (no work-group barrier here: a wave's finger logic only reads what the wave itself wrote in pass A -- the table copies of
-  // its own two orientations, its running y extrema -- so a wave whose orientations were rejected by the camera test, or
-  // that is simply ahead, goes on while the others still classify; the phase clocks of the debug build keep the barrier)
-#ifdef AGH_DEBUG_HOOKS
-  __syncthreads();
-#endif
+  // an orientation the screening put out is treated like one the camera test rejected from here on: no finger logic, no
+  // pass B, no record
+  if (wave == 0 && lane < 8)
+  {
+    ori[lane].ymin = run_ymin;
+    if (!((live >> lane) & 1u))
+      ori[lane].rejected = 1;
+  }
+  __syncthreads();  // all four waves wrote the tables of every orientation still in
   AGH_STAMP(3);
   if (debug_stop == 3)
     return;
@@ -618,9 +595,15 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   {
     const int o = wave + 4 * oo;
     if (ori[o].rejected)
+    {
+      // put out by a later tile after an earlier one had been classified: its table words go back to zero like those the
+      // finger logic reads (they are image planes from pass B on)
+      if (((classified & ~live) >> o) & 1u)
+        for (int k = lane; k < kRmCopies * 44; k += 64)
+          rmc[(k / 44) * kRmCopyStride + o * kRmOriStride + (k % 44)] = 0u;
       continue;
-    const double ymin = wave_min_f64(ymin_w[oo]);
-    const double ymax = wave_max_f64(ymax_w[oo]);
+    }
+    const double ymin = ori[o].ymin;  // (over all tiles, from the screening)
     if (lane < 44)  // this orientation's table: the OR of its copies (only this wave wrote them), which are zeroed again
     {
       unsigned m = 0;
@@ -690,8 +673,6 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     }
     if (lane == 0)
     {
-      ori[o].ymin = ymin;
-      ori[o].ymax = ymax;
       ori[o].has_hand = (e >= 0) ? 1 : 0;
       ori[o].e = e;
       ori[o].last = last;
@@ -707,7 +688,10 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   const int cam_s = cam_source ? (cam_source[samples[s]] & 1) : 0;  // hands_cam_source(i) = pts_cam_source(indices[i])
   double wmin_w[2] = { 100000.0, 100000.0 }, wmax_w[2] = { -100000.0, -100000.0 };
   int nbox_w[2] = { 0, 0 }, numl_w[2] = { 0, 0 }, numr_w[2] = { 0, 0 };
-  double surf_w[2][3], bot_w[2][3];
+  double surf_w[2][3], horpos_w[2];
+  // max of y over ALL cropped points, for grasp_bottom (finger_hand.cpp:135): only an orientation with a hand needs it, so it
+  // is taken here, where such an orientation walks its points anyway, and not in pass A
+  double ymax_w[2] = { -INFINITY, -INFINITY };
   bool posx_w[2] = { false, false };
   for (int oo = 0; oo < 2; oo++)
   {
@@ -718,10 +702,10 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     for (int i = 0; i < 3; i++)
     {
       surf_w[oo][i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;  // rotating_hand.cpp:118-121
-      bot_w[oo][i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymax) + O.T[i][2] * 0.0;
       s2c[i] = (surf_w[oo][i] + F.sample[i]) - G.cam_origin[cam_s][i];  // learning.cpp:382-383
     }
     posx_w[oo] = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
+    horpos_w[oo] = hor_pos;
   }
   if (any_hand)
   {
@@ -762,7 +746,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
         const double bite = G.init_bite;
         const double sfx = surf_w[oo][0], sfy = surf_w[oo][1];
         const bool pos_x = posx_w[oo];
-        double wmin = wmin_w[oo], wmax = wmax_w[oo];
+        double wmin = wmin_w[oo], wmax = wmax_w[oo], ymax = ymax_w[oo];
         int nbox = 0, numl = 0, numr = 0;
         for (int t0 = lane; t0 < nc; t0 += 256)
         {
@@ -779,6 +763,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
             const double2 p = pts[act[u] ? t : 0];
             xr[u] = cs * p.x + ms * p.y;
             yr[u] = sn * p.x + cs * p.y;
+            ymax = max_f64_raw(ymax, yr[u]);  // (an inactive lane holds point 0 once more: idempotent)
           }
           int bit[4];
           bool inbox[4];
@@ -823,6 +808,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
         }
         wmin_w[oo] = wmin;
         wmax_w[oo] = wmax;
+        ymax_w[oo] = ymax;
         nbox_w[oo] += nbox;
         numl_w[oo] += numl;
         numr_w[oo] += numr;
@@ -850,14 +836,14 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
     memset(&h, 0, sizeof(h));
     h.sample = s;
     h.orientation = o;
-    const double wmin = wave_min_f64(wmin_w[oo]), wmax = wave_max_f64(wmax_w[oo]);
+    const double wmin = wave_min_f64(wmin_w[oo]), wmax = wave_max_f64(wmax_w[oo]), ymax = wave_max_f64(ymax_w[oo]);
     const int nbox = wave_sum_i32(nbox_w[oo]), numl = wave_sum_i32(numl_w[oo]), numr = wave_sum_i32(numr_w[oo]);
     for (int i = 0; i < 3; i++)
     {
       h.axis[i] = F.axis[i];
       h.approach[i] = O.approach[i];
       h.binormal[i] = O.binormal[i];
-      h.bottom[i] = bot_w[oo][i] + F.sample[i];  // rotating_hand.cpp:153-154
+      h.bottom[i] = ((O.T[i][0] * horpos_w[oo] + O.T[i][1] * ymax) + O.T[i][2] * 0.0) + F.sample[i];  // rotating_hand.cpp:120-122,153-154
       h.surface[i] = surf_w[oo][i] + F.sample[i];
     }
     h.width = wmax - wmin;
