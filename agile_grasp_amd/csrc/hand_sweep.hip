@@ -21,6 +21,7 @@
 #include "agh_internal.h"
 
 #include <cstddef>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -121,6 +122,34 @@ __device__ __forceinline__ int wave_sum_i32(int v)
   return wave_allsum_i32(v);  // (v_permlane swaps and DPP moves, no ds_bpermute)
 }
 
+// Minima of EIGHT doubles per lane over the wave in one transposed butterfly: at the strides 32, 16 and 8 a lane hands on the
+// half of its values its partner keeps and keeps the other half (v_permlane32_swap / v_permlane16_swap exchange the two halves
+// in place, row_ror:8 inside a row), strides 4, 2, 1 finish the one value left.  Lane l ends with the minimum of value
+// (l >> 3) & 7 -- 36 instructions, where eight separate wave reductions are 8 x 20.
+__device__ __forceinline__ double swap_min32(double a, double b)  // lanes < 32: min over (l, l + 32) of a; lanes >= 32: of b
+{
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return min_f64_raw(__hiloint2double((int) hi[0], (int) lo[0]), __hiloint2double((int) hi[1], (int) lo[1]));
+}
+__device__ __forceinline__ double swap_min16(double a, double b)  // even rows: min over (l, l + 16) of a; odd rows: of b
+{
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return min_f64_raw(__hiloint2double((int) hi[0], (int) lo[0]), __hiloint2double((int) hi[1], (int) lo[1]));
+}
+__device__ __forceinline__ double wave_min8_f64(const double (&m)[8], int lane)
+{
+  const double v0 = swap_min32(m[0], m[4]), v1 = swap_min32(m[1], m[5]), v2 = swap_min32(m[2], m[6]), v3 = swap_min32(m[3], m[7]);
+  const double w0 = swap_min16(v0, v2), w1 = swap_min16(v1, v3);  // value (j) + 2 (l >> 4 & 1) + 4 (l >> 5)
+  const bool up = (lane & 8) != 0;
+  double x = min_f64_raw(up ? w1 : w0, xor_partner_f64<8>(up ? w0 : w1));
+  x = min_f64_raw(x, xor_partner_f64<4>(x));
+  x = min_f64_raw(x, xor_partner_f64<2>(x));
+  x = min_f64_raw(x, xor_partner_f64<1>(x));
+  return x;
+}
+
 // Cropped points staged in LDS at a time: 2176 x double2 (34 KiB) for the online path, 1728 x (double2 + point id)
 // (34 KiB) when per-point normals are needed for the antipodal test -- both leave room for 3 blocks per CU.
 
@@ -134,7 +163,13 @@ __device__ __forceinline__ unsigned lowmask(int n)
 // MODE: 0 = occupancy sweep only; 1 = with the antipodal counts (cloud normals); 2 = mode 1 plus one image per camera
 // for the training instances createInstance(h, cam_pos, cam = 0 / 1) (learning.cpp:389-397).
 template <int MODE, int PX, int PY>
-__global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
+#ifndef AGH_SWEEP_WGS
+#define AGH_SWEEP_WGS 3
+#endif
+#ifndef AGH_SWEEP_TILE
+#define AGH_SWEEP_TILE 2176
+#endif
+__global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
@@ -144,7 +179,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
   constexpr bool NORMALS = MODE != 0, TRAIN = MODE == 2;
   constexpr int kImgPlanes = TRAIN ? 16 : 8;  // TRAIN: plane o = camera 0's points, plane 8 + o = camera 1's
   // the block must stay under a third of the CU's 160 KiB (512-B granules)
-  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : 2176);
+  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : AGH_SWEEP_TILE);
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
@@ -443,16 +478,9 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
         if ((live >> o) & 1u)  // (uniform)
           m[o] = min_f64_raw(m[o], geom_p->sin_a[o] * p.x + geom_p->cos_a[o] * p.y);  // row y of rot * points_ (rotating_hand.cpp:91)
     }
-    double mine = INFINITY;
-#pragma unroll
-    for (int o = 0; o < 8; o++)
-      if ((live >> o) & 1u)
-      {
-        const double v = wave_min_f64(m[o]);
-        mine = lane == o ? v : mine;
-      }
-    if (lane < 8)
-      ypart[wave][lane] = mine;
+    const double mine = wave_min8_f64(m, lane);  // lane l: orientation l >> 3 (+inf for one that is out)
+    if ((lane & 7) == 0)
+      ypart[wave][lane >> 3] = mine;
     __syncthreads();
     bool out = false;
     if (lane < 8)
@@ -480,24 +508,33 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
 #pragma unroll
       for (int u = 0; u < 4; u++)
         pn[u] = pts[(tid + 256 * u) < nc ? tid + 256 * u : 0];
-      for (int b0 = 0; b0 < nc; b0 += 1024)
-      {
-        double xr[4], yr[4];
+      // one pass over U x 256 points, U points per lane; the tile's last pass takes the U that covers what is left (a pass of
+      // four for 1.1 k points classified 2 k)
+      auto pass = [&](auto Uc, int b0) {
+        constexpr int U = decltype(Uc)::value;
+        double xr[U], yr[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < U; u++)
         {
           const double2 p = pn[u];
-          const int tn = b0 + 1024 + 256 * u + tid;
-          pn[u] = pts[tn < nc ? tn : 0];
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
           yr[u] = sn * p.x + cs * p.y;
+        }
+        if (U == 4 && b0 + 1024 < nc)
+        {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+          {
+            const int tn = b0 + 1024 + 256 * u + tid;
+            pn[u] = pts[tn < nc ? tn : 0];
+          }
         }
         // (a lane past the end of the tile holds point 0 once more: the table bits are idempotent, so nothing below needs
         // to know -- no selects, no predicate besides the depth test)
         // depth class yk = #{k : d_k <= y} and region rank c = #{k : thr_k < x} by cell look-up + exact probes
-        int ly[4], lx[4];
+        int ly[U], lx[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < U; u++)
         {
           // v_cvt_i32_f64 truncates and saturates (NaN -> 0), so the clamp can follow the conversion as one integer med3
           const int cy = min(max(cvt_i32_f64_sat((yr[u] - ylo) * ysc), 0), 63);
@@ -505,9 +542,9 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
           ly[u] = G.ylut[cy];
           lx[u] = G.xlut[cx];
         }
-        double dv[4][PY], tv[4][PX];
+        double dv[U][PY], tv[U][PX];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < U; u++)
         {
 #pragma unroll
           for (int j = 0; j < PY; j++)
@@ -517,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
             tv[u][j] = thr_s[lx[u] + j];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < U; u++)
         {
           int yk = ly[u];
 #pragma unroll
@@ -534,6 +571,18 @@ __global__ __launch_bounds__(256, 3) void k_hand_sweep(GridView gv, const HandGe
           if ((yk < K) AGH_DBG_AND(debug_stop != 11 && debug_stop != 10))
             atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + yk));
         }
+      };
+      for (int b0 = 0; b0 < nc; b0 += 1024)
+      {
+        const int left = nc - b0;
+        if (left > 768)
+          pass(std::integral_constant<int, 4>{}, b0);
+        else if (left > 512)
+          pass(std::integral_constant<int, 3>{}, b0);
+        else if (left > 256)
+          pass(std::integral_constant<int, 2>{}, b0);
+        else
+          pass(std::integral_constant<int, 1>{}, b0);
       }
     }
   };
