@@ -216,11 +216,12 @@ public:
     for (std::size_t i = 0; i < hand_list.size(); i++)
     {
       const Vector3d& center = hand_list[i].getGraspSurface();
-      std::size_t k;
-      for (k = 0; k < workspace_.size(); k++)
+      const int n_ws = (int) workspace_.size();  // (Eigen::Index is signed, the stand-in's size() is not)
+      int k;
+      for (k = 0; k < n_ws; k++)
         if (std::fabs(center((int) std::floor(k / 2.0)) - workspace_(k)) < MIN_DIST)
           break;
-      if (k == workspace_.size())
+      if (k == n_ws)
         filtered.push_back(hand_list[i]);
     }
     return filtered;

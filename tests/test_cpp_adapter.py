@@ -600,3 +600,31 @@ def test_pcd_reader_rejects_hostile_headers(tmp_path, edit):
     out = subprocess.run([exe, "parse", path], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "LOAD_FAILED" in out.stdout
+
+
+@pytest.mark.parametrize("std", ["c++11", "c++17"])
+def test_real_type_branch_compiles_against_api_stubs(std):
+    """The branch of types.h a ROS build takes (real pcl::PointCloud / Eigen types) has no library to meet in this image.
+    It is compiled here -- syntax and types only -- against API-shape DECLARATIONS of the Eigen / PCL surface it touches
+    (tests/cpp/stubs, see the README there), together with a translation unit that restates the reference's call sites
+    (localization.cpp:111-113, 142-151; grasp_localizer.cpp:95-103, 137-146; learning.cpp:375-400).  This checks type
+    correctness against that surface (boost pointers, aligned-allocator vectors, signed Eigen::Index, fixed -> dynamic
+    matrix conversion); it says nothing about behaviour with the real libraries."""
+    cmd = ["g++", "-std=" + std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-DAGILE_GRASP_AMD_HAVE_PCL_EIGEN=1",
+           "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "real_types_tu.cpp")]
+    subprocess.check_call(cmd)
+
+
+def test_real_type_stubs_would_catch_a_std_shared_ptr_assumption(tmp_path):
+    """The stubs are only worth something if a wrong assumption fails against them: code that treats PointCloud::Ptr as a
+    std::shared_ptr (fine with the stand-ins, wrong with PCL 1.7) must NOT compile."""
+    src = tmp_path / "bad.cpp"
+    src.write_text("#include <memory>\n#include <agile_grasp_amd/hand_search.h>\n"
+                   "void f() { agile_grasp_amd::PointCloud::Ptr p = std::make_shared<agile_grasp_amd::PointCloud>(); (void) p; }\n")
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-DAGILE_GRASP_AMD_HAVE_PCL_EIGEN=1",
+           "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-I" + os.path.join(ROOT, "include"), str(src)]
+    assert subprocess.run(cmd, capture_output=True).returncode != 0
+    # ... and the same line is fine on the stand-in branch (which is why only the stubs can catch it)
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)]
+    assert subprocess.run(cmd, capture_output=True).returncode == 0

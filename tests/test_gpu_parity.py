@@ -391,12 +391,13 @@ def test_full_size_c2_against_oracle(svm_model):
     assert len(hyps) > 300
 
 
-@pytest.mark.parametrize("name", ["C1", "C4", "C5_0"])
+@pytest.mark.parametrize("name", ["C1", "C4", "C5_0", "C2u"])
 def test_full_size_other_configs_against_oracle(svm_model, name):
     """The BASELINE configs besides C2/C3, whole result list (frames, hypotheses, SVM labels) bit-identical to the oracle:
     C1 (single view, 50k points, 500 samples: every point from camera 0), C4 (1M points, 8000 samples: multi-tile sweeps
     with the parked-points path, the 4096-point moments class, the large scheduling sort), C5_0 (first cloud of the
-    batch, seed 10)."""
+    batch, seed 10), C2u (SURVEY 8d's generator taken literally: the axis-aligned C2 scene, two thirds of whose Taubin
+    neighbourhoods are exactly planar -- the exhaustive argmax of quadric.cpp:283-284, deterministic normals)."""
     from agile_grasp_amd import synthetic
     from oracle import oracle_py as O
 
