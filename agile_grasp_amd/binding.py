@@ -149,6 +149,7 @@ def save_svm_file(path: str, w: np.ndarray, rho: float, kernel: int = SVM_LINEAR
         raise AghError(rc, f"cannot write {path}")
 
 
+AGH_ERR_INVALID_ARGUMENT, AGH_ERR_HIP, AGH_ERR_CAPACITY, AGH_ERR_NO_CLOUD, AGH_ERR_NO_SVM, AGH_ERR_STATE = -1, -3, -4, -5, -6, -8
 AGH_ERR_RETRY = -9  # the context adapted its configuration to the input (include/agh.h): repeat the call
 
 
@@ -457,9 +458,9 @@ class Context:
         self._check(self.lib.agh_comm_last_exchange(self._h, C.byref(b), C.byref(n), C.byref(v)))
         return b.value, n.value, bool(v.value)
 
-    def find_hands_sharded(self, samples: np.ndarray, calculates_antipodal: bool = False) -> np.ndarray:
+    def find_hands_sharded(self, samples: np.ndarray, calculates_antipodal: bool = False, cap: int | None = None) -> np.ndarray:
         samples = np.ascontiguousarray(samples, np.int32)
-        cap = max(8 * samples.shape[0], 1)
+        cap = max(8 * samples.shape[0], 1) if cap is None else cap
         out = np.zeros(cap, HYP_DTYPE)
         n = C.c_int64(0)
         self._check(self.lib.agh_find_hands_sharded(self._h, _p(samples, C.c_int32), C.c_int64(samples.shape[0]),

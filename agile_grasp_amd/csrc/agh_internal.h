@@ -132,6 +132,9 @@ struct Ctx
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t copy_done = nullptr;
+  hipEvent_t copy_gate = nullptr;   // recorded on the build's stream before its kernels: the camera-id copy waits for earlier work only
+  hipEvent_t xyz_copied = nullptr;  // host-buffer agh_set_cloud from PINNED memory: recorded behind the coordinates' copy
+  bool cam_copy_on_copy_stream = false;  // the last grid_build put the camera ids on copy_stream (copy_done was recorded)
   hipStream_t copy_stream = nullptr;  // host-buffer agh_set_cloud: the camera ids go up here while the grid build's first kernels run
   std::string err;
 
@@ -289,6 +292,8 @@ struct Ctx
   double* d_nbuf = nullptr;       // n_ranks segments of per-sample normals (antipodal mode), all-gathered in place
   int64_t nbuf_doubles = 0;
   int64_t* d_xcnt = nullptr;      // n_ranks RAND50 draw counts + scratch
+  bool shard_symmetric_error = false;  // the last sharded device call failed on something every rank saw alike, after the ranks
+                                       // had met in a collective: nobody is left waiting, the communicator stays usable
   int64_t shard_seg_override = 0;    // agh_comm_set_segment_records
   bool shard_full_exchange = false;  // exchange all 8 slots per sample instead of the 2-per-sample prefix
   int64_t shard_seg_records = 0, shard_seg_bytes = 0, shard_S = 0;
@@ -316,10 +321,25 @@ struct Ctx
 // is another stream, wait for the build first (streams the caller brings may be non-blocking ones)
 inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
 {
-  if (!c->cloud_async)
-    return hipSuccess;
+  if (!c->cloud_async || st == c->stream)
+    return hipSuccess;  // (in order behind the build on the context's own stream: the flag stays up for a LATER search on another
+                        // stream, which is not -- ADVICE r4)
   c->cloud_async = false;
-  return st == c->stream ? hipSuccess : hipStreamSynchronize(c->stream);
+  return hipStreamSynchronize(c->stream);
+}
+
+// Bits of d_flags[0]: 1 = a Taubin neighbourhood beyond the capacity classes this context launched, 2 = output buffer too small,
+// 4 = a sample index outside the cloud, 16 = a rank's exchange segment overflowed (sharded search).  The sharded search decides
+// on what EVERY rank reported, never on a rank's own state -- two ranks that disagreed would part ways before the next collective,
+// and raw RCCL has no watchdog -- so a rank's findings travel in word 1 of its segment header and the merge kernel turns the
+// gathered headers into three more bits, identical on every rank: kFlagShardRetry (some rank that had NOT launched the larger
+// classes needs them), kFlagShardHard (some rank that had launched them still overflowed), kFlagSharded (a merge ran: the
+// decision comes from these bits, the rank's own bit 0 is ignored).
+constexpr int kFlagShardRetry = 32, kFlagShardHard = 64, kFlagSharded = 128;
+// word 1 of a segment header: 1 = overflow with the larger classes off, 8 = overflow with them on, 4 = bad sample index
+__host__ __device__ inline int shard_header_word(int flags0, int big_classes_on)
+{
+  return ((flags0 & 1) ? (big_classes_on ? 8 : 1) : 0) | (flags0 & 4);
 }
 
 // ---- kernel launchers (defined in the .hip files) ----

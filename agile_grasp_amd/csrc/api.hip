@@ -533,6 +533,10 @@ void agh_destroy(agh_ctx* ctx)
     (void) hipEventDestroy(e);
   if (c->copy_done)
     (void) hipEventDestroy(c->copy_done);
+  if (c->copy_gate)
+    (void) hipEventDestroy(c->copy_gate);
+  if (c->xyz_copied)
+    (void) hipEventDestroy(c->xyz_copied);
   if (c->copy_stream)
     (void) hipStreamDestroy(c->copy_stream);
   if (c->stream)
@@ -640,6 +644,21 @@ int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const in
   return agh_set_cloud_batch(ctx, xyz, stride_bytes, cam_source, offsets, 1);
 }
 
+// Page-locked host memory (hipHostMalloc / hipHostRegister)?  A copy from it is truly asynchronous: it returns before the
+// source has been read, where a pageable copy returns after.
+static bool is_pinned_host(const void* p)
+{
+  if (!p)
+    return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess)
+  {
+    (void) hipGetLastError();  // (an unregistered pointer is an error on older runtimes, hipMemoryTypeUnregistered on newer ones)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
 int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, const int64_t* offsets,
   int32_t n_clouds)
 {
@@ -673,6 +692,11 @@ int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, co
     c->own_cap_floats = std::max<int64_t>(need, c->own_cap_floats);
     c->own_cap = std::max<int64_t>(n, c->own_cap);
   }
+  // "The caller may overwrite xyz and cam_source as soon as the call returns" (agh.h) holds by itself for pageable sources (the
+  // copy calls return when the source has been read); for PINNED sources the copies are waited for below -- the copies only,
+  // the grid build stays queued (a frame buffer reused at once corrupted the upload silently).
+  const bool xyz_pinned = n > 0 && is_pinned_host(xyz), cam_pinned = n > 0 && is_pinned_host(cam_source);
+  c->cam_copy_on_copy_stream = false;
   if (n > 0)
   {
     if (as_is)
@@ -681,6 +705,12 @@ int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, co
     else
       HIPCHK(c, hipMemcpy2DAsync(c->own_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice,
                   c->stream));
+    if (xyz_pinned)
+    {
+      if (!c->xyz_copied)
+        HIPCHK(c, hipEventCreateWithFlags(&c->xyz_copied, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->xyz_copied, c->stream));
+    }
     if (cam_source)  // (uploaded by grid_build, overlapped with its coordinate-only kernels)
     {
       c->pending_cam_host = cam_source;
@@ -698,6 +728,15 @@ int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, co
     c->pending_cam_host = nullptr;
     if (rc == AGH_OK)
       HIPCHK(c, hipMemcpyAsync(c->own_cam, cam_source, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  }
+  if (xyz_pinned)
+    HIPCHK(c, hipEventSynchronize(c->xyz_copied));
+  if (cam_pinned)
+  {
+    if (c->cam_copy_on_copy_stream)
+      HIPCHK(c, hipEventSynchronize(c->copy_done));
+    else  // the ids went up on the context's stream (no copy stream, or the fallback above): behind the build's kernels
+      HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->cloud_async = rc == AGH_OK;
   return rc;
@@ -1111,8 +1150,28 @@ static int check_flags(Ctx* c, hipStream_t st)
   return flags_to_status(c, flags);
 }
 
-static int flags_to_status(Ctx* c, const int32_t* flags)
+static int flags_to_status(Ctx* c, const int32_t* flags_in)
 {
+  // after a sharded search the capacity decision comes from the gathered segment headers (the same on every rank of the
+  // communicator), not from this rank's own bit 0 and big_classes: agh_internal.h, kFlagShard*
+  int32_t flags[1] = { flags_in[0] };
+  if (flags[0] & kFlagSharded)
+  {
+    flags[0] &= ~1;
+    if (flags[0] & kFlagShardHard)
+    {
+      c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
+               "voxelise the cloud (localization.cpp:43) or reduce the radii";
+      return AGH_ERR_CAPACITY;
+    }
+    if (flags[0] & kFlagShardRetry)
+    {
+      c->big_classes = true;
+      c->err = "a Taubin neighbourhood exceeds the first capacity class; the contexts of the communicator now launch the "
+               "larger classes as well: repeat the call";
+      return AGH_ERR_RETRY;
+    }
+  }
   if ((flags[0] & 1) && !c->big_classes)
   {
     // the launches of the larger capacity classes are skipped until a cloud needs them (~5 us each, and class membership

@@ -355,6 +355,24 @@ int grid_build(Ctx* c, hipStream_t st)
     hipMemsetAsync(c->d_tile_state, 0, sizeof(unsigned long long) * (size_t) (kCellCap / kScanBlock) * c->clouds_cap, st);
     c->build_gen = 1;
   }
+  // host-buffer agh_set_cloud: the camera ids go up on a stream of their own beside the coordinate-only kernels below.  That
+  // stream must not write own_cam while work queued EARLIER on `st` (the previous build's k_scatter, a search) still reads it:
+  // with a pinned source nothing else orders the two (a pageable copy happened to, by blocking).  The gate is recorded here,
+  // before this build's kernels, so the copy waits for the earlier work only.
+  bool cam_gate = false;
+  if (c->pending_cam_host)
+  {
+    if (!c->copy_stream && (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->copy_gate, hipEventDisableTiming) != hipSuccess))
+    {
+      if (c->copy_stream)
+        (void) hipStreamDestroy(c->copy_stream);
+      c->copy_stream = nullptr;
+    }
+    if (c->copy_stream)
+      cam_gate = hipEventRecord(c->copy_gate, st) == hipSuccess && hipStreamWaitEvent(c->copy_stream, c->copy_gate, 0) == hipSuccess;
+  }
   // cell >= r_hands/4 keeps a ball query within 9 x 9 rows
   const double base_cell = std::max(0.02, c->p.nn_radius_hands / 4.0);
   const int nparts = std::max(1, std::min(nblk, kBboxBlocks));
@@ -372,17 +390,11 @@ int grid_build(Ctx* c, hipStream_t st)
     // kernels.  A pageable copy returns when the SOURCE has been read (into the runtime's staging buffers), not necessarily
     // when the data is on the device, so k_scatter waits for an event behind the copy; the coordinates' copy, which was
     // ordered behind everything earlier on the context's stream, has already returned when this one is issued.
-    if (!c->copy_stream && (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess))
-    {
-      if (c->copy_stream)
-        (void) hipStreamDestroy(c->copy_stream);
-      c->copy_stream = nullptr;
-    }
-    hipStream_t cs = c->copy_stream ? c->copy_stream : st;
+    hipStream_t cs = (c->copy_stream && cam_gate) ? c->copy_stream : st;  // (no gate: in order on `st`, behind the kernels above)
     hipError_t e = hipMemcpyAsync(c->own_cam, c->pending_cam_host, sizeof(int32_t) * (size_t) c->pending_cam_n,
       hipMemcpyHostToDevice, cs);
     c->pending_cam_host = nullptr;
+    c->cam_copy_on_copy_stream = cs != st;
     if (e == hipSuccess && cs != st)
     {
       e = hipEventRecord(c->copy_done, cs);

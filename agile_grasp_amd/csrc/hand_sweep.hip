@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void k_compact_sums(const uint8_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sums, int nb, int64_t* __restrict__ n_out,
-  const int32_t* __restrict__ flags_in, HostMirror mir)
+  const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out, int hdr_big, HostMirror mir)
 {
   // nb <= 4096: serial chunks of 256 with a wave scan
   __shared__ int ws[4];
@@ -1001,6 +1001,8 @@ __global__ __launch_bounds__(256) void k_compact_top(int* __restrict__ block_sum
   if (threadIdx.x == 0)
   {
     *n_out = carry;
+    if (hdr_flags_out)  // sharded search: see k_compact_offsets
+      *hdr_flags_out = shard_header_word(flags_in[0], hdr_big);
     if (mir.hdr)
     {
       mir.hdr[0] = carry;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const agh_hypothesis* __r
 // one work-group scans the S popcounts (output offset of every sample, total count), then 10 threads copy each record
 // (16 bytes per thread, coalesced).
 __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restrict__ vmask, int S, int* __restrict__ offs,
-  int64_t* __restrict__ n_out, const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out, HostMirror mir)
+  int64_t* __restrict__ n_out, const int32_t* __restrict__ flags_in, int64_t* __restrict__ hdr_flags_out, int hdr_big, HostMirror mir)
 {
   // thread t owns the samples [t per, (t + 1) per), per a multiple of 16: its masks arrive as 16-byte loads, all in flight
   // together (one byte per load and iteration made this kernel 15 us for the 16 000 samples of a batch; the buffer is
@@ -1104,8 +1106,8 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint8_t* __restr
   if (tid == 0)
   {
     *n_out = total;
-    if (hdr_flags_out)  // sharded search: this rank's "a neighbourhood beyond the launched capacity classes" travels in its
-      *hdr_flags_out = flags_in[0] & 1;  // segment header, so that every rank learns it from the same all-gather
+    if (hdr_flags_out)  // sharded search: this rank's findings (capacity class, bad index) travel in its segment header, so
+      *hdr_flags_out = shard_header_word(flags_in[0], hdr_big);  // that every rank learns them from the same all-gather
     if (mir.hdr)
     {
       mir.hdr[0] = total;
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_compact_copy(const agh_hypothesis* __re
 __global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __restrict__ slots,
   const uint8_t* __restrict__ vmask, int S, int n_slots, agh_hypothesis* __restrict__ out, int64_t cap,
   int32_t* __restrict__ slot_of_hyp, int32_t* __restrict__ flags, int32_t epoch, int64_t* __restrict__ n_out,
-  int64_t* __restrict__ hdr_flags_out, HostMirror mir)
+  int64_t* __restrict__ hdr_flags_out, int hdr_big, HostMirror mir)
 {
   __shared__ int wsum[2][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1209,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_compact_fused(const agh_hypothesis* __r
   {
     *n_out = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
     if (hdr_flags_out)  // sharded search: see k_compact_offsets
-      *hdr_flags_out = flags[0] & 1;
+      *hdr_flags_out = shard_header_word(flags[0], hdr_big);
     if (mir.hdr)  // (bit 1 of the word, "list longer than cap", may still be raised by other work-groups of this launch:
     {             // the host derives it from the count)
       mir.hdr[0] = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
@@ -1375,18 +1377,20 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
   const HostMirror mir = c->mirror;
   if (S <= 4096)
     hipLaunchKernelGGL(k_compact_fused, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
-      (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags, mir);
+      (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags,
+      c->big_classes ? 1 : 0, mir);
   else if (S <= 65536)
   {
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
-      d_nout, (const int32_t*) c->d_flags, d_hdr_flags, mir);
+      d_nout, (const int32_t*) c->d_flags, d_hdr_flags, c->big_classes ? 1 : 0, mir);
     hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
       (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, mir);
   }
   else
   {
     hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp);
-    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout, (const int32_t*) c->d_flags, mir);
+    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout, (const int32_t*) c->d_flags, d_hdr_flags,
+      c->big_classes ? 1 : 0, mir);
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp, d_out, cap,
       c->d_slot_index, c->d_flags, c->epoch, mir);
   }

@@ -40,6 +40,7 @@ static constexpr ncclResult_t ncclSuccess = 0;
 static constexpr ncclDataType_t ncclChar = 0;
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -119,6 +120,7 @@ Rccl* rccl()
 }
 
 // n contexts of one process exchanging through device copies (agh_comm_init_local)
+constexpr int kLocalBarrierTimeoutS = 120;
 struct LocalGroup
 {
   int n = 0;
@@ -141,8 +143,13 @@ struct LocalGroup
       generation++;
       cv.notify_all();
     }
-    else
-      cv.wait(lk, [&] { return generation != g || failed; });
+    else if (!cv.wait_for(lk, std::chrono::seconds(kLocalBarrierTimeoutS), [&] { return generation != g || failed; }))
+    {
+      // a rank never came (it returned before the collective on an error its peers did not share -- a broken precondition,
+      // e.g. no cloud on one rank): fail every waiter instead of hanging the process; the group is unusable afterwards
+      failed = true;
+      cv.notify_all();
+    }
     return !failed;
   }
   void abort()
@@ -231,11 +238,11 @@ __host__ __device__ inline int64_t shard_lo(int64_t n, int64_t r, int64_t G)
   return (n * r) / G;
 }
 
-// header of an empty slice: no hypotheses, and the capacity-class flag (bit 0 of flags[0]) as k_compact_* would write it
-__global__ void k_shard_empty_header(int64_t* __restrict__ hdr, const int32_t* __restrict__ flags)
+// header of an empty slice: no hypotheses, and the rank's findings (shard_header_word) as k_compact_* would write them
+__global__ void k_shard_empty_header(int64_t* __restrict__ hdr, const int32_t* __restrict__ flags, int big)
 {
   hdr[0] = 0;
-  hdr[1] = flags[0] & 1;
+  hdr[1] = shard_header_word(flags[0], big);
 }
 
 // RAND50: draws my slice consumes (50 per neighbourhood of more than 50 points, quadric.cpp:177-193)
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
     for (int q = 0; q < G; q++)
     {
       int64_t cnt = *reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes);
-      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 1);
+      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 13);  // shard_header_word
       if (cnt > seg_records)
       {
         ov = 1;
@@ -323,8 +330,8 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
       *n_out = o;
       if (ov)
         atomicOr(&flags[0], 16);
-      if (need)  // some rank met a neighbourhood beyond the capacity classes it launched: every rank reports it
-        atomicOr(&flags[0], 1);
+      // what the ranks found, the same word on every rank (agh_internal.h: kFlagShard*)
+      atomicOr(&flags[0], kFlagSharded | ((need & 1) ? kFlagShardRetry : 0) | ((need & 8) ? kFlagShardHard : 0) | (need & 4));
       if (o > cap)
         atomicOr(&flags[0], 2);
     }
@@ -423,6 +430,33 @@ int agh_comm_unique_id(uint8_t id[AGH_COMM_ID_BYTES])
   return AGH_OK;
 }
 
+// What every rank of a communicator must agree on: the parameters that decide WHICH collectives a call issues
+// (normals_mode: the RAND50 draw-count exchange) and what the shared result means (geometry, radii, camera origins, seed).
+// device and profile are per rank.  FNV-1a over the fields' bytes.
+static uint64_t params_fingerprint(const agh_params& p)
+{
+  uint64_t h = 1469598103934665603ull;
+  auto eat = [&](const void* v, size_t n) {
+    const unsigned char* b = (const unsigned char*) v;
+    for (size_t i = 0; i < n; i++)
+      h = (h ^ b[i]) * 1099511628211ull;
+  };
+  eat(&p.finger_width, sizeof(double));
+  eat(&p.hand_outer_diameter, sizeof(double));
+  eat(&p.hand_depth, sizeof(double));
+  eat(&p.hand_height, sizeof(double));
+  eat(&p.init_bite, sizeof(double));
+  eat(&p.nn_radius_taubin, sizeof(double));
+  eat(&p.nn_radius_hands, sizeof(double));
+  eat(&p.nn_radius_normals, sizeof(double));
+  eat(&p.cam_origin[0][0], sizeof(double) * 6);
+  eat(&p.normals_mode, sizeof(p.normals_mode));
+  eat(&p.rand_seed, sizeof(p.rand_seed));
+  return h;
+}
+static const char* kParamsDiffer = "the contexts of a communicator must be created with the same agh_params (hand geometry, radii, "
+                                   "camera origins, normals_mode, rand_seed): ranks that disagree issue different collectives";
+
 int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[AGH_COMM_ID_BYTES])
 {
   if (!ctx || !id)
@@ -458,6 +492,39 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
   c->comm->rank = rank;
   c->comm->n_ranks = n_ranks;
   c->comm->nccl = comm;
+  // the first collective of the communicator: every rank's parameter fingerprint (every rank calls agh_comm_init, so nobody
+  // waits alone; all ranks see the same words and accept or refuse together)
+  {
+    int rc = AGH_OK;
+    if (!c->d_xcnt)
+    {
+      int64_t have = 0;
+      rc = grow(c, &c->d_xcnt, &have, 128);
+    }
+    uint64_t mine = params_fingerprint(c->p), all[64];
+    if (rc == AGH_OK && hipMemcpyAsync(c->d_xcnt + 64 + rank, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      rc = AGH_ERR_HIP;
+    if (rc == AGH_OK)
+      rc = all_gather(c, c->d_xcnt + 64, sizeof(int64_t), c->stream);
+    if (rc == AGH_OK && (hipMemcpyAsync(all, c->d_xcnt + 64, sizeof(uint64_t) * (size_t) n_ranks, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipStreamSynchronize(c->stream) != hipSuccess))
+      rc = AGH_ERR_HIP;
+    if (rc == AGH_OK)
+      for (int q = 0; q < n_ranks; q++)
+        if (all[q] != all[0])
+        {
+          c->err = kParamsDiffer;
+          rc = AGH_ERR_INVALID_ARGUMENT;
+          break;
+        }
+    if (rc != AGH_OK)
+    {
+      if (rc == AGH_ERR_HIP)
+        c->err = "agh_comm_init: the parameter check (first all-gather of the communicator) failed";
+      comm_release(c);
+      return rc;
+    }
+  }
   return AGH_OK;
 }
 
@@ -468,6 +535,13 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
   for (int q = 0; q < n_ranks; q++)
     if (!ctxs[q] || ctxs[q]->c.comm)
       return AGH_ERR_STATE;
+  for (int q = 1; q < n_ranks; q++)
+    if (params_fingerprint(ctxs[q]->c.p) != params_fingerprint(ctxs[0]->c.p))
+    {
+      for (int k = 0; k < n_ranks; k++)
+        ctxs[k]->c.err = kParamsDiffer;
+      return AGH_ERR_INVALID_ARGUMENT;
+    }
   std::shared_ptr<LocalGroup> g(new LocalGroup());
   g->n = n_ranks;
   g->send.assign((size_t) n_ranks, nullptr);
@@ -592,6 +666,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
     return AGH_ERR_STATE;
   }
   *entered = true;  // from here on a failure is this rank's own
+  c->shard_symmetric_error = false;
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   HIPCHK(c, order_after_cloud(c, st));
@@ -656,6 +731,28 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   const int32_t* my_idx = d_sample_idx + lo;
   if (calculates_antipodal)
   {
+    if (G > 1)
+    {
+      // The all-points pass is sharded by POINT range, so every rank must hold the same cloud here -- unlike the plain search,
+      // where a cloud per rank is a supported mode.  A rank cannot see another rank's cloud: with different point counts the
+      // byte counts of the normals' all-gather below would differ from rank to rank (a hang or silent garbage under RCCL).
+      // The counts are exchanged first (8 bytes per rank, an offline pass) and every rank refuses alike.
+      int64_t mine = c->n, all[64];
+      HIPCHK(c, hipMemcpyAsync(c->d_xcnt + 64 + r, &mine, sizeof(int64_t), hipMemcpyHostToDevice, st));
+      if ((rc = all_gather(c, c->d_xcnt + 64, sizeof(int64_t), st)) != AGH_OK)
+        return rc;
+      HIPCHK(c, hipMemcpyAsync(all, c->d_xcnt + 64, sizeof(int64_t) * (size_t) G, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+      for (int q = 0; q < G; q++)
+        if (all[q] != all[0])
+        {
+          c->err = "agh_find_hands_sharded: calculates_antipodal shards the all-points pass by point range and needs the SAME "
+                   "cloud on every rank (the ranks hold clouds of different sizes)";
+          *entered = false;  // (every rank saw the same counts and returns here: nobody is left in a collective)
+          c->shard_symmetric_error = true;
+          return AGH_ERR_STATE;
+        }
+    }
     // hand_search.cpp:13-26 sharded by point range; the buffer is padded to G equal ranges for the in-place all-gather
     if ((int64_t) G * pcnt > c->normals_cap || !c->d_normals)  // (normals_cap counts points)
     {
@@ -722,8 +819,6 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
       c->err = "hand sweep launch failed";
       return rc;
     }
-    if (Sr > 65536)  // (the compaction for long lists does not write the header flags: no speculation there, see below)
-      HIPCHK(c, hipMemsetAsync(my_count + 1, 0, sizeof(int64_t), st));
     // K4 straight into my segment of the exchange buffer; an overflow of the segment shows as count > seg_records
     if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st, my_count + 1)) != AGH_OK)
     {
@@ -734,7 +829,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   else  // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must
         // learn of a capacity-class retry from EVERY rank, or this one would repeat the collective alone)
   {
-    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags);
+    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags, c->big_classes ? 1 : 0);
     HIPCHK(c, hipGetLastError());
   }
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
@@ -790,18 +885,20 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
   HIPCHK(c, hipStreamSynchronize(st));
   if (flags[0] & 16)
     return 16;
-  if ((flags[0] & 1) && !c->big_classes)
+  // (every rank reads the same segment headers, so every rank takes the same branch here -- whatever its own big_classes was:
+  // a rank that had the larger classes on reports a hard overflow, one that had not asks for the retry, and a retry anybody
+  // asks for is taken by all)
+  if (flags[0] & kFlagShardHard)
   {
-    // (every rank reads the same segment headers, so every rank lands here and switches together)
+    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity";
+    return AGH_ERR_CAPACITY;
+  }
+  if (flags[0] & kFlagShardRetry)
+  {
     c->big_classes = true;
     c->err = "a Taubin neighbourhood exceeds the first capacity class; the contexts of the communicator now launch the "
              "larger classes as well: repeat the call";
     return AGH_ERR_RETRY;
-  }
-  if (flags[0] & 1)
-  {
-    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity";
-    return AGH_ERR_CAPACITY;
   }
   if (flags[0] & 2)
   {
@@ -857,18 +954,11 @@ static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx,
     return AGH_ERR_INVALID_ARGUMENT;
   }
   *entered = true;  // every rank passed the same checks on the same arguments: what fails from here on fails on this rank alone
-  {
-    // a rank reads only ITS slice of the list (when every rank searches a cloud of its own the other slices index other clouds):
-    // only that slice is checked, and a bad index in it is this rank's own failure
-    const int G = c->comm->n_ranks, r = c->comm->rank;
-    const int64_t lo = shard_lo(n_samples, r, G), hi = c->n == 0 ? lo : shard_lo(n_samples, r + 1, G);
-    for (int64_t i = lo; i < hi; i++)
-      if (sample_idx[i] < 0 || sample_idx[i] >= c->n)
-      {
-        c->err = "agh_find_hands_sharded: sample index out of range";
-        return AGH_ERR_INVALID_ARGUMENT;
-      }
-  }
+  // (The sample indices are NOT range-checked here.  A rank reads only its slice of the list -- when every rank searches a cloud
+  // of its own the other slices index other clouds -- so a host-side check could only ever fail on ONE rank, which would then
+  // leave before the collectives the others wait in.  The kernels validate every index they read
+  // (kStatusBadIndex), the finding travels in the rank's segment header, and every rank returns AGH_ERR_INVALID_ARGUMENT
+  // together after the exchange.)
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
   if (rc != AGH_OK)
@@ -893,13 +983,23 @@ static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx,
     if (rc != AGH_OK)
     {
       (void) hipStreamSynchronize(c->stream);
+      *entered = !c->shard_symmetric_error;
       return rc;
     }
     rc = shard_flags(c, c->stream, &n);
+    // The collectives of this attempt have completed on this rank, and what shard_flags reports (other than a HIP failure of its
+    // own) was derived from the gathered headers: the same on every rank.  Such errors -- a retry, a capacity limit, a bad
+    // index, a caller's buffer that is too small -- leave the communicator usable (a caller that came back with
+    // a larger buffer found the in-process communicator aborted).
+    *entered = rc == AGH_ERR_HIP;
     if (rc == AGH_ERR_RETRY)
+    {
+      *entered = true;  // (the next attempt's collectives)
       continue;  // the larger capacity classes are on now, on every rank
+    }
     if (rc != 16)
       break;
+    *entered = true;
     // a rank found more than its segment holds: every rank sees the same headers, so every rank repeats with 8 per sample
     c->shard_full_exchange = true;
     rc = AGH_ERR_RETRY;
@@ -971,6 +1071,7 @@ static int classify_sharded_host_impl(agh_ctx* ctx, agh_hypothesis* out, uint8_t
     return rc;
   int64_t n = 0;
   rc = shard_flags(c, c->stream, &n);
+  *entered = rc == AGH_ERR_HIP;  // (the collective is over; what is reported from here on is the same on every rank)
   if (rc != AGH_OK)
     return rc == 16 ? AGH_ERR_CAPACITY : rc;
   if (n > cap)

@@ -133,8 +133,10 @@ const char* agh_last_error(const agh_ctx* ctx); /* ctx may be NULL: error of the
  * cam_source: 0/1 per point (Eigen::VectorXi pts_cam_source), may be NULL (all 0).
  * The host variant returns when xyz and cam_source have been READ (the caller may free or overwrite them at once); the grid
  * build is then still queued on the context's stream, in front of whatever uses the cloud next -- a search on another stream
- * waits for it first -- and an asynchronous failure of the build surfaces at that call's synchronisation.  (Upload from pinned
- * memory, hipHostMalloc / hipHostRegister, if the caller can: a pageable upload is a blocking copy.) */
+ * waits for it first -- and an asynchronous failure of the build surfaces at that call's synchronisation.  That promise holds
+ * for pageable AND for page-locked sources (hipHostMalloc / hipHostRegister): a copy from page-locked memory is truly
+ * asynchronous, so the call then waits for the two copies (not for the build) before it returns.  Upload from page-locked
+ * memory if the caller can: a pageable upload goes through the runtime's staging buffers. */
 int agh_set_cloud(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* cam_source, int64_t n);
 int agh_set_cloud_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, const int32_t* d_cam_source,
   int64_t n, void* hip_stream);

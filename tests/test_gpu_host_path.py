@@ -136,3 +136,77 @@ def test_preprocess_then_everything_twice_with_growing_lattice(svm_model):
         fresh.close()
     assert results[0] == results[2]
     ctx.close()
+
+
+def test_set_cloud_from_page_locked_memory_may_be_overwritten_at_once(tiny_scene, small_scene):
+    """with a page-locked source (hipHostMalloc) the upload copies are truly asynchronous -- agh_set_cloud still
+    promises that xyz and cam_source may be reused as soon as it returns, so it must wait for the COPIES.  Two clouds alternate
+    through one pair of page-locked buffers that are scribbled over right after every call; the camera-id copy (a stream of its
+    own) must also not overtake the previous cloud's search."""
+    import torch
+
+    from agile_grasp_amd import binding
+
+    scenes = [small_scene, tiny_scene]
+    refs = [_reference(sc, sc.samples, (np.zeros(3528, np.float32), 0.0))[0] for sc in scenes]
+    nmax = max(sc.xyz.shape[0] for sc in scenes)
+    xyz_pin = torch.empty((nmax, 3), dtype=torch.float32).pin_memory()
+    cam_pin = torch.empty((nmax,), dtype=torch.int32).pin_memory()
+    assert xyz_pin.is_pinned() and cam_pin.is_pinned()
+    xyz_np, cam_np = xyz_pin.numpy(), cam_pin.numpy()
+    ctx = binding.Context(scenes[0].cam_origins)
+    for it in range(40):
+        k = it & 1
+        sc = scenes[k]
+        n = sc.xyz.shape[0]
+        xyz_np[:n] = sc.xyz
+        cam_np[:n] = sc.cam
+        ctx.set_cloud(xyz_np[:n], cam_np[:n])
+        xyz_np[:] = np.float32(1e3) + np.float32(it)  # the frame buffer is reused at once
+        cam_np[:] = 1 - (it & 1)
+        try:
+            h = ctx.find_hands(sc.samples)
+        except binding.AghError as e:  # (the over-dense `small` scene: the larger capacity classes, reported once)
+            assert e.code == binding.AGH_ERR_RETRY and it == 0
+            h = ctx.find_hands(sc.samples)
+        _same(h, refs[k])
+    ctx.close()
+
+
+def test_second_search_on_another_stream_still_waits_for_the_build(small_scene):
+    """the first search after a host-buffer agh_set_cloud runs on the context's own stream (in order behind the
+    build) -- a SECOND search, on a caller's non-blocking stream, must still be ordered behind that build."""
+    import ctypes as C
+
+    import torch
+
+    from agile_grasp_amd import binding
+
+    sc = small_scene
+    ref = _reference(sc, sc.samples, (np.zeros(3528, np.float32), 0.0))[0]
+    dev = torch.device("cuda", 0)
+    ctx = binding.Context(sc.cam_origins)
+    s_t = torch.from_numpy(sc.samples).to(dev)
+    S = sc.samples.size
+    out_a = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
+    out_b = torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev)
+    n_a = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_b = torch.zeros(1, dtype=torch.int64, device=dev)
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0  # hipStreamNonBlocking
+    torch.cuda.synchronize()
+    for it in range(12):
+        ctx.set_cloud(sc.xyz, sc.cam)
+        ctx.find_hands_torch(s_t, out_a, n_a, stream=None)       # the context's stream: no wait needed, none taken
+        ctx.find_hands_torch(s_t, out_b, n_b, stream=st.value)   # another stream, right behind
+        assert hip.hipStreamSynchronize(st) == 0
+        try:
+            ctx.synchronize()
+        except binding.AghError as e:
+            assert e.code == binding.AGH_ERR_RETRY and it == 0
+            continue
+        got = np.frombuffer(out_b.cpu().numpy().tobytes(), dtype=binding.HYP_DTYPE)[:int(n_b.item())]
+        _same(got, ref)
+    hip.hipStreamDestroy(st)
+    ctx.close()

@@ -448,3 +448,110 @@ def test_cpp_adapter_sharded_search(tmp_path, small_scene, svm_model):
         pts, _cam = ctx.learning_points(int(i))
         assert int(owners) == 1 and int(cols) == int(n_box) == pts.shape[1] and int(foreign) == 0
         assert float(total) == (float(np.cumsum(pts.T.reshape(-1))[-1]) if pts.size else 0.0)  # sequential sum, point-major
+
+
+# ---- round 5: every rank takes the same branch (the table of early returns) ----
+def _run_ranks_codes(ctxs, fn):
+    """Like _run_ranks, but returns (result or None, AghError code or 0) per rank instead of raising the first error."""
+    from agile_grasp_amd import binding
+
+    def wrapped(r, c):
+        try:
+            return fn(r, c), 0
+        except binding.AghError as e:
+            return None, e.code
+
+    return _run_ranks(ctxs, wrapped)
+
+
+def test_bad_sample_index_in_one_slice_fails_on_every_rank_alike(tiny_scene):
+    """the host variant used to range-check only the rank's own slice BEFORE the collectives, so one rank alone
+    returned while the others went into the all-gather (a hang under RCCL, an aborted in-process communicator).  Now the
+    kernels validate, the finding travels in the segment header, and every rank returns AGH_ERR_INVALID_ARGUMENT after the
+    exchange -- and the communicator is still usable."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctxs = _group(sc, 4)
+    bad = sc.samples.copy()
+    bad[-1] = sc.xyz.shape[0] + 5  # only the LAST rank's slice holds it
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(bad))
+    assert [code for _, code in res] == [binding.AGH_ERR_INVALID_ARGUMENT] * 4
+    bad[-1] = -3
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(bad))
+    assert [code for _, code in res] == [binding.AGH_ERR_INVALID_ARGUMENT] * 4
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):  # the communicator survived
+        _same(hyps, ref)
+
+
+def test_too_small_output_buffer_is_recoverable(tiny_scene):
+    """`n > cap` is reported after the collectives with *n_out set so that the caller can come back with a larger
+    buffer -- which needs a communicator that was not aborted on the way out."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    assert len(ref) > 4
+    ctxs = _group(sc, 3)
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(sc.samples, cap=4))
+    assert [code for _, code in res] == [binding.AGH_ERR_CAPACITY] * 3
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        _same(hyps, ref)
+
+
+def test_ranks_with_different_capacity_class_state_decide_alike(small_scene):
+    """One context of the communicator has launched the larger Taubin capacity classes before (it searched a dense cloud on its
+    own), the others have not.  The retry must be every rank's decision or nobody's: it is taken from the gathered segment
+    headers (which say whether the reporting rank had the classes on), not from a rank's own big_classes."""
+    from agile_grasp_amd import binding
+
+    sc = small_scene  # over-dense: its neighbourhoods need the 4096 class
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)  # (the host entry point repeats by itself after AGH_ERR_RETRY)
+    ctxs = [binding.Context(sc.cam_origins) for _ in range(3)]
+    for c in ctxs:
+        c.set_cloud(sc.xyz, sc.cam)
+    ctxs[1].find_hands(sc.samples)  # rank 1 switches its larger classes on, alone
+    binding.comm_init_local(ctxs)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        _same(hyps, ref)
+
+
+def test_contexts_with_different_parameters_cannot_form_a_communicator(tiny_scene):
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    a = binding.Context(sc.cam_origins)
+    b = binding.Context(sc.cam_origins, normals_mode=binding.NORMALS_RAND50)  # would issue one more collective per call
+    with pytest.raises(binding.AghError) as e:
+        binding.comm_init_local([a, b])
+    assert e.value.code == binding.AGH_ERR_INVALID_ARGUMENT
+    c = binding.Context(sc.cam_origins, finger_width=0.012)
+    with pytest.raises(binding.AghError):
+        binding.comm_init_local([a, c])
+    binding.comm_init_local([a, binding.Context(sc.cam_origins)])  # the same parameters: fine
+
+
+def test_antipodal_pass_refuses_clouds_of_different_sizes_on_every_rank(tiny_scene):
+    """calculates_antipodal shards the all-points pass by POINT range: it needs the same cloud on every rank.  With clouds of
+    different sizes the normals' all-gather would carry different byte counts per rank; the sizes are exchanged first and every
+    rank refuses alike, leaving the communicator usable for the plain search (where a cloud per rank is a supported mode)."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctxs = [binding.Context(sc.cam_origins) for _ in range(3)]
+    ctxs[0].set_cloud(sc.xyz, sc.cam)
+    ctxs[1].set_cloud(sc.xyz[:-7], sc.cam[:-7])
+    ctxs[2].set_cloud(sc.xyz, sc.cam)
+    binding.comm_init_local(ctxs)
+    few = sc.samples[sc.samples < sc.xyz.shape[0] - 7]
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(few, calculates_antipodal=True))
+    assert [code for _, code in res] == [binding.AGH_ERR_STATE] * 3
+    res = _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(few))  # still usable
+    assert len({len(h) for h in res}) == 1 and len(res[0]) > 0
