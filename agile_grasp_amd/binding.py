@@ -80,7 +80,7 @@ assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200 and HANDLE_DTYP
 
 EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device", "agh_set_cloud_batch", "agh_set_cloud_batch_device",
-    "agh_preprocess", "agh_preprocess_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_preprocess", "agh_preprocess_device", "agh_localize", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_get_timing_counts", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
@@ -147,6 +147,37 @@ def save_svm_file(path: str, w: np.ndarray, rho: float, kernel: int = SVM_LINEAR
                                           C.c_int32(3528), _p(al, C.c_double), C.c_double(rho))
     if rc != 0:
         raise AghError(rc, f"cannot write {path}")
+
+
+class AghLocalizeParams(C.Structure):
+    _fields_ = [("size_left", C.c_int64), ("dense", C.c_int32), ("classify", C.c_int32), ("workspace", C.c_double * 6),
+                ("cell_size", C.c_double), ("sample_idx", C.POINTER(C.c_int32)), ("n_samples", C.c_int64),
+                ("sample_seed", C.c_uint64), ("min_inliers", C.c_int32), ("reserved", C.c_int32), ("min_length", C.c_double)]
+
+
+class AghLocalizeResult(C.Structure):
+    _fields_ = [("n_voxels", C.c_int64), ("n_hypotheses", C.c_int64), ("n_hands", C.c_int64), ("n_handles", C.c_int64),
+                ("n_inlier_idx", C.c_int64)]
+
+
+def draw_samples(n_points: int, n_samples: int, seed: int) -> np.ndarray:
+    """The sample list agh_localize draws on the device for sample_idx = NULL (include/agh.h): one index per stratum."""
+    M = (1 << 64) - 1
+
+    def splitmix64(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    out = np.empty(n_samples, np.int32)
+    for k in range(n_samples):
+        if n_points >= n_samples:
+            lo, hi = (k * n_points) // n_samples, ((k + 1) * n_points) // n_samples
+            out[k] = lo + splitmix64((seed ^ (k * 0x9E3779B97F4A7C15)) & M) % (hi - lo)
+        else:
+            out[k] = k if k < n_points else -(1 << 31)
+    return out
 
 
 AGH_ERR_INVALID_ARGUMENT, AGH_ERR_HIP, AGH_ERR_CAPACITY, AGH_ERR_NO_CLOUD, AGH_ERR_NO_SVM, AGH_ERR_STATE = -1, -3, -4, -5, -6, -8
@@ -302,6 +333,47 @@ class Context:
                                               _p(idx, C.c_int32), C.c_int64(idx.shape[0]), C.byref(n)))
         out = out[:n.value].copy()
         return out, idx[:int(out["n_inliers"].sum())].copy()
+
+    def localize(self, xyz: np.ndarray, size_left: int, workspace, samples=None, n_samples: int = 0, sample_seed: int = 1,
+                 classify: bool = True, min_inliers: int = 3, min_length: float = 0.005, cell_size: float = 0.003,
+                 dense: bool = False):
+        """agh_localize: raw capture -> voxels -> search -> SVM -> handles in one call with one synchronisation
+        (grasp_localizer.cpp:95-103).  `samples`: indices into the voxelised cloud, or None: n_samples are drawn on the device.
+        Returns a dict: handles, inlier_idx, hands (what the handle search ran on), samples, n_voxels, n_hypotheses."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        lp = AghLocalizeParams()
+        lp.size_left, lp.dense, lp.classify = size_left, 1 if dense else 0, 1 if classify else 0
+        ws = np.ascontiguousarray(workspace, np.float64)
+        assert ws.size == 6
+        for k in range(6):
+            lp.workspace[k] = float(ws[k])
+        lp.cell_size = cell_size
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, np.int32)
+            lp.sample_idx = samples.ctypes.data_as(C.POINTER(C.c_int32))
+            S = samples.shape[0]
+        else:
+            lp.sample_idx = None
+            S = int(n_samples)
+        lp.n_samples, lp.sample_seed, lp.min_inliers, lp.min_length = S, sample_seed, min_inliers, min_length
+        bufs = getattr(self, "_loc_bufs", None)
+        hcap = max(min(8 * S, 8192), 1)
+        if bufs is None or bufs[0].shape[0] < hcap or bufs[3].shape[0] < max(S, 1):
+            bufs = self._loc_bufs = (np.zeros(hcap, HANDLE_DTYPE), np.zeros(hcap, np.int32), np.zeros(hcap, HYP_DTYPE),
+                                     np.zeros(max(S, 1), np.int32))
+        handles, idx, hands, sout = bufs
+        res = AghLocalizeResult()
+        self._check(self.lib.agh_localize(self._h, _p(xyz, C.c_float), C.c_int64(xyz.shape[1] * 4), C.c_int64(xyz.shape[0]),
+                                          C.byref(lp), handles.ctypes.data_as(C.c_void_p), C.c_int64(hcap), _p(idx, C.c_int32),
+                                          C.c_int64(hcap), hands.ctypes.data_as(C.c_void_p), C.c_int64(hcap), _p(sout, C.c_int32),
+                                          C.byref(res)))
+        self.n = res.n_voxels
+        self.last_samples = S
+        self.last_n = res.n_hypotheses
+        return {"handles": handles[:res.n_handles].copy(), "inlier_idx": idx[:res.n_inlier_idx].copy(),
+                "hands": hands[:res.n_hands].copy(), "samples": sout[:S].copy(), "n_voxels": int(res.n_voxels),
+                "n_hypotheses": int(res.n_hypotheses)}
 
     def cloud(self):
         xyz = np.zeros((max(self.n, 1), 3), np.float32)

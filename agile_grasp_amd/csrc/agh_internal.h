@@ -94,8 +94,10 @@ enum SampleStatus : int
   kStatusOverflow = 1,    // neighbourhood larger than the kernel's LDS capacity
   kStatusDegenerate = 2,  // no frame (an empty neighbourhood; rank-deficient pencils DO get one since round 3): no hypotheses
   kStatusRows = 3,
-  kStatusBadIndex = 4     // sample index outside the cloud (device-resident sample lists are validated on the device)
+  kStatusBadIndex = 4,    // sample index outside the cloud (device-resident sample lists are validated on the device)
+  kStatusSkipped = 5      // kSampleSkip: an unused slot of a device-drawn sample list
 };
+constexpr int32_t kSampleSkip = INT32_MIN;
 
 // K-1 (voxelize.hip): per-camera voxel lattice of the preprocessing step
 constexpr unsigned long long kVoxMaxWords = 1ull << 28;  // 1 GiB of bitmap (a 6 m x 6 m x 3 m lattice at 3 mm)
@@ -168,6 +170,7 @@ struct Ctx
   long long* d_vox_total = nullptr;
   unsigned* d_vox_bitmap = nullptr;
   int64_t vox_bitmap_cap = 0;      // words (a multiple of the popcount block)
+  int64_t vox_last_words = 0;   // lattice words of the last preprocessed cloud (a much larger kept bitmap is dropped)
   VoxDesc* h_vox_desc = nullptr;   // pinned host mirror of the descriptor, written by k_vox_lattice / k_vox_totals
   float* d_vox_xyz = nullptr;      // voxelised cloud (packed xyz) and camera ids
   int32_t* d_vox_cam = nullptr;
@@ -193,6 +196,9 @@ struct Ctx
   std::vector<int64_t> cloud_off;   // host copy, n_clouds + 1
   std::vector<int32_t> cloud_off_i32;
   bool cloud_off_on_device = false;
+  bool defer_cloud_count = false;  // set by the deferred preprocessing for the agh_set_cloud_device call it makes next
+  bool n_is_bound = false;  // agh_localize, between its launches and its synchronisation: `n` is the RAW point count, an upper bound of
+                            // the voxelised cloud's; the true count is d_cloud_off[1], written by the voxeliser
   int* d_cloud_off = nullptr;       // kMaxClouds + 1
   int32_t* d_scloud = nullptr;      // s_cap: cloud of every sample of the last call (written by k_taubin_moments)
   GridDesc* d_desc = nullptr;       // clouds_cap
@@ -346,7 +352,7 @@ __host__ __device__ inline int shard_header_word(int flags0, int big_classes_on)
 int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int64_t size_left, int dense,
   const double workspace[6], double cell, hipStream_t st, int64_t cap_words, VoxDesc* host_desc, bool with_lattice);
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
-  VoxDesc* host_desc, bool with_lattice);
+  VoxDesc* host_desc, bool with_lattice, int* cloud_off_out = nullptr);
 // host mirror of the handle search's results (pinned memory of the context; all nullptr / 0: none)
 struct HandleMirror
 {
@@ -357,7 +363,7 @@ struct HandleMirror
   int* counts;  // [0] handles, [1] inlier indices, [2] error, [3] the batched walk declined and no sequential kernel was launched
 };
 int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
-  const HandleMirror& hm, bool with_sequential);
+  const HandleMirror& hm, bool with_sequential, const int* d_H = nullptr);
 int grid_build(Ctx* c, hipStream_t st);
 int taubin_frames(Ctx* c, const int32_t* d_samples, int64_t S, double radius, agh_frame* d_frames, int32_t* d_nt,
   bool write_normals, hipStream_t st);

@@ -591,11 +591,22 @@ int agh_set_cloud_batch_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_
   c->stride_floats = stride_bytes / 4;
   c->d_cam = d_cam_source;
   c->has_normals = false;
+  // agh_localize: n is only a BOUND of the cloud's size -- the voxeliser, still queued on this stream, writes the true offsets
+  // {0, count} into d_cloud_off itself; every kernel of the build and of the search reads them there
+  const bool bound = c->defer_cloud_count && n_clouds == 1;
+  c->defer_cloud_count = false;
+  c->n_is_bound = bound;
   // the offsets travel to the device only when they change (a stream of equally sized clouds re-uses them)
   bool same = c->n_clouds == n_clouds && (int) c->cloud_off.size() == n_clouds + 1 && c->cloud_off_on_device;
   for (int k = 0; same && k <= n_clouds; k++)
     same = c->cloud_off[(size_t) k] == offsets[k];
-  if (!same)
+  if (bound)
+  {
+    c->n_clouds = 1;
+    c->cloud_off.assign(offsets, offsets + 2);
+    c->cloud_off_on_device = false;  // (what the device holds is the true count, not this bound)
+  }
+  else if (!same)
   {
     c->n_clouds = n_clouds;
     c->cloud_off.assign(offsets, offsets + n_clouds + 1);
@@ -743,9 +754,25 @@ int agh_set_cloud_batch(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, co
 }
 
 // ---- f1: preprocessing (NaN removal, workspace box, per-camera voxelisation), then the grid build ----
+static int preprocess_device_impl(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
+  int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream, bool defer_count, bool* deferred);
+
 int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
   int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream)
 {
+  return preprocess_device_impl(ctx, d_xyz, stride_bytes, n, size_left, dense, workspace, cell_size, n_voxels_out, hip_stream, false,
+    nullptr);
+}
+
+// defer_count (agh_localize): when the context already has a voxel bitmap to speculate with, nothing is waited for -- the voxel
+// count stays on the device (d_cloud_off, written by the voxeliser's scan), the grid build is queued for the BOUND n, and
+// *deferred tells the caller that the descriptor (error word, counts) is still to be read from the pinned mirror after its own
+// synchronisation.  Without a bitmap (a context's first cloud) the call behaves as agh_preprocess_device.
+static int preprocess_device_impl(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left,
+  int dense, const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream, bool defer_count, bool* deferred)
+{
+  if (deferred)
+    *deferred = false;
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
@@ -787,6 +814,13 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
   VoxDesc h;
   for (int attempt = 0;; attempt++)
   {
+    // (a bitmap kept from a much larger lattice is dropped: every later cloud would clear and count all of it)
+    if (c->d_vox_bitmap && c->vox_last_words > 0 && c->vox_bitmap_cap > 8 * c->vox_last_words + (1 << 20))
+    {
+      (void) hipFree(c->d_vox_bitmap);
+      c->d_vox_bitmap = nullptr;
+      c->vox_bitmap_cap = 0;
+    }
     const bool speculative = c->d_vox_bitmap && c->vox_bitmap_cap > 0;
     if ((rc = vox_stage1(c, d_xyz, stride_bytes / 4, n, size_left, dense, workspace, cell_size, st,
            speculative ? c->vox_bitmap_cap : (int64_t) kVoxMaxWords, c->h_vox_desc, !speculative)) != AGH_OK)
@@ -800,17 +834,27 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
       h = *c->h_vox_desc;
       if (h.error)
         break;
-      const int64_t want = (((int64_t) h.n_words + (int64_t) h.n_words / 4) / 4096 + 1) * 4096;  // a quarter of headroom
+      // a quarter of headroom -- never beyond the lattice limit the block tables (d_vox_blk2: kVoxMaxWords / 4096 + 1 entries)
+      // are sized for: the unclamped size reached 81 921 blocks for lattices above 0.8 x 2^28 words
+      const int64_t want = std::min<int64_t>((((int64_t) h.n_words + (int64_t) h.n_words / 4) / 4096 + 1) * 4096, (int64_t) kVoxMaxWords);
       if ((rc = dev_alloc(c, &c->d_vox_bitmap, (size_t) want + 4096)))
         return rc;
       c->vox_bitmap_cap = want;
     }
-    if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, c->vox_bitmap_cap, st, c->h_vox_desc, speculative)) != AGH_OK)
+    const bool defer = defer_count && speculative && n > 0;
+    if ((rc = vox_stage2(c, d_xyz, stride_bytes / 4, n, cell_size, c->vox_bitmap_cap, st, c->h_vox_desc, speculative,
+           defer ? c->d_cloud_off : nullptr)) != AGH_OK)
     {
       c->err = "preprocessing launch failed";
       return rc;
     }
     timing_mark(c, "preprocess", st);
+    if (defer)
+    {
+      *deferred = true;
+      c->defer_cloud_count = true;
+      return agh_set_cloud_device(ctx, c->d_vox_xyz, 12, c->d_vox_cam, n, hip_stream);
+    }
     HIPCHK(c, hipStreamSynchronize(st));  // the voxel count sizes the search structure
     h = *c->h_vox_desc;
     if (h.error != 2 || attempt >= 1)
@@ -826,6 +870,7 @@ int agh_preprocess_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes
              "(Localization::setWorkspace) that bounds the scene";
     return AGH_ERR_CAPACITY;
   }
+  c->vox_last_words = (int64_t) h.n_words;
   const int64_t nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
   if (n_voxels_out)
     *n_voxels_out = nv;
@@ -919,6 +964,42 @@ static bool handle_thresholds(double* x1, double* x2)
   return true;
 }
 
+// device buffers of the handle search for up to n_hands hands, and its pinned staging: the hands go up with an asynchronous copy
+// (agh_find_handles) or are written there by the device (agh_localize); the handles, the inlier lists and the counts are written
+// to host memory by the kernels themselves -- one synchronisation, no read-back copies
+static int ensure_handle_buffers(Ctx* c, int64_t n_hands)
+{
+  if (n_hands > c->h_cap || !c->d_h_counts)
+  {
+    const size_t cap = (size_t) std::max<int64_t>(n_hands, 256);
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_h_hands, cap)) || (rc = dev_alloc(c, &c->d_h_bits, cap * ((cap + 63) / 64))) ||
+        (rc = dev_alloc(c, &c->d_h_rowcnt, cap)) || (rc = dev_alloc(c, &c->d_h_first, cap)) ||
+        (rc = dev_alloc(c, &c->d_h_n, cap)) || (rc = dev_alloc(c, &c->d_h_idx, cap)) ||
+        (rc = dev_alloc(c, &c->d_h_counts, 8)) || (rc = dev_alloc(c, &c->d_h_handles, cap)) ||
+        (rc = dev_alloc(c, &c->d_h_tmp, cap)))
+      return rc;
+    c->h_cap = (int64_t) cap;
+  }
+  if (n_hands > c->h_pin_handles_cap || !c->h_pin_handles)
+  {
+    const int64_t cap = std::max<int64_t>(n_hands, 1024);
+    if (c->h_pin_handles)
+    {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void) hipHostFree(c->h_pin_handles);
+      c->h_pin_handles = nullptr;
+      c->h_pin_handles_cap = 0;
+    }
+    void* p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, (size_t) (256 + cap * (int64_t) (sizeof(agh_hypothesis) + sizeof(agh_handle) + sizeof(int32_t))),
+                hipHostMallocDefault));
+    c->h_pin_handles = static_cast<uint8_t*>(p);
+    c->h_pin_handles_cap = cap;
+  }
+  return AGH_OK;
+}
+
 int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, int64_t* n_handles_out)
 {
@@ -938,35 +1019,10 @@ int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands,
     return AGH_ERR_INVALID_ARGUMENT;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  if (n_hands > c->h_cap || !c->d_h_counts)
   {
-    const size_t cap = (size_t) std::max<int64_t>(n_hands, 256);
-    int rc;
-    if ((rc = dev_alloc(c, &c->d_h_hands, cap)) || (rc = dev_alloc(c, &c->d_h_bits, cap * ((cap + 63) / 64))) ||
-        (rc = dev_alloc(c, &c->d_h_rowcnt, cap)) || (rc = dev_alloc(c, &c->d_h_first, cap)) ||
-        (rc = dev_alloc(c, &c->d_h_n, cap)) || (rc = dev_alloc(c, &c->d_h_idx, cap)) ||
-        (rc = dev_alloc(c, &c->d_h_counts, 4)) || (rc = dev_alloc(c, &c->d_h_handles, cap)) ||
-        (rc = dev_alloc(c, &c->d_h_tmp, cap)))
+    const int rc = ensure_handle_buffers(c, n_hands);
+    if (rc != AGH_OK)
       return rc;
-    c->h_cap = (int64_t) cap;
-  }
-  // pinned staging (as in agh_find_hands): the hands go up with an asynchronous copy, the handles, the inlier lists and the
-  // counts are written to host memory by the kernels themselves -- one synchronisation, no read-back copies
-  if (n_hands > c->h_pin_handles_cap || !c->h_pin_handles)
-  {
-    const int64_t cap = std::max<int64_t>(n_hands, 1024);
-    if (c->h_pin_handles)
-    {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      (void) hipHostFree(c->h_pin_handles);
-      c->h_pin_handles = nullptr;
-      c->h_pin_handles_cap = 0;
-    }
-    void* p = nullptr;
-    HIPCHK(c, hipHostMalloc(&p, (size_t) (256 + cap * (int64_t) (sizeof(agh_hypothesis) + sizeof(agh_handle) + sizeof(int32_t))),
-                hipHostMallocDefault));
-    c->h_pin_handles = static_cast<uint8_t*>(p);
-    c->h_pin_handles_cap = cap;
   }
   int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
   agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
@@ -1304,6 +1360,317 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
     std::memcpy(out, h_rec, sizeof(agh_hypothesis) * (size_t) from_pin);
   if (n > from_pin)  // (lists beyond the mirror's room: the rest comes from the device copy)
     HIPCHK(c, hipMemcpy(out + from_pin, c->d_out_own + from_pin, sizeof(agh_hypothesis) * (size_t) (n - from_pin), hipMemcpyDeviceToHost));
+  return AGH_OK;
+}
+
+// ---- the online chain in one call (grasp_localizer.cpp:95-103) ----
+namespace
+{
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// One sample per stratum of the cloud (include/agh.h, agh_localize); the point count is read on the device.
+__global__ void k_draw_samples(const int* __restrict__ cloud_off, int n_clouds, int S, unsigned long long seed,
+  int32_t* __restrict__ out, int32_t* __restrict__ host_out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= S)
+    return;
+  const long long N = cloud_off[n_clouds];
+  int32_t v;
+  if (N >= S)
+  {
+    const long long lo = ((long long) k * N) / S, hi = ((long long) (k + 1) * N) / S;
+    v = (int32_t) (lo + (long long) (splitmix64(seed ^ ((unsigned long long) k * 0x9E3779B97F4A7C15ull)) % (unsigned long long) (hi - lo)));
+  }
+  else
+    v = k < N ? k : kSampleSkip;
+  out[k] = v;
+  if (host_out)
+    host_out[k] = v;
+}
+// The hands Learning::classify kept (svm_keep; all of them if !use_keep), in list order (learning.cpp:236-243), as the handle
+// search's input -- and a second time into pinned host memory.  One work-group: an ordered compaction is a scan.
+// host_counts: [4] hypotheses, [5] kept, [6] the search's error word.
+__global__ __launch_bounds__(1024) void k_compact_kept(const agh_hypothesis* __restrict__ in, const int64_t* __restrict__ n_in,
+  int64_t cap_in, int use_keep, agh_hypothesis* __restrict__ out, int out_cap, int* __restrict__ n_out,
+  agh_hypothesis* __restrict__ host_out, int host_cap, int* __restrict__ host_counts, const int32_t* __restrict__ flags)
+{
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = min(*n_in, cap_in);
+  if (tid == 0)
+    carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < n; b0 += 1024)
+  {
+    const int64_t i = b0 + tid;
+    const bool keep = i < n && (!use_keep || in[i].svm_keep != 0);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0)
+      wsum[wave] = __popcll(m);
+    __syncthreads();
+    int base = carry, tot = 0;
+    for (int w = 0; w < 16; w++)
+    {
+      base += w < wave ? wsum[w] : 0;
+      tot += wsum[w];
+    }
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep)
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(in + i);
+      if (pos < out_cap)
+        for (int q = 0; q < 10; q++)
+          reinterpret_cast<uint4*>(out + pos)[q] = src[q];
+      if (host_out && pos < host_cap)
+        for (int q = 0; q < 10; q++)
+          reinterpret_cast<uint4*>(host_out + pos)[q] = src[q];
+    }
+    __syncthreads();
+    if (tid == 0)
+      carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0)
+  {
+    *n_out = carry;
+    if (host_counts)
+    {
+      host_counts[4] = (int) n;
+      host_counts[5] = carry;
+      host_counts[6] = flags[0] | (*n_in > cap_in ? 2 : 0);
+    }
+  }
+}
+}  // namespace
+
+int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
+  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  if (result)
+    *result = agh_localize_result{ 0, 0, 0, 0, 0 };
+  if (!lp || n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz) || !(lp->cell_size > 0.0) ||
+      lp->size_left < 0 || lp->n_samples < 0 || lp->n_samples > (1 << 24) || lp->min_inliers < 1 || handle_cap < 0 || idx_cap < 0 ||
+      hands_cap < 0 || (handle_cap > 0 && !handles_out) || (idx_cap > 0 && !inlier_idx_out) || (hands_cap > 0 && !hands_out))
+  {
+    c->err = "agh_localize: bad arguments (see include/agh.h)";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  if (lp->classify && !c->has_svm)
+  {
+    c->err = "agh_localize: classify needs a loaded SVM (agh_load_svm*)";
+    return AGH_ERR_NO_SVM;
+  }
+  double x1 = 0, x2 = 0;
+  if (!handle_thresholds(&x1, &x2))
+  {
+    c->err = "agh_localize: this libm's acos is not monotone around the 0.34 rad thresholds";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t S = lp->n_samples;
+  hipStream_t st = c->stream;
+  int rc;
+  // ---- 1. raw cloud up, voxelisation and grid build queued; the voxel count stays on the device when it can ----
+  const bool as_is = stride_bytes <= 32;  // (as agh_preprocess)
+  const int64_t dev_stride = as_is ? stride_bytes : 12;
+  const int64_t need = n * (dev_stride / 4);
+  if (need > c->raw_cap || !c->d_raw_xyz)
+  {
+    if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
+      return rc;
+    c->raw_cap = need;
+  }
+  if (n > 0)
+  {
+    if (as_is)
+      HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, st));
+    else
+      HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, st));
+  }
+  bool deferred = false;
+  int64_t nv = 0;
+  rc = preprocess_device_impl(ctx, c->d_raw_xyz, dev_stride, n, lp->size_left, lp->dense, lp->workspace, lp->cell_size, &nv, nullptr,
+    true, &deferred);
+  if (rc != AGH_OK)
+    return rc;
+  c->cloud_async = false;  // (everything below is queued on the context's own stream, and the call ends with its synchronisation)
+  // ---- 2. buffers for the bounds ----
+  if ((rc = ensure_call_buffers(c, std::max<int64_t>(S, 1))) != AGH_OK)  // (S = 0: the later stages still want their buffers)
+    return rc;
+  if (S > c->idx_cap || !c->d_idx_own)
+  {
+    if ((rc = dev_alloc(c, &c->d_idx_own, (size_t) std::max<int64_t>(S, 1024))))
+      return rc;
+    c->idx_cap = std::max<int64_t>(S, 1024);
+  }
+  if ((rc = ensure_host_staging(c, S, 1024)) != AGH_OK)
+    return rc;
+  int32_t* h_idx = reinterpret_cast<int32_t*>(c->h_pin + kPinHeaderBytes);
+  const int64_t hyp_bound = 8 * S;
+  const int64_t hand_bound = std::min<int64_t>(hyp_bound, 8192);
+  if ((rc = ensure_handle_buffers(c, hand_bound)) != AGH_OK)
+    return rc;
+  if (lp->classify && c->s_cap * 8 > c->keep_cap)
+  {
+    if (c->d_keep)
+      (void) hipFree(c->d_keep);
+    if (c->d_svm_sums)
+      (void) hipFree(c->d_svm_sums);
+    c->d_keep = nullptr;
+    c->d_svm_sums = nullptr;
+    c->keep_cap = 0;
+    HIPCHK(c, hipMalloc((void**) &c->d_keep, (size_t) (c->s_cap * 8)));
+    HIPCHK(c, hipMalloc((void**) &c->d_svm_sums, (size_t) (c->s_cap * 8) * sizeof(double)));
+    c->keep_cap = c->s_cap * 8;
+  }
+  int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
+  agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
+  agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
+  int32_t* h_hidx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
+  const HandleMirror hm{ h_handles, (int) c->h_pin_handles_cap, h_hidx, (int) c->h_pin_handles_cap, h_counts };
+  int* d_hcount = c->d_h_counts + 4;  // (behind the HandleCounts record)
+  // ---- 3. the sample list ----
+  if (S > 0)
+  {
+    if (lp->sample_idx)
+    {
+      std::memcpy(h_idx, lp->sample_idx, sizeof(int32_t) * (size_t) S);
+      HIPCHK(c, hipMemcpyAsync(c->d_idx_own, h_idx, sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_draw_samples, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, (const int*) c->d_cloud_off, 1, (int) S,
+        (unsigned long long) lp->sample_seed, c->d_idx_own, h_idx);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  // ---- 4. search -> classification -> kept hands -> handle search, then the one synchronisation ----
+  VoxDesc h;
+  bool handles_only = false;
+  for (int attempt = 0;; attempt++)
+  {
+    for (int k = 0; k < (handles_only ? 4 : 8); k++)  // ([4..6], the search's counts, outlive a repeat of the handle search alone)
+      h_counts[k] = 0;
+    const bool with_sequential = c->handles_sequential;
+    if (!handles_only)
+    {
+      c->mirror = HostMirror{ nullptr, 0, nullptr };
+      if ((rc = agh_find_hands_device(ctx, c->d_idx_own, S, 0, c->d_out_own, c->s_cap * 8, c->d_nout, st)) != AGH_OK)
+      {
+        (void) hipStreamSynchronize(st);
+        c->n_is_bound = false;
+        return rc;
+      }
+      if (lp->classify && (rc = agh_classify_device(ctx, c->d_keep, st)) != AGH_OK)
+      {
+        (void) hipStreamSynchronize(st);
+        c->n_is_bound = false;
+        return rc;
+      }
+      hipLaunchKernelGGL(k_compact_kept, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_out_own, (const int64_t*) c->d_nout,
+        c->s_cap * 8, lp->classify ? 1 : 0, c->d_h_hands, (int) hand_bound, d_hcount, h_hands, (int) c->h_pin_handles_cap, h_counts,
+        (const int32_t*) c->d_flags);
+      HIPCHK(c, hipGetLastError());
+    }
+    timing_begin(c, st);
+    rc = handle_search(c, hand_bound, x1, x2, lp->min_inliers, lp->min_length, st, hm, with_sequential, d_hcount);
+    timing_mark(c, "handle_search", st);
+    if (rc != AGH_OK)
+    {
+      (void) hipStreamSynchronize(st);
+      c->n_is_bound = false;
+      c->err = "handle search launch failed";
+      return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (deferred)  // the descriptor of the speculative voxelisation, now on the host
+    {
+      deferred = false;
+      h = *c->h_vox_desc;
+      nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
+      c->n_is_bound = false;
+      if (h.error)
+      {
+        // error 2: the lattice outgrew the bitmap kept from the previous cloud -- the whole call once more, sized from this
+        // cloud's lattice (the context then has no bitmap to speculate with: the preprocessing takes its own round trips)
+        c->has_cloud = false;
+        c->n = 0;
+        c->cloud_off_on_device = false;
+        if (h.error == 2 && attempt == 0)
+        {
+          (void) hipFree(c->d_vox_bitmap);
+          c->d_vox_bitmap = nullptr;
+          c->vox_bitmap_cap = 0;
+          return agh_localize(ctx, xyz, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
+            samples_out, result);
+        }
+        c->err = "the voxel lattice of the kept points exceeds 2^33 cells (1 GiB bitmap): set a workspace "
+                 "(Localization::setWorkspace) that bounds the scene";
+        return AGH_ERR_CAPACITY;
+      }
+      c->vox_last_words = (int64_t) h.n_words;
+      c->n = nv;
+      c->cloud_off.assign({ (int64_t) 0, nv });
+      c->cloud_off_on_device = true;  // ({0, nv}: what the voxeliser wrote)
+      c->n_clouds = 1;
+    }
+    if (!handles_only)
+    {
+      int32_t flags[1] = { h_counts[6] };
+      rc = flags_to_status(c, flags);
+      if (rc == AGH_ERR_RETRY && attempt < 2)
+        continue;  // (the larger capacity classes are on now: the search once more, on the cloud that is already there)
+      if (rc != AGH_OK)
+        return rc;
+    }
+    if (h_counts[2] == 2 || h_counts[5] > 8192)
+    {
+      c->err = "agh_localize: more than 8192 hands for the handle search (classify first, or search fewer samples)";
+      return AGH_ERR_CAPACITY;
+    }
+    const bool declined = h_counts[3] != 0;  // a row of the pair matrix longer than a wave (see agh_find_handles)
+    c->handles_sequential = declined;
+    if (declined && !with_sequential && attempt < 3)
+    {
+      handles_only = true;
+      continue;
+    }
+    break;
+  }
+  if (h_counts[2])
+  {
+    c->err = "agh_localize: a seed hand has more than 2048 inliers";
+    return AGH_ERR_CAPACITY;
+  }
+  const int64_t n_hyp = h_counts[4], n_kept = h_counts[5];
+  c->last_nout = std::min<int64_t>(n_hyp, c->s_cap * 8);
+  if (result)
+    *result = agh_localize_result{ nv, n_hyp, n_kept, h_counts[0], h_counts[1] };
+  if (samples_out && S > 0)
+    std::memcpy(samples_out, h_idx, sizeof(int32_t) * (size_t) S);
+  if (h_counts[0] > handle_cap || h_counts[1] > idx_cap || (hands_out && n_kept > hands_cap))
+  {
+    c->err = "agh_localize: output buffers too small (the counts are in *result)";
+    return AGH_ERR_CAPACITY;
+  }
+  if (h_counts[0] > 0)
+  {
+    std::memcpy(handles_out, h_handles, sizeof(agh_handle) * (size_t) h_counts[0]);
+    std::memcpy(inlier_idx_out, h_hidx, sizeof(int32_t) * (size_t) h_counts[1]);
+  }
+  if (hands_out && n_kept > 0)
+    std::memcpy(hands_out, h_hands, sizeof(agh_hypothesis) * (size_t) n_kept);
   return AGH_OK;
 }
 

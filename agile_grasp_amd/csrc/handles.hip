@@ -21,13 +21,23 @@ namespace agh
 {
 
 constexpr int kHandleListCap = 2048;  // inliers of one seed (LDS)
+constexpr int kHandleMaxHands = 8192;
 
 __device__ __forceinline__ double dot3d(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
+// d_H (all kernels of this file): the number of hands in device memory, when the host does not know it (agh_localize: the
+// hands are what the SVM kept of a search still in flight); the launch is then sized for a bound and H, W are read here.
 __global__ __launch_bounds__(256) void k_handle_pairs(const agh_hypothesis* __restrict__ hands, int H, double x1, double x2,
-  unsigned long long* __restrict__ bits, int W, int* __restrict__ rowcnt)
+  unsigned long long* __restrict__ bits, int W, int* __restrict__ rowcnt, const int* __restrict__ d_H)
 {
+  if (d_H)
+  {
+    H = min(*d_H, kHandleMaxHands);
+    W = (H + 63) >> 6;
+  }
   const int i = blockIdx.x;
+  if (i >= H)
+    return;
   const int tid = threadIdx.x, lane = tid & 63;
   const agh_hypothesis& hi = hands[i];
   const double ia[3] = { hi.axis[0], hi.axis[1], hi.axis[2] };
@@ -92,9 +102,16 @@ template <bool SMALL>
 __global__ __launch_bounds__(256) void k_handle_greedy(const agh_hypothesis* __restrict__ hands, int H,
   const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
   int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts,
-  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts)
+  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts, const int* __restrict__ d_H)
 {
   constexpr int kCap = SMALL ? 1024 : kHandleListCap;
+  if (d_H)
+  {
+    H = *d_H;
+    W = (H + 63) >> 6;
+    if (H > kHandleMaxHands || (H <= kHandleLdsHands) != SMALL)  // (both variants are launched; the other one's case)
+      return;
+  }
   if (!counts->sequential)  // (k_handle_batch has done the search)
     return;
   __shared__ unsigned long long alive[128];  // W <= 128 (H <= 8192)
@@ -405,9 +422,29 @@ template <bool SMALL>
 __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __restrict__ hands, int H,
   const unsigned long long* __restrict__ bits, int W, const int* __restrict__ rowcnt, int min_inliers, double min_length,
   int* __restrict__ h_first, int* __restrict__ h_n, int* __restrict__ inlier_idx, HandleCounts* __restrict__ counts,
-  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts, int* __restrict__ tmp)
+  int* __restrict__ host_idx, int host_idx_cap, int* __restrict__ host_counts, int* __restrict__ tmp, const int* __restrict__ d_H)
 {
   constexpr int kBatch = 16;
+  if (d_H)
+  {
+    H = *d_H;
+    W = (H + 63) >> 6;
+    if (H > kHandleMaxHands)  // loud, by the general variant alone
+    {
+      if (!SMALL && threadIdx.x == 0)
+      {
+        counts->n_handles = 0;
+        counts->n_idx = 0;
+        counts->error = 2;
+        counts->sequential = 0;
+        if (host_counts)
+          host_counts[2] = 2;
+      }
+      return;
+    }
+    if ((H <= kHandleLdsHands) != SMALL)  // (both variants are launched; the other one's case)
+      return;
+  }
   __shared__ unsigned long long alive[128], elig[128], done[128];  // W <= 128 (H <= 8192)
   __shared__ double hpos[SMALL ? kHandleLdsHands : 1][6];  // axis, bottom
   __shared__ unsigned long long lbits[SMALL ? kHandleLdsHands * kHandleLdsWords : 1];
@@ -545,10 +582,14 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
       load_row(i, row0, row1);
       m0 = lane < W ? (row0 & alive[lane]) : 0ull;
       m1 = 64 + lane < W ? (row1 & alive[64 + lane]) : 0ull;
+      // (the sharing test below assumes a row holds its own seed.  k_handle_pairs sets the diagonal only if the hand's axis and
+      // approach pass the alignment test against themselves, i.e. for unit vectors; for hands a caller did not normalise a seed
+      // retired by an earlier candidate of the round could share no bit with it and be committed from its stale evaluation --
+      // ADVICE r4.  The seed's own bit is OR-ed into the mask the sharing test reads, not into the member set.)
       if (lane < W)
-        rowm[wave][lane] = m0;
+        rowm[wave][lane] = m0 | (lane == (i >> 6) ? (1ull << (i & 63)) : 0ull);
       if (64 + lane < W)
-        rowm[wave][64 + lane] = m1;
+        rowm[wave][64 + lane] = m1 | (64 + lane == (i >> 6) ? (1ull << (i & 63)) : 0ull);
       const int n = wave_allsum_i32(__popcll(m0) + __popcll(m1));  // <= 64 (s_maxrow)
       accept = n >= min_inliers;  // handle_search.cpp:47-48
       if (accept)
@@ -883,32 +924,36 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
 // with the kernel (agh_find_handles remembers what the previous set of hands needed, so a stream of similar clouds pays the
 // ~5 us of an unneeded launch only when it is needed).
 int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, double min_length, hipStream_t st,
-  const HandleMirror& hm, bool with_sequential)
+  const HandleMirror& hm, bool with_sequential, const int* d_H)
 {
+  // d_H: the count lives on the device and H is only its bound (agh_localize) -- launches sized for the bound, both LDS
+  // variants of the walk queued, each returning at once when the count is the other one's case
   const int Hi = (int) H, W = (Hi + 63) / 64;
   if (Hi == 0)
     return hipMemsetAsync(c->d_h_counts, 0, sizeof(HandleCounts), st) == hipSuccess ? AGH_OK : AGH_ERR_HIP;
   hipLaunchKernelGGL(k_handle_pairs, dim3(Hi), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi, x1, x2,
-    c->d_h_bits, W, c->d_h_rowcnt);
+    c->d_h_bits, W, c->d_h_rowcnt, d_H);
   // the walk: sixteen seeds at a time (rows of at most 64 hands), else -- flagged on the device -- the sequential kernel
-  if (Hi <= kHandleLdsHands)
+  if (Hi <= kHandleLdsHands || d_H)
     hipLaunchKernelGGL(k_handle_batch<true>, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp);
-  else
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp, d_H);
+  if (Hi > kHandleLdsHands)
     hipLaunchKernelGGL(k_handle_batch<false>, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
       (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp);
-  if (!with_sequential)
-    ;
-  else if (Hi <= kHandleLdsHands)
-    hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
-      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts);
-  else
-    hipLaunchKernelGGL(k_handle_greedy<false>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
-      (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
-      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts);
+      c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, c->d_h_tmp, d_H);
+  if (with_sequential)
+  {
+    if (Hi <= kHandleLdsHands || d_H)
+      hipLaunchKernelGGL(k_handle_greedy<true>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+        (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+        c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, d_H);
+    if (Hi > kHandleLdsHands)
+      hipLaunchKernelGGL(k_handle_greedy<false>, dim3(1), dim3(256), 0, st, (const agh_hypothesis*) c->d_h_hands, Hi,
+        (const unsigned long long*) c->d_h_bits, W, (const int*) c->d_h_rowcnt, min_inliers, min_length, c->d_h_first,
+        c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, d_H);
+  }
+  // (a handle holds at least min_inliers >= 1 hands: H bounds the handles too)
   hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
     (const int*) c->d_h_first, (const int*) c->d_h_n, (const int*) c->d_h_idx,
     (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles, hm.handles, hm.handle_cap);

@@ -80,11 +80,16 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     zero_flags[tid] = 0;  // first kernel of an agh_find_hands call: the flags are only set by later kernels
   if (!first_class && status[s] != kStatusOverflow)
     return;  // an earlier (smaller) capacity class already handled this sample
-  if (samples[s] < 0 || samples[s] >= n_points)
+  // (n_points < 0: the host only knows a bound -- agh_localize, whose cloud is still being voxelised when this launch is queued --
+  // and the count is the last of the device-side cloud offsets)
+  const int n_pts = n_points >= 0 ? n_points : gv.cloud_off[gv.n_clouds];
+  if (samples[s] < 0 || samples[s] >= n_pts)
   {
     if (threadIdx.x == 0)
     {
-      status[s] = kStatusBadIndex;
+      // kSampleSkip: a slot of a device-drawn sample list beyond what the cloud could fill (fewer points than samples): no
+      // frame, no hypotheses, no error
+      status[s] = samples[s] == kSampleSkip ? kStatusSkipped : kStatusBadIndex;
       nt[s] = 0;
     }
     return;
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   if (ok ? (ks_class <= nmin || ks_class > CAP) : (nmin != 0))
     return;
   const bool valid = ok;
-  const bool bad_index = status[s] == kStatusBadIndex;
+  const bool bad_index = status[s] == kStatusBadIndex || status[s] == kStatusSkipped;
   const float* qp = xyz + (int64_t) (bad_index ? 0 : samples[s]) * stride;
   if (!valid)
   {
@@ -1275,7 +1280,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
+      r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
       zf, c->d_scloud, moments_dbg);
     zf = nullptr;
     first = false;
@@ -1285,11 +1290,11 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   // c->big_classes stays set).  Skipped classes leave kStatusOverflow behind, which k_taubin_eigen turns into the flag.
   if (first || c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
+      r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
       zf, c->d_scloud, moments_dbg);
   if (c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
-      r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, (int) c->n,
+      r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
       (int32_t*) nullptr, c->d_scloud, (long long*) nullptr);
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)

@@ -68,13 +68,15 @@ __global__ __launch_bounds__(kPreBlock) void k_vox_count(const float* __restrict
     blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total, VoxDesc* host_desc);
+__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total, VoxDesc* host_desc, int* cloud_off_out);
 
 // Exclusive scan of an int array with one block (in place); total to *total if given.  Two one-thread kernels ride along
 // (each was a ~5 us launch of its own: a few dependent global accesses by one thread): init_desc -- the descriptor's
 // reset in front of k_vox_classify --, and totals_desc -- the voxel counts per camera and the host mirror behind the second scan.
+// cloud_off_out: the context's device-side cloud offsets {0, voxel count} -- so that a grid build queued behind this kernel
+// finds the count on the device, without the host having to wait for it (agh_localize).
 __global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t nb, long long* total, VoxDesc* init_desc,
-  VoxDesc* totals_desc, VoxDesc* host_desc)
+  VoxDesc* totals_desc, VoxDesc* host_desc, int* cloud_off_out)
 {
   __shared__ long long carry;
   __shared__ int wsum[16];
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_vox_scan(int* __restrict__ v, int64_t 
   if (total && threadIdx.x == 0)
     *total = carry;
   if (totals_desc && threadIdx.x == 0)  // (v was written by this work-group: the barriers above order it)
-    vox_totals(totals_desc, v, carry, host_desc);
+    vox_totals(totals_desc, v, carry, host_desc, cloud_off_out);
 }
 
 // Camera id (rank in the NaN-free cloud >= size_left), workspace test, per-camera minimum and maximum.
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void k_vox_popcount(const unsigned* __restrict
     blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total_v, VoxDesc* host_desc)
+__device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long long total_v, VoxDesc* host_desc, int* cloud_off_out)
 {
   const long long* total = &total_v;
   if (d->error)
@@ -335,6 +337,8 @@ __device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long 
     d->n_vox[0] = d->n_vox[1] = 0;
     if (host_desc)
       *host_desc = *d;
+    if (cloud_off_out)
+      cloud_off_out[0] = cloud_off_out[1] = 0;
     return;
   }
   const long long first1 = d->word_ofs[1] / kWordsPerBlock < d->n_words / kWordsPerBlock
@@ -344,6 +348,11 @@ __device__ void vox_totals(VoxDesc* d, const int* __restrict__ blk_prefix, long 
   d->n_vox[1] = *total - first1;
   if (host_desc)
     *host_desc = *d;
+  if (cloud_off_out)
+  {
+    cloud_off_out[0] = 0;
+    cloud_off_out[1] = (int) *total;
+  }
 }
 
 // Emit the voxels in bitmap order = (camera, x, y, z) lexicographic order; coordinates as localization.cpp:313-324.
@@ -441,7 +450,7 @@ int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int
     {
       hipLaunchKernelGGL(k_vox_count, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n, c->d_vox_blk);
       hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk, nb, (long long*) nullptr, c->d_vox_desc,
-        (VoxDesc*) nullptr, (VoxDesc*) nullptr);
+        (VoxDesc*) nullptr, (VoxDesc*) nullptr, (int*) nullptr);
     }
     hipLaunchKernelGGL(k_vox_classify, dim3((unsigned) nb), dim3(kPreBlock), 0, st, d_xyz, stride_floats, n,
       dense ? (const int*) nullptr : (const int*) c->d_vox_blk, size_left, ws, c->d_vox_code, c->d_vox_desc);
@@ -455,7 +464,7 @@ int vox_stage1(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, int
 // n_words: the lattice's size, or any multiple of kWordsPerBlock above it that the bitmap has room for (the blocks beyond the
 // lattice hold no bits and emit nothing)
 int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, double cell, int64_t n_words, hipStream_t st,
-  VoxDesc* host_desc, bool with_lattice)
+  VoxDesc* host_desc, bool with_lattice, int* cloud_off_out)
 {
   const int64_t cap_words = n_words;
   if (n == 0)
@@ -475,7 +484,7 @@ int vox_stage2(Ctx* c, const float* d_xyz, int64_t stride_floats, int64_t n, dou
       c->d_vox_blk2);
   }
   hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, st, c->d_vox_blk2, nb2, c->d_vox_total, (VoxDesc*) nullptr, c->d_vox_desc,
-    host_desc);  // (+ the voxel counts per camera and the host mirror)
+    host_desc, cloud_off_out);  // (+ the voxel counts per camera, the host mirror, the device-side cloud offsets)
   if (n > 0 && n_words > 0)
     hipLaunchKernelGGL(k_vox_emit, dim3((unsigned) nb2), dim3(256), 0, st, (const unsigned*) c->d_vox_bitmap,
       (const int*) c->d_vox_blk2, (const VoxDesc*) c->d_vox_desc, cell, c->d_vox_xyz, c->d_vox_cam);

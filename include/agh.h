@@ -187,6 +187,47 @@ typedef struct agh_handle
 int agh_find_handles(agh_ctx* ctx, const agh_hypothesis* hands, int64_t n_hands, int32_t min_inliers, double min_length,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, int64_t* n_handles_out);
 
+/* The chain the reference's online caller runs per cloud (GraspLocalizer::localizeGrasps, grasp_localizer.cpp:95-103:
+ * localizeHands -> predictAntipodalHands -> findHandles) as ONE call with ONE synchronisation: raw capture in, handles out.
+ * Preprocessing (as agh_preprocess), grid build, sample selection, hand search, classification (as agh_classify), compaction of
+ * the kept hands and the handle search (as agh_find_handles) are queued on the context's stream without a host round trip in
+ * between: the voxel count, the hypothesis count and the number of kept hands stay on the device, launches are sized for their
+ * bounds (n, 8 x n_samples, min(8 x n_samples, 8192)).  The results equal those of the four separate calls on the same
+ * samples, bit for bit.  The first cloud of a context (no voxel bitmap to speculate with yet) and a cloud whose lattice
+ * outgrew the bitmap take the preprocessing's own synchronisations once.
+ *
+ * sample_idx: n_samples indices into the VOXELISED cloud (localizeHands' `indices`; validated on the device:
+ * AGH_ERR_INVALID_ARGUMENT), or NULL: n_samples indices are drawn on the device -- one per stratum
+ * [k N / S, (k + 1) N / S) of the N voxels, offset splitmix64(sample_seed ^ k * 0x9E3779B97F4A7C15) % width, i.e. sorted,
+ * distinct, every point equally likely (hand_search.cpp:36-39 draws a uniform subset with pcl::RandomSample seeded by the
+ * clock: not reproducible, never part of parity); with N < S every point is a sample.  The list can be read back (samples_out).
+ * classify != 0: Learning::classify between the search and the handle search (needs agh_load_svm*); 0: every hypothesis
+ * is handed to the handle search (at most 8192).
+ * hands_out (optional, hands_cap records): the hands the handle search ran on, in list order -- inlier_idx_out indexes them.
+ * After the call the context holds the voxelised cloud and the search's results like after the separate calls
+ * (agh_get_cloud, agh_get_frames, agh_get_images ...). */
+typedef struct agh_localize_params
+{
+  int64_t size_left;       /* camera id of raw point i = (i >= size_left) */
+  int32_t dense;           /* as agh_preprocess */
+  int32_t classify;
+  double workspace[6];
+  double cell_size;        /* the reference passes 0.003 */
+  const int32_t* sample_idx;
+  int64_t n_samples;
+  uint64_t sample_seed;
+  int32_t min_inliers;     /* grasp_localizer.cpp:103: from the launch file */
+  int32_t reserved;
+  double min_length;       /* 0.005 */
+} agh_localize_params;
+typedef struct agh_localize_result
+{
+  int64_t n_voxels, n_hypotheses, n_hands, n_handles, n_inlier_idx;
+} agh_localize_result;
+int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
+  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
+
 /* The context's current cloud: packed xyz (3 floats per point) and camera ids; returns the number of points. */
 int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
 

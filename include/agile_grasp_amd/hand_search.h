@@ -20,6 +20,7 @@
 #include <ctime>
 #include <iostream>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../agh.h"
@@ -271,6 +272,64 @@ public:
       pts_cam_source_out((std::size_t) i) = cam[(std::size_t) i];
     }
     searched_n_ = nv;
+    return true;
+  }
+
+  /** The online chain of grasp_localizer.cpp:95-103 -- preprocessing, search, Learning::classify, HandleSearch -- as ONE device
+   *  call with one synchronisation (agh_localize): the raw capture goes in, the hands the classifier kept, the handles and
+   *  their inlier lists come out as records.  indices empty: num_samples indices are drawn ON THE DEVICE (one per stratum of
+   *  the voxelised cloud, seeded like randomSample: setSampleSeed or the clock).
+   *  @return false (after printing) on error */
+  bool localize(const PointCloud::Ptr& cloud_in, int size_left, const VectorXd& workspace, double cell_size,
+    const std::vector<int>& indices, const std::string& svm_filename, int min_inliers, double min_length,
+    std::vector<agh_hypothesis>& hands_out, std::vector<agh_handle>& handles_out, std::vector<std::int32_t>& inliers_out)
+  {
+    hands_out.clear();
+    handles_out.clear();
+    inliers_out.clear();
+    if (!ensureContext())
+      return false;
+    if (agh_load_svm_file(ctx_, svm_filename.c_str()) != AGH_OK)
+    {
+      std::cout << " Exception: " << agh_last_error(ctx_) << "\n";  // learning.cpp:187-191
+      return false;
+    }
+    agh_localize_params lp;
+    lp.size_left = (std::int64_t) size_left;
+    lp.dense = cloud_is_dense(*cloud_in) ? 1 : 0;
+    lp.classify = 1;
+    for (int i = 0; i < 6; i++)
+      lp.workspace[i] = workspace(i);
+    lp.cell_size = cell_size;
+    std::vector<std::int32_t> idx(indices.begin(), indices.end());
+    lp.sample_idx = idx.empty() ? nullptr : idx.data();
+    lp.n_samples = idx.empty() ? (std::int64_t) (num_samples_ < 0 ? 0 : num_samples_) : (std::int64_t) idx.size();
+    lp.sample_seed = sample_seed_set_ ? (std::uint64_t) sample_seed_ : (std::uint64_t) std::time(nullptr);
+    lp.min_inliers = min_inliers;
+    lp.reserved = 0;
+    lp.min_length = min_length;
+    const std::int64_t cap = lp.n_samples * 8 < 8192 ? lp.n_samples * 8 + 1 : 8193;
+    hands_out.resize((std::size_t) cap);
+    handles_out.resize((std::size_t) cap);
+    inliers_out.resize((std::size_t) cap);
+    last_samples_.assign((std::size_t) lp.n_samples, 0);
+    agh_localize_result res;
+    const std::int64_t n = (std::int64_t) cloud_in->size();
+    const int rc = agh_localize(ctx_, n > 0 ? &cloud_in->points[0].x : nullptr, (std::int64_t) sizeof(cloud_in->points[0]), n, &lp,
+      handles_out.data(), cap, inliers_out.data(), cap, hands_out.data(), cap, last_samples_.empty() ? nullptr : last_samples_.data(),
+      &res);
+    if (rc != AGH_OK)
+    {
+      hands_out.clear();
+      handles_out.clear();
+      inliers_out.clear();
+      fail("agh_localize");
+      return false;
+    }
+    hands_out.resize((std::size_t) res.n_hands);
+    handles_out.resize((std::size_t) res.n_handles);
+    inliers_out.resize((std::size_t) res.n_inlier_idx);
+    searched_n_ = res.n_voxels;
     return true;
   }
 

@@ -204,6 +204,69 @@ public:
     return handle_search.findHandles(hand_list, min_inliers, min_length);
   }
 
+  /** Additional: what GraspLocalizer::localizeGrasps runs per cloud (grasp_localizer.cpp:95-103) --
+   *      hands = localizeHands(cloud, size_left, indices, false, false);
+   *      antipodal_hands = predictAntipodalHands(hands, svm_file_name);
+   *      handles = findHandles(antipodal_hands, min_inliers, 0.005);
+   *  -- as ONE call into the device library with one synchronisation (agh_localize: no host round trip of the hypotheses
+   *  between the stages).  Same handles as the three calls on the same sample indices; with `indices` empty the samples are
+   *  drawn on the device (see HandSearch::localize).  The hands the classifier kept come back through `antipodal_hands`
+   *  (Handle::getHandList of every handle is that list).  With setFiltersBoundaries(true) -- a host-side filter BETWEEN the
+   *  search and the classifier -- the three separate calls are made. */
+  std::vector<Handle> localizeHandles(const PointCloud::Ptr& cloud_in, int size_left, const std::vector<int>& indices,
+    const std::string& svm_filename, int min_inliers, double min_length, std::vector<GraspHypothesis>* antipodal_hands = nullptr)
+  {
+    std::vector<Handle> handle_list;
+    if (antipodal_hands)
+      antipodal_hands->clear();
+    if (filters_boundaries_)
+    {
+      std::vector<GraspHypothesis> kept = predictAntipodalHands(localizeHands(cloud_in, size_left, indices, false, false), svm_filename);
+      if (antipodal_hands)
+        *antipodal_hands = kept;
+      return findHandles(kept, min_inliers, min_length);
+    }
+    if (size_left == 0 || !cloud_in || cloud_in->size() == 0)
+    {
+      std::cout << "Input cloud is empty!\n";
+      std::cout << size_left << std::endl;
+      return handle_list;
+    }
+    std::ifstream f(svm_filename.c_str());
+    if (!f.good())
+    {
+      std::cout << " Error: File " << svm_filename << " does not exist!\n";  // learning.cpp:172-178
+      return handle_list;
+    }
+    ensureSearch();
+    std::vector<agh_hypothesis> hands;
+    std::vector<agh_handle> handles;
+    std::vector<std::int32_t> idx;
+    if (!search_->localize(cloud_in, size_left, workspace_, 0.003, indices, svm_filename, min_inliers, min_length, hands, handles, idx))
+      return handle_list;
+    remove_nan_in_place(*cloud_in);  // localization.cpp:27 filters the caller's cloud in place
+    std::shared_ptr<std::vector<GraspHypothesis> > kept(new std::vector<GraspHypothesis>());
+    kept->reserve(hands.size());
+    for (std::size_t i = 0; i < hands.size(); i++)
+    {
+      kept->push_back(GraspHypothesis(hands[i], -1));
+      kept->back().setFullAntipodal(true);  // learning.cpp:240
+    }
+    std::cout << kept->size() << " antipodal hand configurations found\n";  // localization.cpp:153
+    if (antipodal_hands)
+      *antipodal_hands = *kept;
+    const std::shared_ptr<const std::vector<GraspHypothesis> > shared = kept;
+    for (std::size_t h = 0; h < handles.size(); h++)
+    {
+      const agh_handle& r = handles[h];
+      std::vector<int> in(idx.begin() + r.first_inlier, idx.begin() + r.first_inlier + r.n_inliers);
+      handle_list.push_back(Handle(r, shared, in));
+      std::cout << "handle found with " << in.size() << " inliers\n";  // handle_search.cpp:73
+    }
+    std::cout << "Handle Search\n " << handle_list.size() << " handles found\n";  // handle_search.cpp:82-84
+    return handle_list;
+  }
+
   /** the voxelised cloud and camera ids the last localizeHands searched (what the reference plots) */
   const PointCloud::Ptr& getSearchedCloud() const { return last_cloud_; }
   const VectorXi& getSearchedCamSource() const { return last_cam_; }

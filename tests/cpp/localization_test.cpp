@@ -65,6 +65,34 @@ int main(int argc, char** argv)
         (int) loc.getSearchedCamSource()((int) i));
     return 0;
   }
+  if (std::strcmp(argv[3], "chain") == 0)
+  {
+    // grasp_localizer.cpp:95-103 twice: the three calls of the reference's caller, then the one-call form; the two must print
+    // the same kept hands and the same handles
+    std::vector<GraspHypothesis> hands3 = loc.localizeHands(cloud, (int) size_left, idx, false, false);
+    std::vector<GraspHypothesis> kept3 = loc.predictAntipodalHands(hands3, argv[2]);
+    std::vector<Handle> handles3 = loc.findHandles(kept3, 2, 0.005);
+    std::vector<GraspHypothesis> kept1;
+    std::vector<Handle> handles1 = loc.localizeHandles(cloud, (int) size_left, idx, argv[2], 2, 0.005, &kept1);
+    for (int pass = 0; pass < 2; pass++)
+    {
+      const std::vector<GraspHypothesis>& kept = pass == 0 ? kept3 : kept1;
+      const std::vector<Handle>& handles = pass == 0 ? handles3 : handles1;
+      std::printf("CHAIN%d %zu %zu\n", pass == 0 ? 3 : 1, kept.size(), handles.size());
+      for (size_t i = 0; i < kept.size(); i++)
+        std::printf("K%d %.17g %.17g %.17g %.17g %d\n", pass == 0 ? 3 : 1, kept[i].getGraspSurface()(0), kept[i].getGraspBottom()(1),
+          kept[i].getApproach()(2), kept[i].getGraspWidth(), kept[i].isFullAntipodal() ? 1 : 0);
+      for (size_t i = 0; i < handles.size(); i++)
+      {
+        std::printf("G%d %zu %.17g %.17g %.17g %.17g %zu", pass == 0 ? 3 : 1, handles[i].getInliers().size(), handles[i].getAxis()(0),
+          handles[i].getCenter()(1), handles[i].getBinormal()(2), handles[i].getWidth(), handles[i].getHandList().size());
+        for (size_t k = 0; k < handles[i].getInliers().size(); k++)
+          std::printf(" %d", handles[i].getInliers()[k]);
+        std::printf("\n");
+      }
+    }
+    return 0;
+  }
   const bool antipodal = std::strcmp(argv[3], "antipodal") == 0;  // calculates_antipodal (antipodal_test.cpp:61)
   std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, antipodal, false);
   if (antipodal)

@@ -221,6 +221,31 @@ def test_localization_facade_matches_c_abi(tmp_path, svm_model):
 
 
 @pytest.mark.gpu
+def test_localization_one_call_chain_equals_the_three_calls(tmp_path):
+    """Localization::localizeHandles (agh_localize: grasp_localizer.cpp:95-103 as one device call) prints the same kept
+    hands and the same handles, inlier lists included, as localizeHands -> predictAntipodalHands -> findHandles."""
+    exe = _build_loc(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    vox, vcam = _preprocess_numpy(xyz, size_left, ws)
+    idx = np.sort(np.random.default_rng(1).permutation(len(vox))[:300]).astype(np.int32)
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, idx, ws, cams)
+    out = subprocess.run([exe, path, os.path.join(GOLD, "svm_032015_linear_20_20_same"), "chain"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    c3 = [l.split()[1:] for l in lines if l.startswith("CHAIN3")][0]
+    c1 = [l.split()[1:] for l in lines if l.startswith("CHAIN1")][0]
+    assert c3 == c1 and int(c3[0]) > 0
+    k3 = [l.split()[1:] for l in lines if l.startswith("K3 ")]
+    k1 = [l.split()[1:] for l in lines if l.startswith("K1 ")]
+    assert k3 == k1 and len(k3) == int(c3[0]) and all(r[-1] == "1" for r in k1)
+    g3 = [l.split()[1:] for l in lines if l.startswith("G3 ")]
+    g1 = [l.split()[1:] for l in lines if l.startswith("G1 ")]
+    assert g3 == g1 and len(g3) == int(c3[1])
+
+
+@pytest.mark.gpu
 def test_localization_facade_antipodal_labels(tmp_path):
     """src/tests/antipodal_test.cpp: localizeHands with calculates_antipodal = true (all-points normals pass + 20 degree
     antipodal test); the half / full labels must be the ones the C ABI gives for the same voxelised cloud."""

@@ -15,7 +15,7 @@ def _unit(v):
     return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
-def _crafted(seed, n_handles=5, per=14, clutter=60, ties=False, dead=0):
+def _crafted(seed, n_handles=5, per=14, clutter=60, ties=False, dead=0, nonunit=0):
     """Hands along a few straight handles (common axis and approach up to small noise, bottoms spread along the axis,
     one 3 cm hole in every second handle so that shortenHandle has something to cut) plus clutter."""
     from oracle import oracle_py as orc
@@ -52,6 +52,12 @@ def _crafted(seed, n_handles=5, per=14, clutter=60, ties=False, dead=0):
     hands = np.array(recs, orc.HYP_DTYPE)[rng.permutation(len(recs))]
     if dead:
         hands["width"][rng.choice(len(hands), dead, replace=False)] = -1.0  # already retired (handle_search.cpp:13)
+    if nonunit:
+        # hands a caller did not normalise: axis . axis = 0.81 fails the alignment test against ITSELF (handle_search.cpp:19-28
+        # makes no exception for j == i), so such a seed is not among its own inliers
+        sel = rng.choice(len(hands), nonunit, replace=False)
+        hands["axis"][sel] *= 0.9
+        hands["approach"][sel] *= 0.9
     return hands
 
 
@@ -62,6 +68,7 @@ def _cases():
         "crafted_dead": (_crafted(3, dead=25), 3, 0.005),
         "crafted_min5": (_crafted(4, per=9), 5, 0.02),
         "crafted_long": (_crafted(5, n_handles=2, per=120, clutter=10), 10, 0.005),
+        "crafted_nonunit": (_crafted(9, n_handles=6, per=16, nonunit=40), 3, 0.005),
         "none_found": (_crafted(6, n_handles=0, clutter=80), 3, 0.005),
         "single": (_crafted(7, n_handles=0, clutter=1), 1, 0.005),
         "empty": (_crafted(8, n_handles=0, clutter=0), 3, 0.005),

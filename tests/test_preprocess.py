@@ -119,3 +119,109 @@ def test_preprocess_then_search_equals_oracle_chain():
     for f in ("sample", "orientation", "cam_source", "n_in_box", "axis", "approach", "binormal", "bottom", "surface",
               "width"):
         assert np.array_equal(got[f], rh[f]), f
+
+
+HYP_FIELDS = ("sample", "orientation", "cam_source", "n_in_box", "half_antipodal", "full_antipodal", "finger_index",
+              "depth_index", "svm_keep", "axis", "approach", "binormal", "bottom", "surface", "width")
+HANDLE_FIELDS = ("axis", "center", "approach", "binormal", "hands_center", "width", "n_inliers", "first_inlier")
+
+
+def _four_calls(ctx, rc, samples, classify, min_inliers=2):
+    ctx.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    h = ctx.find_hands(samples)
+    if classify:
+        k = ctx.classify().astype(bool)
+        h = h.copy()
+        h["svm_keep"] = k
+        h = h[k]
+    hd, idx = ctx.find_handles(h, min_inliers, 0.005)
+    return h, hd, idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classify", [True, False])
+def test_localize_one_call_equals_the_four_call_chain_and_the_oracle(svm_model, classify):
+    """agh_localize (grasp_localizer.cpp:95-103 as one call, one synchronisation, counts kept on the device) against the four
+    separate entry points AND against the oracle's chain preprocess -> find_hands -> classify -> find_handles, through the
+    handles, every field exact.  Clouds of different sizes alternate through ONE context (the speculative voxel bitmap, the
+    bound-sized launches and the device-side cloud count all change from call to call); explicit and device-drawn samples."""
+    from agile_grasp_amd import binding, synthetic
+    from oracle import oracle_py as orc
+
+    w, rho = svm_model
+    # (few objects: the small tables of these sizes, crowded with the default fourteen, pile surfaces into neighbourhoods
+    # beyond the Taubin kernels' capacity)
+    raws = [synthetic.make_raw_cloud(120_000, 7, n_objects=4), synthetic.make_raw_cloud(60_000, 8, n_objects=2),
+            synthetic.make_raw_cloud(200_000, 9, n_objects=6)]
+    one = binding.Context(raws[0].cam_origins)
+    chain = binding.Context(raws[0].cam_origins)
+    for c in (one, chain):
+        c.load_svm(w, rho)
+    n_handles = 0
+    for it in range(7):
+        rc = raws[it % 3]
+        nv_ref = chain.preprocess(rc.xyz, rc.size_left, rc.workspace)
+        if it % 2 == 0:
+            samples = np.sort(np.random.default_rng(it).permutation(nv_ref)[:600]).astype(np.int32)
+            got = one.localize(rc.xyz, rc.size_left, rc.workspace, samples=samples, classify=classify, min_inliers=2)
+        else:
+            got = one.localize(rc.xyz, rc.size_left, rc.workspace, n_samples=600, sample_seed=40 + it, classify=classify,
+                               min_inliers=2)
+            samples = got["samples"]
+            assert np.array_equal(samples, binding.draw_samples(nv_ref, 600, 40 + it))
+            assert np.all(np.diff(samples) > 0) and samples[0] >= 0 and samples[-1] < nv_ref
+        assert got["n_voxels"] == nv_ref
+        h, hd, idx = _four_calls(chain, rc, samples, classify)
+        assert got["n_hypotheses"] == chain.last_n and len(got["hands"]) == len(h) and len(h) > 0
+        for f in HYP_FIELDS:
+            assert np.array_equal(got["hands"][f], h[f]), f
+        assert len(got["handles"]) == len(hd) and np.array_equal(got["inlier_idx"], idx)
+        n_handles += len(hd)
+        for f in HANDLE_FIELDS:
+            assert np.array_equal(got["handles"][f], hd[f]), f
+        if it == 0:  # ... and the chain itself against the oracle
+            v, cam = orc.preprocess(rc.xyz, rc.size_left, rc.workspace)
+            r = orc.find_hands(orc.default_params(rc.cam_origins), v, cam, samples, want_images=True)
+            oh = r["hyps"]
+            if classify:
+                keep, _ = orc.classify(r["images"], w, rho)
+                oh = oh[np.asarray(keep, bool)]
+            ohd, oidx = orc.find_handles(oh, 2, 0.005)
+            for f in ("sample", "orientation", "axis", "approach", "binormal", "bottom", "surface", "width"):
+                assert np.array_equal(got["hands"][f], oh[f]), f
+            assert np.array_equal(got["inlier_idx"], oidx)
+            for f in HANDLE_FIELDS:
+                assert np.array_equal(got["handles"][f], ohd[f]), f
+        # the context is left as after the separate calls
+        xyz_v, cam_v = one.cloud()
+        xyz_c, cam_c = chain.cloud()
+        assert np.array_equal(xyz_v, xyz_c) and np.array_equal(cam_v, cam_c)
+    assert n_handles > 0
+
+
+@pytest.mark.gpu
+def test_localize_edge_cases(svm_model):
+    from agile_grasp_amd import binding, synthetic
+
+    rc = synthetic.make_raw_cloud(60_000, 7)
+    ctx = binding.Context(rc.cam_origins)
+    with pytest.raises(binding.AghError) as e:  # classification asked for, no model
+        ctx.localize(rc.xyz, rc.size_left, rc.workspace, n_samples=10)
+    assert e.value.code == binding.AGH_ERR_NO_SVM
+    ctx.load_svm(*svm_model)
+    nv = ctx.localize(rc.xyz, rc.size_left, rc.workspace, n_samples=0)["n_voxels"]  # no samples: an empty result, the cloud is set
+    assert nv > 0 and ctx.cloud()[0].shape[0] == nv
+    for bad in (nv, -1):  # a sample outside the voxelised cloud is found on the device (the host does not know the count yet)
+        with pytest.raises(binding.AghError) as e:
+            ctx.localize(rc.xyz, rc.size_left, rc.workspace, samples=np.array([3, bad], np.int32))
+        assert e.value.code == binding.AGH_ERR_INVALID_ARGUMENT
+    got = ctx.localize(rc.xyz, rc.size_left, rc.workspace, n_samples=64, sample_seed=5)  # ... and the context still works
+    assert got["n_hypotheses"] > 0
+    # fewer points than samples: every point is a sample, the rest of the list is skipped without an error
+    tiny = rc.xyz[:40]
+    got = ctx.localize(tiny, min(rc.size_left, 40), rc.workspace, n_samples=64, classify=False)
+    n = got["n_voxels"]
+    assert 0 < n <= 40 and np.array_equal(got["samples"][:n], np.arange(n)) and np.all(got["samples"][n:] == -(1 << 31))
+    # an empty capture
+    got = ctx.localize(np.zeros((0, 3), np.float32), 0, rc.workspace, n_samples=16)
+    assert got["n_voxels"] == 0 and got["n_hypotheses"] == 0 and len(got["handles"]) == 0
