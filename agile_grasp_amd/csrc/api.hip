@@ -1400,6 +1400,8 @@ __global__ __launch_bounds__(1024) void k_compact_kept(const agh_hypothesis* __r
   int64_t cap_in, int use_keep, agh_hypothesis* __restrict__ out, int out_cap, int* __restrict__ n_out,
   agh_hypothesis* __restrict__ host_out, int host_cap, int* __restrict__ host_counts, const int32_t* __restrict__ flags)
 {
+  constexpr int kList = 8192;  // (the handle search takes no more)
+  __shared__ int src[kList];   // position in the output -> position in the input
   __shared__ int wsum[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1422,28 +1424,30 @@ __global__ __launch_bounds__(1024) void k_compact_kept(const agh_hypothesis* __r
       tot += wsum[w];
     }
     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep)
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(in + i);
-      if (pos < out_cap)
-        for (int q = 0; q < 10; q++)
-          reinterpret_cast<uint4*>(out + pos)[q] = src[q];
-      if (host_out && pos < host_cap)
-        for (int q = 0; q < 10; q++)
-          reinterpret_cast<uint4*>(host_out + pos)[q] = src[q];
-    }
+    if (keep && pos < kList)
+      src[pos] = (int) i;
     __syncthreads();
     if (tid == 0)
       carry += tot;
     __syncthreads();
   }
+  const int K = carry, kw = min(K, min(out_cap, kList));
+  // ten threads per record, sixteen bytes each: every record leaves as one 160-byte run, to the device and to the host
+  for (int t = tid; t < kw * 10; t += 1024)
+  {
+    const int k = t / 10, part = t - 10 * k;
+    const uint4 v = reinterpret_cast<const uint4*>(in + src[k])[part];
+    reinterpret_cast<uint4*>(out + k)[part] = v;
+    if (host_out && k < host_cap)
+      reinterpret_cast<uint4*>(host_out + k)[part] = v;
+  }
   if (tid == 0)
   {
-    *n_out = carry;
+    *n_out = K;
     if (host_counts)
     {
       host_counts[4] = (int) n;
-      host_counts[5] = carry;
+      host_counts[5] = K;
       host_counts[6] = flags[0] | (*n_in > cap_in ? 2 : 0);
     }
   }

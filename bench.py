@@ -272,6 +272,79 @@ def host_api_c_extra(sc, calls: int):
             return {"error": str(e)[-300:]}
 
 
+def sq_issue_figures(kernel: str):
+    """Issue-slot figures of one kernel from the committed SQ-counter pass of this workload (profiles/rNN_c2_sq_counters.txt:
+    one `rocprofv3 --pmc SQ_*` run of `bench.py --config C2`, per-dispatch averages per shader engine, scripts/pmc_table.py).
+    Static like roofline.traffic: counters cannot be collected inside the timed run."""
+    import hashlib
+
+    for name in ("r05_c2_sq_counters.txt", "r04_c2_sq_counters.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        blob = open(path, "rb").read()
+        cur, tab = None, {}
+        for line in blob.decode().splitlines():
+            if not line.startswith(" "):
+                cur = line.strip()
+            elif cur is not None and cur.startswith(kernel):
+                k, v = line.split()
+                tab[k] = float(v)
+        need = ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
+        if not all(k in tab for k in need) or tab["SQ_WAVES"] <= 0 or tab["SQ_WAVE_CYCLES"] <= 0:
+            continue
+        waves_per_simd = 3  # three 256-thread work-groups per CU (LDS), a wave of each on every SIMD
+        return {"valu_insts_per_wave": tab["SQ_INSTS_VALU"] / tab["SQ_WAVES"], "waves": int(tab["SQ_WAVES"]) * 32,
+                "wave_issuing_frac": tab["SQ_ACTIVE_INST_ANY"] / tab["SQ_WAVE_CYCLES"],
+                "wave_valu_frac": tab["SQ_ACTIVE_INST_VALU"] / tab["SQ_WAVE_CYCLES"],
+                "resident_waves_per_simd": waves_per_simd,
+                "simd_issue_frac": waves_per_simd * tab["SQ_ACTIVE_INST_ANY"] / tab["SQ_WAVE_CYCLES"],
+                "simd_valu_frac": waves_per_simd * tab["SQ_ACTIVE_INST_VALU"] / tab["SQ_WAVE_CYCLES"],
+                "source": f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (SQ counters of a separate "
+                          "rocprofv3 --pmc pass over this workload; simd_* = resident waves per SIMD x the fraction of a wave's "
+                          "lifetime it issues [any / VALU] instructions: ~1 means the SIMD's issue port is saturated)"}
+    return None
+
+
+def pipeline_extra(steps: int):
+    """grasp_localizer.cpp:95-103 per raw capture, host buffers in and out: the four entry points (preprocess, find_hands, classify,
+    find_handles: four synchronisations) against agh_localize (one call, one synchronisation), same samples, same handles."""
+    from agile_grasp_amd import binding, synthetic
+
+    rc = synthetic.make_raw_cloud(700_000, 21)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
+    ctx = binding.Context(rc.cam_origins)
+    ctx.load_svm(z["w"], float(z["rho"]))
+    nv = ctx.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    samples = np.sort(np.random.default_rng(5).permutation(nv)[:2000]).astype(np.int32)
+
+    def four():
+        t0 = time.perf_counter()
+        ctx.preprocess(rc.xyz, rc.size_left, rc.workspace)
+        h = ctx.find_hands(samples)
+        k = ctx.classify().astype(bool)
+        hd, _ = ctx.find_handles(h[k], 3, 0.005)
+        return time.perf_counter() - t0, len(h), int(k.sum()), len(hd)
+
+    def one():
+        t0 = time.perf_counter()
+        r = ctx.localize(rc.xyz, rc.size_left, rc.workspace, samples=samples, classify=True, min_inliers=3, min_length=0.005)
+        return time.perf_counter() - t0, r["n_hypotheses"], len(r["hands"]), len(r["handles"])
+
+    for _ in range(3):
+        four()
+    t4 = [four() for _ in range(steps)]
+    for _ in range(3):
+        one()
+    t1 = [one() for _ in range(steps)]
+    assert t4[-1][1:] == t1[-1][1:], (t4[-1], t1[-1])
+    return {"workload": "raw two-view capture, 699999 points -> 3 mm voxels -> 2000-sample search -> HOG + SVM -> handle search "
+                        "(grasp_localizer.cpp:95-103), host buffers in and out",
+            "voxels": int(nv), "hypotheses": int(t1[-1][1]), "svm_kept": int(t1[-1][2]), "handles": int(t1[-1][3]),
+            "four_calls_ms": statistics.median(t[0] for t in t4) * 1e3, "agh_localize_ms": statistics.median(t[0] for t in t1) * 1e3,
+            "agh_localize_min_ms": min(t[0] for t in t1) * 1e3, "calls": steps}
+
+
 def settle(ctx, step, fence):
     """Two untimed steps on every rank before anything is measured.  A context starts with the launches of the larger
     capacity classes switched off (they are empty for voxelised clouds); the first step of a cloud that needs them reports
@@ -836,6 +909,7 @@ def main():
                         traffic_src = (f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (separate rocprofv3 --pmc "
                                        "FETCH_SIZE / WRITE_SIZE passes over this workload, gfx950 corrections applied); not measured in this run")
                         break
+        issue = sq_issue_figures("k_hand_sweep") if not distributed else None
         # whole-path algorithmic bytes (B_alg of BASELINE.md section 4), of this rank's share
         b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_local_hyp + (14112 if classify else 0)
         # --shard clouds (the default; N = 1 is its first member: one cloud on one GPU): one more cloud per GPU -- per-GPU work
@@ -865,9 +939,12 @@ def main():
                                    f"{'rand50' if normals_mode else 'deterministic'} normals{', + HOG/linear SVM' if classify else ''}",
                        "scene_variant": "tilted", "points": sc.n, "samples": S, "hypotheses": int(total_hyp), "parallelism": par},
             "samples_per_s": S * (world if by_cloud else 1) * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # "bound": what the counters say limits the kernel -- its SIMDs' instruction issue, not HBM (traffic is BELOW the
+            # algorithmic bytes: the cloud is cache resident).  achieved / peak / frac stay the contract's HBM figures; the
+            # issue-slot figures beside them show what an instruction cut can still buy.
+            "roofline": {"bound": "valu-issue" if issue else "hbm", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "issue": issue,
                          "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
                          "launches_timed": sweep_timed, "launches_timed_note": "HIP events around every fourth k_hand_sweep "
                          "launch of the timed region (two event records per step cost 6 us of a 0.24 ms step)",
@@ -916,6 +993,7 @@ def main():
                                                             "C2u (axis-aligned) in the reference's production mode")
             res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
             res["host_api_c"] = host_api_c_extra(sc, max(20, args.steps))
+            res["pipeline"] = pipeline_extra(max(20, args.steps))
             # the other single-GPU BASELINE configs, on the same clock as the headline
             z = np.load(os.path.join(ROOT, "tests", "golden", "svm_weights.npz"))
             res["c3"] = single_cloud_extra(args, dev, stream, "C2", normals_mode,

@@ -24,6 +24,11 @@ def gpu_chain():
     hd, idx = ctx.find_handles(h[k], 3, 0.005); t.append(time.perf_counter())
     return h, k, hd, idx, np.diff(t)
 
+def gpu_one_call():
+    t0 = time.perf_counter()
+    r = ctx.localize(rc.xyz, rc.size_left, rc.workspace, samples=samples, classify=True, min_inliers=3, min_length=0.005)
+    return r, time.perf_counter() - t0
+
 for _ in range(3):
     gpu_chain()
 K = 20
@@ -32,6 +37,19 @@ for _ in range(K):
     h, k, hd, idx, dt = gpu_chain()
     acc += dt
 acc /= K
+for _ in range(3):
+    gpu_one_call()
+one = []
+for _ in range(K):
+    r1, dt1 = gpu_one_call()
+    one.append(dt1)
+one_ms = float(np.median(one)) * 1e3
+assert len(r1["handles"]) == len(hd) and np.array_equal(r1["inlier_idx"], idx) and r1["n_hypotheses"] == len(h)
+drawn = []
+for _ in range(K):  # the sample list drawn on the device instead of uploaded
+    t0 = time.perf_counter()
+    ctx.localize(rc.xyz, rc.size_left, rc.workspace, n_samples=2000, sample_seed=5, classify=True)
+    drawn.append(time.perf_counter() - t0)
 t0 = time.perf_counter()
 v, cam = orc.preprocess(rc.xyz, rc.size_left, rc.workspace); t1_pre = time.perf_counter()
 THREADS = int(os.environ.get("PIPELINE_BENCH_CPU_THREADS", "32"))  # the port scales to a few dozen threads, not to 256
@@ -47,6 +65,8 @@ print(json.dumps({
     "svm_kept": int(k.sum()), "handles": int(len(hd)),
     "gpu_ms": {"preprocess": acc[0] * 1e3, "find_hands": acc[1] * 1e3, "classify": acc[2] * 1e3, "find_handles": acc[3] * 1e3,
                "total": acc.sum() * 1e3},
+    "gpu_one_call_ms": {"agh_localize": one_ms, "min": float(np.min(one)) * 1e3, "device_drawn_samples": float(np.median(drawn)) * 1e3,
+                        "note": "the same chain as ONE call with one synchronisation (agh_localize), same samples, same handles"},
     "cpu_oracle_ms": {"preprocess": t_pre * 1e3, "find_hands": (t2 - t1) * 1e3, "classify": (t3 - t2) * 1e3,
                       "find_handles": (t4 - t3) * 1e3, "total": (t_pre + (t4 - t1)) * 1e3,
                       "note": f"the whole chain on the host: preprocessing and handle search on one thread, search and "
