@@ -735,27 +735,33 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     return;
   // ---- pass B: grasp parameters, box, antipodal counts, image (rotating_hand.cpp:111-170) ----
   const int cam_s = cam_source ? (cam_source[samples[s]] & 1) : 0;  // hands_cam_source(i) = pts_cam_source(indices[i])
-  double wmin_w[2] = { 100000.0, 100000.0 }, wmax_w[2] = { -100000.0, -100000.0 };
-  int nbox_w[2] = { 0, 0 }, numl_w[2] = { 0, 0 }, numr_w[2] = { 0, 0 };
-  double surf_w[2][3], horpos_w[2];
-  // max of y over ALL cropped points, for grasp_bottom (finger_hand.cpp:135): only an orientation with a hand needs it, so it
-  // is taken here, where such an orientation walks its points anyway, and not in pass A
-  double ymax_w[2] = { -INFINITY, -INFINITY };
-  bool posx_w[2] = { false, false };
-  for (int oo = 0; oo < 2; oo++)
+  // Few orientations have a hand (815 of C2's 9354), and a work-group that has one used to leave its points to ONE wave while
+  // three idled -- on exactly the work-groups that run longest.  Every wave now takes a quarter of the tile for each such
+  // orientation; its extrema and counts meet in LDS (PassBPart, on top of the finger phase's suffix table, dead by now) and the
+  // orientation's own wave combines them for the record.  ymax: the max of y over ALL cropped points, for grasp_bottom
+  // (finger_hand.cpp:135) -- only an orientation with a hand needs it, so it is taken here and not in pass A.
+  struct PassBPart
   {
-    const OriState& O = ori[wave + 4 * oo];
+    double wmin, wmax, ymax;
+    int nbox, numl, numr, pad;
+  };
+  static_assert(sizeof(PassBPart) * 32 <= sizeof(suf_s), "the partial results live on the suffix table");
+  PassBPart* const part = reinterpret_cast<PassBPart*>(&suf_s[0][0]);  // [wave][orientation]
+  if (lane < 8)
+    part[wave * 8 + lane] = PassBPart{ 100000.0, -100000.0, -INFINITY, 0, 0, 0, 0 };  // (a wave reads back only what it wrote)
+  // surface point and image orientation of orientation o (rotating_hand.cpp:118-121, learning.cpp:382-383)
+  auto ori_consts = [&](int o, double (&surf)[3], bool& pos_x, double& hor_pos) {
+    const OriState& O = ori[o];
     const int e = O.e < 0 ? 0 : O.e;
-    const double hor_pos = (G.hand_outer_diameter / 2.0) + (G.fs[e] / 1);  // finger_hand.cpp:127-132, one-hot hand_
+    hor_pos = (G.hand_outer_diameter / 2.0) + (G.fs[e] / 1);  // finger_hand.cpp:127-132, one-hot hand_
     double s2c[3];
     for (int i = 0; i < 3; i++)
     {
-      surf_w[oo][i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;  // rotating_hand.cpp:118-121
-      s2c[i] = (surf_w[oo][i] + F.sample[i]) - G.cam_origin[cam_s][i];  // learning.cpp:382-383
+      surf[i] = (O.T[i][0] * hor_pos + O.T[i][1] * O.ymin) + O.T[i][2] * 0.0;
+      s2c[i] = (surf[i] + F.sample[i]) - G.cam_origin[cam_s][i];
     }
-    posx_w[oo] = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
-    horpos_w[oo] = hor_pos;
-  }
+    pos_x = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
+  };
   if (any_hand)
   {
     const bool refill = ntiles > 1;  // a single tile is still resident in LDS
@@ -782,9 +788,8 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
       }
       else if (refill)
         nc = gather_tile(all_done);
-      for (int oo = 0; oo < 2; oo++)
+      for (int o = 0; o < 8; o++)
       {
-        const int o = wave + 4 * oo;
         const OriState& O = ori[o];
         if (O.rejected || !O.has_hand)
           continue;
@@ -793,21 +798,23 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
         const double left = G.fs[e], right = G.fs[10 + e];
         const double box_y = G.boxy[last];
         const double bite = G.init_bite;
-        const double sfx = surf_w[oo][0], sfy = surf_w[oo][1];
-        const bool pos_x = posx_w[oo];
-        double wmin = wmin_w[oo], wmax = wmax_w[oo], ymax = ymax_w[oo];
+        double surf[3], hor_pos_;
+        bool pos_x;
+        ori_consts(o, surf, pos_x, hor_pos_);
+        const double sfx = surf[0], sfy = surf[1];
+        double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
         int nbox = 0, numl = 0, numr = 0;
-        for (int t0 = lane; t0 < nc; t0 += 256)
+        for (int t0 = tid; t0 < nc; t0 += 1024)
         {
           // four independent points per lane in stages (straight-line code: the two exactly-rounded divisions of each point
           // overlap with those of the others; the image update is the only predicated part)
-          const bool full = (t0 - lane) + 256 <= nc;
+          const bool full = (t0 - tid) + 1024 <= nc;
           double xr[4], yr[4];
           bool act[4];
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
-            const int t = t0 + 64 * u;
+            const int t = t0 + 256 * u;
             act[u] = full || t < nc;
             const double2 p = pts[act[u] ? t : 0];
             xr[u] = cs * p.x + ms * p.y;
@@ -839,12 +846,12 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
             if (inbox[u])
             {
               if (TRAIN)  // pid = (index << 1) | camera
-                atomicOr(&img[o + 8 * (int) (pid[t0 + 64 * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
+                atomicOr(&img[o + 8 * (int) (pid[t0 + 256 * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
               else
                 atomicOr(&img[o][bit[u] >> 5], 1u << (bit[u] & 31));
               if (NORMALS)
               {
-                const double* nn = normals + 3 * (int64_t) (pid[t0 + 64 * u] >> 1);
+                const double* nn = normals + 3 * (int64_t) (pid[t0 + 256 * u] >> 1);
                 const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
                 const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
                 const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
@@ -855,22 +862,33 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
             }
           }
         }
-        wmin_w[oo] = wmin;
-        wmax_w[oo] = wmax;
-        ymax_w[oo] = ymax;
-        nbox_w[oo] += nbox;
-        numl_w[oo] += numl;
-        numr_w[oo] += numr;
+        // this wave's share of the tile, folded into its slot (the tiles of a neighbourhood come one after the other)
+        wmin = wave_min_f64(wmin);
+        wmax = wave_max_f64(wmax);
+        ymax = wave_max_f64(ymax);
+        nbox = wave_sum_i32(nbox);
+        if (NORMALS)
+        {
+          numl = wave_sum_i32(numl);
+          numr = wave_sum_i32(numr);
+        }
+        if (lane == 0)
+        {
+          PassBPart& P = part[wave * 8 + o];
+          P.wmin = min_f64_raw(P.wmin, wmin);
+          P.wmax = max_f64_raw(P.wmax, wmax);
+          P.ymax = max_f64_raw(P.ymax, ymax);
+          P.nbox += nbox;
+          P.numl += numl;
+          P.numr += numr;
+        }
       }
       if (!refill || all_done)
         break;
       next_tile();
     }
   }
-  // (no work-group barrier here either: a wave writes the records and image planes of its own two orientations)
-#ifdef AGH_DEBUG_HOOKS
-  __syncthreads();
-#endif
+  __syncthreads();  // every wave's share of pass B (partials, image bits) is in LDS
   AGH_STAMP(5);
   if (debug_stop == 5)
     return;
@@ -885,15 +903,28 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     memset(&h, 0, sizeof(h));
     h.sample = s;
     h.orientation = o;
-    const double wmin = wave_min_f64(wmin_w[oo]), wmax = wave_max_f64(wmax_w[oo]), ymax = wave_max_f64(ymax_w[oo]);
-    const int nbox = wave_sum_i32(nbox_w[oo]), numl = wave_sum_i32(numl_w[oo]), numr = wave_sum_i32(numr_w[oo]);
+    double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
+    int nbox = 0, numl = 0, numr = 0;
+    for (int w = 0; w < 4; w++)
+    {
+      const PassBPart P = part[w * 8 + o];
+      wmin = min_f64_raw(wmin, P.wmin);
+      wmax = max_f64_raw(wmax, P.wmax);
+      ymax = max_f64_raw(ymax, P.ymax);
+      nbox += P.nbox;
+      numl += P.numl;
+      numr += P.numr;
+    }
+    double surf[3], hor_pos;
+    bool pos_x_;
+    ori_consts(o, surf, pos_x_, hor_pos);
     for (int i = 0; i < 3; i++)
     {
       h.axis[i] = F.axis[i];
       h.approach[i] = O.approach[i];
       h.binormal[i] = O.binormal[i];
-      h.bottom[i] = ((O.T[i][0] * horpos_w[oo] + O.T[i][1] * ymax) + O.T[i][2] * 0.0) + F.sample[i];  // rotating_hand.cpp:120-122,153-154
-      h.surface[i] = surf_w[oo][i] + F.sample[i];
+      h.bottom[i] = ((O.T[i][0] * hor_pos + O.T[i][1] * ymax) + O.T[i][2] * 0.0) + F.sample[i];  // rotating_hand.cpp:120-122,153-154
+      h.surface[i] = surf[i] + F.sample[i];
     }
     h.width = wmax - wmin;
     h.cam_source = cam_s;
