@@ -897,7 +897,7 @@ def main():
         if not distributed:
             import hashlib
 
-            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tf):
                     try:

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 for cfg in C2 C3 C4; do
   rm -rf /tmp/kt_$cfg
   # (--batch-clouds 0: every k_hand_sweep launch of the trace is the single-cloud launch the bench line's roofline describes)
@@ -55,6 +55,10 @@ timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TA
 timeout 300 python scripts/preprocess_bench.py 2> /dev/null | grep raw_points > $OUT/${TAG}_preprocess.jsonl
 timeout 300 python scripts/handles_bench.py 2> /dev/null | grep '"hands"' > $OUT/${TAG}_handles.jsonl
 timeout 300 python scripts/pipeline_bench.py 2> /dev/null | tail -1 > $OUT/${TAG}_pipeline.json
+# the one-call chain's kernel budget (agh_localize in a loop under rocprofv3 --kernel-trace)
+timeout 400 bash scripts/localize_trace.sh ${TAG}_localize > $OUT/${TAG}_localize_kernels_per_call.txt 2>&1
+cp $R/gpurun_out/${TAG}_localize_kernel_trace_stats.csv $OUT/ 2> /dev/null
+cd $R
 timeout 600 python scripts/train_bench.py 2> /dev/null | grep '"instances"' > $OUT/${TAG}_training.jsonl
 rm -rf /tmp/kt_train
 (cd /tmp && TRAIN_BENCH_CPU_N=300 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_train -o kt -- python $R/scripts/train_bench.py > /tmp/kt_train.log 2>&1)
