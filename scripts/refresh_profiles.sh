@@ -36,6 +36,7 @@ q=$(find /tmp/pmc_sq -name "*.db" | head -1); [ -n "$q" ] && python $R/scripts/p
 f=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
 [ -n "$f" ] && [ -n "$w" ] && python $R/scripts/pmc_traffic.py $f $w C2:det $OUT/${TAG}_pmc_traffic.json > /dev/null
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null   # bench.py reads roofline.traffic from here
+cp $OUT/${TAG}_c2_sq_counters.txt $R/profiles/${TAG}_c2_sq_counters.txt 2>/dev/null   # ... and roofline.issue from here
 cd $R
 timeout 400 python bench.py --config C2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_c2.json 2> /dev/null   # the driver's own command line
 # the multi-GPU line as far as one GPU can show it: the sharded entry points on an RCCL communicator of ONE rank (--dist), first
