@@ -806,9 +806,11 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
   const int* __restrict__ h_n, const int* __restrict__ inlier_idx, const HandleCounts* __restrict__ counts,
   agh_handle* __restrict__ out, agh_handle* __restrict__ host_out, int host_cap)
 {
-  const int h = blockIdx.x, lane = threadIdx.x;
-  if (h >= counts->n_handles)
-    return;
+  // (one wave per handle; a grid smaller than the bound on the handles -- agh_localize -- strides over them)
+  const int lane = threadIdx.x;
+  const int n_handles = counts->n_handles;
+  for (int h = blockIdx.x; h < n_handles; h += gridDim.x)
+  {
   const int n = h_n[h];
   const int* in = inlier_idx + h_first[h];
   // axis_mat * axis_mat^T in the oracle's LaneSum64 order (handle.cpp:14-20)
@@ -917,6 +919,7 @@ __global__ __launch_bounds__(64) void k_handle_build(const agh_hypothesis* __res
     if (host_out && h < host_cap)
       host_out[h] = hd;
   }
+  }  // (the handles of this wave)
 }
 
 // with_sequential: also launch k_handle_greedy, which does the search when k_handle_batch declines it on the device (a row of the
@@ -954,7 +957,7 @@ int handle_search(Ctx* c, int64_t H, double x1, double x2, int min_inliers, doub
         c->d_h_n, c->d_h_idx, reinterpret_cast<HandleCounts*>(c->d_h_counts), hm.idx, hm.idx_cap, hm.counts, d_H);
   }
   // (a handle holds at least min_inliers >= 1 hands: H bounds the handles too)
-  hipLaunchKernelGGL(k_handle_build, dim3(Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
+  hipLaunchKernelGGL(k_handle_build, dim3(d_H ? std::min(Hi, 1024) : Hi), dim3(64), 0, st, (const agh_hypothesis*) c->d_h_hands,
     (const int*) c->d_h_first, (const int*) c->d_h_n, (const int*) c->d_h_idx,
     (const HandleCounts*) reinterpret_cast<HandleCounts*>(c->d_h_counts), c->d_h_handles, hm.handles, hm.handle_cap);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
