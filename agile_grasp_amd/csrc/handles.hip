@@ -17,6 +17,8 @@
 //   K5c k_handle_build   Handle::Handle per accepted handle, one wave each.
 #include "agh_internal.h"
 
+#include <type_traits>
+
 namespace agh
 {
 
@@ -452,7 +454,11 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
   __shared__ unsigned long long rowm[kBatch][128];  // row & availability of the round's candidates
   __shared__ unsigned imask[kBatch];
   __shared__ int c_open[kBatch], c_h[kBatch], c_base[kBatch];
-  __shared__ unsigned short mlist[kBatch][64];
+  // a candidate's members: up to kMaxRow = 128 hands, two per lane (element p of a wave's lists lives in lane p & 63, slot p >> 6).
+  // Rows of more than 64 hands used to send the WHOLE search to the sequential kernel (5 ms for the 3 260-hand stress case).
+  constexpr int kMaxRow = 128, kE = kMaxRow / 64;
+  __shared__ unsigned short mlist[kBatch][kMaxRow];  // members in bit order; reused for the sorted member list
+  __shared__ double sdist[kBatch][kMaxRow];          // the members' distances along the seed's axis, sorted
   __shared__ int n_cand, s_nh, s_nidx, s_maxrow, tot_nh, tot_nidx;
   // per accepted handle, in commit order: seed, offset of its list in tmp_idx, length; then the handles by ascending seed
   // (in LDS: the epilogue's rank and prefix loops would otherwise be chains of dependent global loads)
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
     for (int k = tid; k < H * W; k += 1024)
       lbits[k] = bits[k];
   __syncthreads();
-  if (s_maxrow > 64)  // a row longer than a wave: the sequential kernel (launched next) does this search
+  if (s_maxrow > kMaxRow)  // a row longer than two waves' worth: the sequential kernel (launched next) does this search
   {
     if (tid == 0)
     {
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
     AGH_HSTAMP(1);
     // ---- evaluation: wave k takes candidate k against the availability as it stands now ----
     unsigned long long m0 = 0ull, m1 = 0ull;
-    int kept = 0, out_j = 0;
+    int kept = 0;
     bool accept = false;
     if (wave < nc)
     {
@@ -590,14 +596,14 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
         rowm[wave][lane] = m0 | (lane == (i >> 6) ? (1ull << (i & 63)) : 0ull);
       if (64 + lane < W)
         rowm[wave][64 + lane] = m1 | (64 + lane == (i >> 6) ? (1ull << (i & 63)) : 0ull);
-      const int n = wave_allsum_i32(__popcll(m0) + __popcll(m1));  // <= 64 (s_maxrow)
+      const int n = wave_allsum_i32(__popcll(m0) + __popcll(m1));  // <= kMaxRow (s_maxrow)
       accept = n >= min_inliers;  // handle_search.cpp:47-48
       if (accept)
       {
         // one inlier per lane.  The holder of bit b of word w is member number base(w) + popcount(bits below b): it drops its
         // index into the wave's list at that position, and lane e picks up entry e (a scalar walk over the set bits, n steps
         // per seed, kept the CU's one scalar unit busy for all sixteen waves: the evaluation phase was 2.6 us)
-        int my_j = 0, cnt = 0;
+        int cnt = 0;
         for (int half = 0; half < (W > 64 ? 2 : 1); half++)
         {
           const unsigned long long mm = half ? m1 : m0;
@@ -615,44 +621,80 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
           }
         }
         AGH_WAVE_SYNC();
-        my_j = lane < n ? (int) mlist[wave][lane] : 0;
-        double de = 0.0;
-        if (lane < n)
-        {
-          double ia[3], d[3];
-          for (int r = 0; r < 3; r++)
+        // (E = slots per lane: 1 when no row of this search holds more than 64 hands -- the common case pays for one)
+        auto evaluate = [&](auto Ec) {
+          constexpr int E = decltype(Ec)::value;
+          int mj[E];
+          double de[E];
+#pragma unroll
+          for (int e = 0; e < E; e++)
           {
-            ia[r] = SMALL ? hpos[i][r] : hands[i].axis[r];
-            const double ibr = SMALL ? hpos[i][3 + r] : hands[i].bottom[r];
-            d[r] = (SMALL ? hpos[my_j][3 + r] : hands[my_j].bottom[r]) - ibr;
+            const int pe = lane + 64 * e;
+            mj[e] = pe < n ? (int) mlist[wave][pe] : 0;
+            de[e] = 0.0;
+            if (pe < n)
+            {
+              double ia[3], d[3];
+              for (int r = 0; r < 3; r++)
+              {
+                ia[r] = SMALL ? hpos[i][r] : hands[i].axis[r];
+                const double ibr = SMALL ? hpos[i][3 + r] : hands[i].bottom[r];
+                d[r] = (SMALL ? hpos[mj[e]][3 + r] : hands[mj[e]].bottom[r]) - ibr;
+              }
+              de[e] = dot3d(ia, d);  // dist_along_line (:34)
+            }
           }
-          de = dot3d(ia, d);  // dist_along_line (:34)
-        }
-        // rank by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
-        const int dlo = __double2loint(de), dhi = __double2hiint(de);
-        int rank = 0;
-        for (int k = 0; k < n; k++)
-        {
-          const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
-          const int jk = __builtin_amdgcn_readlane(my_j, k);
-          rank += (dk < de || (dk == de && jk < my_j)) ? 1 : 0;
-        }
-        const int dst = (lane < n ? rank : lane) * 4;  // the sorted list, one entry per lane
-        const int slo = __builtin_amdgcn_ds_permute(dst, dlo), shi = __builtin_amdgcn_ds_permute(dst, dhi);
-        out_j = __builtin_amdgcn_ds_permute(dst, my_j);
-        const double sdv = __hiloint2double(shi, slo);
-        const double nx_d = __hiloint2double(__shfl_down(shi, 1), __shfl_down(slo, 1));
-        const unsigned long long gm = __ballot(lane + 1 < n && nx_d - sdv > 0.02);  // shortenHandle: first gap > 2 cm (:95-99)
-        kept = gm ? __ffsll((long long) gm) - 1 : n;  // the elements before the gap position (:111)
-        accept = kept >= min_inliers && kept > 0;
-        if (accept)
-        {
-          const double s0 = __hiloint2double(__builtin_amdgcn_readlane(shi, 0), __builtin_amdgcn_readlane(slo, 0));
-          const double s1 = __hiloint2double(__builtin_amdgcn_readlane(shi, kept - 1), __builtin_amdgcn_readlane(slo, kept - 1));
-          const double mn = s0 < 10000000 ? s0 : 10000000;  // :62-72, the reference's +-1e7 start values
-          const double mx = s1 > -10000000 ? s1 : -10000000;
-          accept = (mx - mn > min_length);
-        }
+          // rank by (distance, index): std::sort's order, ties by index (the oracle's stated choice)
+          int rank[E];
+#pragma unroll
+          for (int e = 0; e < E; e++)
+            rank[e] = 0;
+#pragma unroll
+          for (int f = 0; f < E; f++)  // against the elements of slot f, read lane by lane
+          {
+            const int dlo = __double2loint(de[f]), dhi = __double2hiint(de[f]);
+            const int nf = min(64, n - 64 * f);
+            for (int k = 0; k < nf; k++)
+            {
+              const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+              const int jk = __builtin_amdgcn_readlane(mj[f], k);
+#pragma unroll
+              for (int e = 0; e < E; e++)
+                rank[e] += (dk < de[e] || (dk == de[e] && jk < mj[e])) ? 1 : 0;
+            }
+          }
+          AGH_WAVE_SYNC();  // (every lane has read its members: the list is rewritten in sorted order)
+#pragma unroll
+          for (int e = 0; e < E; e++)
+            if (lane + 64 * e < n)
+            {
+              sdist[wave][rank[e]] = de[e];
+              mlist[wave][rank[e]] = (unsigned short) mj[e];
+            }
+          AGH_WAVE_SYNC();
+          // shortenHandle: the first gap of more than 2 cm between neighbours of the sorted list (:95-99); the elements before
+          // the gap position stay (:111)
+          kept = n;
+#pragma unroll
+          for (int e = E - 1; e >= 0; e--)
+          {
+            const int pe = lane + 64 * e;
+            const unsigned long long gm = __ballot(pe + 1 < n && sdist[wave][min(pe + 1, kMaxRow - 1)] - sdist[wave][pe] > 0.02);
+            kept = gm ? 64 * e + __ffsll((long long) gm) - 1 : kept;
+          }
+          accept = kept >= min_inliers && kept > 0;
+          if (accept)
+          {
+            const double s0 = sdist[wave][0], s1 = sdist[wave][kept - 1];
+            const double mn = s0 < 10000000 ? s0 : 10000000;  // :62-72, the reference's +-1e7 start values
+            const double mx = s1 > -10000000 ? s1 : -10000000;
+            accept = (mx - mn > min_length);
+          }
+        };
+        if (s_maxrow <= 64)
+          evaluate(std::integral_constant<int, 1>{});
+        else
+          evaluate(std::integral_constant<int, kE>{});
       }
       if (lane == 0)
       {
@@ -722,10 +764,11 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
       if (accept)
       {
         const int h = s_nh + c_h[wave], base = s_nidx + c_base[wave];
-        if (lane < kept)
+        for (int pe = lane; pe < kept; pe += 64)
         {
-          tmp_idx[base + lane] = (unsigned short) out_j;
-          atomicAnd(&alive[out_j >> 6], ~(1ull << (out_j & 63)));  // :75-78
+          const int oj = (int) mlist[wave][pe];  // (the wave's sorted member list)
+          tmp_idx[base + pe] = (unsigned short) oj;
+          atomicAnd(&alive[oj >> 6], ~(1ull << (oj & 63)));  // :75-78
         }
         if (lane == 0)
         {
@@ -774,12 +817,12 @@ __global__ __launch_bounds__(1024) void k_handle_batch(const agh_hypothesis* __r
       h_first[r] = first;
       h_n[r] = n;
     }
-    if (lane < n)
+    for (int p = lane; p < n; p += 64)
     {
-      const int j = tmp_idx[base + lane];
-      inlier_idx[first + lane] = j;
-      if (host_idx && first + lane < host_idx_cap)
-        host_idx[first + lane] = j;  // (the host-buffer entry point: the list is on the host when the stream drains)
+      const int j = tmp_idx[base + p];
+      inlier_idx[first + p] = j;
+      if (host_idx && first + p < host_idx_cap)
+        host_idx[first + p] = j;  // (the host-buffer entry point: the list is on the host when the stream drains)
     }
   }
   if (tid == 0)
