@@ -1562,6 +1562,17 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
   // ---- 4. search -> classification -> kept hands -> handle search, then the one synchronisation ----
   VoxDesc h;
   bool handles_only = false;
+  // a failure between the launches and the synchronisation, while the host only knows a BOUND of the cloud's size: the context
+  // must not be left believing the bound is the cloud
+  auto drop_bound_cloud = [&]() {
+    if (c->n_is_bound)
+    {
+      c->n_is_bound = false;
+      c->has_cloud = false;
+      c->n = 0;
+      c->cloud_off_on_device = false;
+    }
+  };
   for (int attempt = 0;; attempt++)
   {
     for (int k = 0; k < (handles_only ? 4 : 8); k++)  // ([4..6], the search's counts, outlive a repeat of the handle search alone)
@@ -1573,13 +1584,13 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
       if ((rc = agh_find_hands_device(ctx, c->d_idx_own, S, 0, c->d_out_own, c->s_cap * 8, c->d_nout, st)) != AGH_OK)
       {
         (void) hipStreamSynchronize(st);
-        c->n_is_bound = false;
+        drop_bound_cloud();
         return rc;
       }
       if (lp->classify && (rc = agh_classify_device(ctx, c->d_keep, st)) != AGH_OK)
       {
         (void) hipStreamSynchronize(st);
-        c->n_is_bound = false;
+        drop_bound_cloud();
         return rc;
       }
       hipLaunchKernelGGL(k_compact_kept, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_out_own, (const int64_t*) c->d_nout,
@@ -1593,7 +1604,7 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
     if (rc != AGH_OK)
     {
       (void) hipStreamSynchronize(st);
-      c->n_is_bound = false;
+      drop_bound_cloud();
       c->err = "handle search launch failed";
       return rc;
     }
