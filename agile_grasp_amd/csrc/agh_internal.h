@@ -98,6 +98,9 @@ enum SampleStatus : int
   kStatusSkipped = 5      // kSampleSkip: an unused slot of a device-drawn sample list
 };
 constexpr int32_t kSampleSkip = INT32_MIN;
+constexpr int kBigCap = 4096;    // per-sample neighbour-list scratch (and the largest LDS-resident class of K1a) without ...
+constexpr int kHugeCap = 6144;   // ... and with the 6144 class (Ctx::huge_classes)
+constexpr int kHugePool = 512;   // samples of ONE launch that may need the 6144 class at once (AGH_ERR_CAPACITY beyond)
 
 // K-1 (voxelize.hip): per-camera voxel lattice of the preprocessing step
 constexpr unsigned long long kVoxMaxWords = 1ull << 28;  // 1 GiB of bitmap (a 6 m x 6 m x 3 m lattice at 3 mm)
@@ -257,6 +260,11 @@ struct Ctx
   agh_hypothesis* d_out_last = nullptr;  // where the last call's compacted records live
   int64_t* d_nout_last = nullptr;
   int32_t* d_flags = nullptr;  // [0] any overflow, [1] ...
+  bool huge_classes = false;  // ... and the 6144 class behind those (K1a through global scratch, K1c in LDS): neighbourhoods of up to
+                              // kHugeCap points; enabled like big_classes, by the first call that needs it (AGH_ERR_RETRY once)
+  float4* d_huge_stage = nullptr;            // kHugePool x kHugeCap candidates of the 6144 class, unsorted
+  unsigned long long* d_huge_key = nullptr;  // ... and their (d2, index) keys
+  int* d_huge_count = nullptr;               // slots handed out in this call
   bool big_classes = false;  // launch the larger capacity classes of K1a / K1c too (sticky; set by the first call that
                              // met a neighbourhood beyond the first class, see AGH_ERR_RETRY)
   bool zero_flags_pending = false;  // the next k_taubin_moments launch clears d_flags first
@@ -323,6 +331,8 @@ struct Ctx
   int32_t timing_counts[AGH_TIMING_SLOTS] = { 0 };  // timed launches per slot of the last agh_get_timing (agh_get_timing_counts)
 };
 
+inline int class_level(const Ctx* c) { return c->huge_classes ? 2 : (c->big_classes ? 1 : 0); }
+
 // a search about to run on `st`: if the host-buffer agh_set_cloud left its grid build running on the context's stream and `st`
 // is another stream, wait for the build first (streams the caller brings may be non-blocking ones)
 inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
@@ -341,11 +351,13 @@ inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
 // gathered headers into three more bits, identical on every rank: kFlagShardRetry (some rank that had NOT launched the larger
 // classes needs them), kFlagShardHard (some rank that had launched them still overflowed), kFlagSharded (a merge ran: the
 // decision comes from these bits, the rank's own bit 0 is ignored).
-constexpr int kFlagShardRetry = 32, kFlagShardHard = 64, kFlagSharded = 128;
-// word 1 of a segment header: 1 = overflow with the larger classes off, 8 = overflow with them on, 4 = bad sample index
-__host__ __device__ inline int shard_header_word(int flags0, int big_classes_on)
+constexpr int kFlagShardRetry = 32, kFlagShardHard = 64, kFlagSharded = 128, kFlagShardRetryHuge = 256;
+// word 1 of a segment header: an overflow of the capacity classes the rank had launched -- 1 with the larger classes off (level
+// 0: a retry with them helps), 8 with them on (level 1: a retry with the 6144 class helps), 16 with that on too (level 2: hard)
+// -- and 4 = bad sample index
+__host__ __device__ inline int shard_header_word(int flags0, int class_level)
 {
-  return ((flags0 & 1) ? (big_classes_on ? 8 : 1) : 0) | (flags0 & 4);
+  return ((flags0 & 1) ? (class_level >= 2 ? 16 : (class_level == 1 ? 8 : 1)) : 0) | (flags0 & 4);
 }
 
 // ---- kernel launchers (defined in the .hip files) ----

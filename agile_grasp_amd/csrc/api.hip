@@ -204,9 +204,17 @@ int ensure_call_buffers(Ctx* c, int64_t S)
       return rc;
     c->images_cam_cap = cap;
   }
-  if (S <= c->s_cap)
+  const int64_t want_stride = c->huge_classes ? kHugeCap : kBigCap;
+  if (c->huge_classes && !c->d_huge_stage)
+  {
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_huge_stage, (size_t) kHugePool * kHugeCap)) ||
+        (rc = dev_alloc(c, &c->d_huge_key, (size_t) kHugePool * kHugeCap)) || (rc = dev_alloc(c, &c->d_huge_count, 4)))
+      return rc;
+  }
+  if (S <= c->s_cap && c->nbr_stride == want_stride)
     return AGH_OK;
-  const int64_t cap = std::max<int64_t>(S, 1024);
+  const int64_t cap = std::max<int64_t>(std::max<int64_t>(S, c->s_cap), 1024);
   int rc;
   if ((rc = dev_alloc(c, &c->d_samples, cap)))
     return rc;
@@ -218,7 +226,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_status, cap)) || (rc = dev_alloc(c, &c->d_weight, cap)) || (rc = dev_alloc(c, &c->d_order, cap)) || (rc = dev_alloc(c, &c->d_order_sweep, cap)) || (rc = dev_alloc(c, &c->d_vmask, cap + 16)))
     return rc;
-  c->nbr_stride = 4096;
+  c->nbr_stride = want_stride;  // (the sorted neighbour list of a sample: 4096 entries, 6144 once the 6144 class is on)
   if ((rc = dev_alloc(c, &c->d_nbr, cap * c->nbr_stride)))
     return rc;
   if ((rc = dev_alloc(c, &c->d_eig, cap * 12)))
@@ -517,7 +525,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_order_sweep, c->d_vmask, c->d_cloud_off, c->d_scloud, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -1216,15 +1224,17 @@ static int flags_to_status(Ctx* c, const int32_t* flags_in)
     flags[0] &= ~1;
     if (flags[0] & kFlagShardHard)
     {
-      c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
+      c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity; "
                "voxelise the cloud (localization.cpp:43) or reduce the radii";
       return AGH_ERR_CAPACITY;
     }
-    if (flags[0] & kFlagShardRetry)
+    if (flags[0] & (kFlagShardRetry | kFlagShardRetryHuge))
     {
       c->big_classes = true;
-      c->err = "a Taubin neighbourhood exceeds the first capacity class; the contexts of the communicator now launch the "
-               "larger classes as well: repeat the call";
+      if (flags[0] & kFlagShardRetryHuge)
+        c->huge_classes = true;
+      c->err = "a Taubin neighbourhood exceeds the capacity classes launched so far; the contexts of the communicator now launch "
+               "the larger classes as well: repeat the call";
       return AGH_ERR_RETRY;
     }
   }
@@ -1238,10 +1248,17 @@ static int flags_to_status(Ctx* c, const int32_t* flags_in)
              "well: repeat the call";
     return AGH_ERR_RETRY;
   }
+  if ((flags[0] & 1) && !c->huge_classes)
+  {
+    // ... and a neighbourhood beyond 4096 points needs the 6144 class (K1a through global scratch): the same on-demand switch
+    c->huge_classes = true;
+    c->err = "a Taubin neighbourhood exceeds 4096 points; the context now launches the 6144 class as well: repeat the call";
+    return AGH_ERR_RETRY;
+  }
   if (flags[0] & 1)
   {
-    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity; "
-             "voxelise the cloud (localization.cpp:43) or reduce the radii";
+    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity (or more than 512 "
+             "samples of one call need the 6144 class); voxelise the cloud (localization.cpp:43) or reduce the radii";
     return AGH_ERR_CAPACITY;
   }
   if ((flags[0] & 2) && !(flags[0] & 16))
@@ -1317,8 +1334,12 @@ int agh_find_hands(agh_ctx* ctx, const int32_t* sample_idx, int64_t n_samples, i
     HIPCHK(c, hipMemcpyAsync(d_idx, h_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
   }
   int64_t n = 0;
-  for (int attempt = 0; attempt < 2; attempt++)  // (AGH_ERR_RETRY: the context has enabled the larger classes)
+  for (int attempt = 0; attempt < 3; attempt++)  // (AGH_ERR_RETRY: the context has enabled the larger classes; then, once, the 6144 class)
   {
+    // (a retry may have switched a capacity class on that wants larger per-sample scratch: sized HERE, so that the device call does
+    // not reallocate d_out_own after it was handed over)
+    if ((rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0))) != AGH_OK)
+      return rc;
     hdr[0] = -1;  // (stays -1 if no concatenation kernel ran: empty input, a debug stop)
     hdr[1] = 0;
     c->mirror = HostMirror{ h_rec, c->h_pin_records, hdr };
@@ -1644,8 +1665,13 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
     {
       int32_t flags[1] = { h_counts[6] };
       rc = flags_to_status(c, flags);
-      if (rc == AGH_ERR_RETRY && attempt < 2)
-        continue;  // (the larger capacity classes are on now: the search once more, on the cloud that is already there)
+      if (rc == AGH_ERR_RETRY && attempt < 3)
+      {
+        // (the larger capacity classes are on now: the search once more, on the cloud that is already there)
+        if ((rc = ensure_call_buffers(c, std::max<int64_t>(S, 1))) != AGH_OK)
+          return rc;
+        continue;
+      }
       if (rc != AGH_OK)
         return rc;
     }

@@ -1409,11 +1409,11 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
   if (S <= 4096)
     hipLaunchKernelGGL(k_compact_fused, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
       (const uint8_t*) c->d_vmask, (int) S, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, d_nout, d_hdr_flags,
-      c->big_classes ? 1 : 0, mir);
+      class_level(c), mir);
   else if (S <= 65536)
   {
     hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, (const uint8_t*) c->d_vmask, (int) S, c->d_scan_tmp,
-      d_nout, (const int32_t*) c->d_flags, d_hdr_flags, c->big_classes ? 1 : 0, mir);
+      d_nout, (const int32_t*) c->d_flags, d_hdr_flags, class_level(c), mir);
     hipLaunchKernelGGL(k_compact_copy, dim3((n + 24) / 25), dim3(256), 0, st, (const agh_hypothesis*) c->d_slots,
       (const uint8_t*) c->d_vmask, (const int*) c->d_scan_tmp, n, d_out, cap, c->d_slot_index, c->d_flags, c->epoch, mir);
   }
@@ -1421,7 +1421,7 @@ int compact_hypotheses(Ctx* c, int64_t S, agh_hypothesis* d_out, int64_t cap, in
   {
     hipLaunchKernelGGL(k_compact_sums, dim3(nb), dim3(256), 0, st, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp);
     hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(256), 0, st, c->d_scan_tmp, nb, d_nout, (const int32_t*) c->d_flags, d_hdr_flags,
-      c->big_classes ? 1 : 0, mir);
+      class_level(c), mir);
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, st, c->d_slots, (const uint8_t*) c->d_vmask, n, c->d_scan_tmp, d_out, cap,
       c->d_slot_index, c->d_flags, c->epoch, mir);
   }

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
     for (int q = 0; q < G; q++)
     {
       int64_t cnt = *reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes);
-      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 13);  // shard_header_word
+      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 29);  // shard_header_word
       if (cnt > seg_records)
       {
         ov = 1;
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
       if (ov)
         atomicOr(&flags[0], 16);
       // what the ranks found, the same word on every rank (agh_internal.h: kFlagShard*)
-      atomicOr(&flags[0], kFlagSharded | ((need & 1) ? kFlagShardRetry : 0) | ((need & 8) ? kFlagShardHard : 0) | (need & 4));
+      atomicOr(&flags[0], kFlagSharded | ((need & 1) ? kFlagShardRetry : 0) | ((need & 8) ? kFlagShardRetryHuge : 0) |
+                            ((need & 16) ? kFlagShardHard : 0) | (need & 4));
       if (o > cap)
         atomicOr(&flags[0], 2);
     }
@@ -829,7 +830,7 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   else  // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must
         // learn of a capacity-class retry from EVERY rank, or this one would repeat the collective alone)
   {
-    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags, c->big_classes ? 1 : 0);
+    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags, class_level(c));
     HIPCHK(c, hipGetLastError());
   }
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
@@ -890,13 +891,15 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
   // asks for is taken by all)
   if (flags[0] & kFlagShardHard)
   {
-    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 4096 points, the kernels' LDS capacity";
+    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity";
     return AGH_ERR_CAPACITY;
   }
-  if (flags[0] & kFlagShardRetry)
+  if (flags[0] & (kFlagShardRetry | kFlagShardRetryHuge))
   {
     c->big_classes = true;
-    c->err = "a Taubin neighbourhood exceeds the first capacity class; the contexts of the communicator now launch the "
+    if (flags[0] & kFlagShardRetryHuge)
+      c->huge_classes = true;
+    c->err = "a Taubin neighbourhood exceeds the capacity classes launched so far; the contexts of the communicator now launch the "
              "larger classes as well: repeat the call";
     return AGH_ERR_RETRY;
   }
@@ -975,8 +978,11 @@ static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx,
   if (n_samples > 0)
     HIPCHK(c, hipMemcpyAsync(c->d_idx_own, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
   int64_t n = 0;
-  for (int attempt = 0; attempt < 3; attempt++)  // (at most one repeat for the capacity classes, one for the segment size)
+  for (int attempt = 0; attempt < 4; attempt++)  // (at most two repeats for the capacity classes, one for the segment size)
   {
+    // (a retry may have switched a capacity class on that wants larger per-sample scratch: sized here, not under the device call)
+    if ((rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0))) != AGH_OK)
+      return rc;
     // (s_cap >= n_samples, so d_out_own holds the complete list: 8 slots per sample)
     rc = agh_find_hands_sharded_device(ctx, c->d_idx_own, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
       c->stream);

@@ -414,6 +414,177 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K1a, the 6144 class: neighbourhoods of 4097 .. kHugeCap points (un-voxelised captures: kdtree.radiusSearch has max_nn = 0,
+// hand_search.cpp:85).  They do not fit the LDS-resident kernel above (28 bytes of LDS per neighbour), and they are rare, so
+// this class trades speed for room: the ball's points and their (d2, index) keys go to a slot of a global pool, every point
+// finds its place in FLANN's order by counting the smaller keys (tiles of the key array through LDS: n^2 / 256 comparisons
+// per thread, ~0.3 ms for 6000 points), the sorted list is written to the sample's neighbour list like the other classes',
+// and the 37 sums run over it in that order with the term tile and the one-wave add chain of the kernel above -- the same
+// products, the same additions in the same order: bit-identical sums.  Launched only once a call has met such a
+// neighbourhood (Ctx::huge_classes), one work-group per sample, of which all but the flagged ones return at once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const float* __restrict__ xyz, int64_t stride,
+  const int32_t* __restrict__ samples, int S, float r2f, double rpad, double* __restrict__ sums, int32_t* __restrict__ nt,
+  int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, float4* __restrict__ pool_stage,
+  unsigned long long* __restrict__ pool_key, int* __restrict__ pool_count)
+{
+  constexpr int kTS = kChunk + 2;
+  constexpr int kKeyTile = 2048;
+  __shared__ __attribute__((aligned(16))) double termbuf[kNumSums * kTS];
+  __shared__ unsigned long long ktile[kKeyTile];
+  __shared__ RowTable rt;
+  __shared__ int count, slot_s;
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (status[s] != kStatusOverflow)
+    return;  // (an earlier class handled this sample, or it has no neighbourhood)
+  if (tid == 0)
+  {
+    count = 0;
+    slot_s = atomicAdd(pool_count, 1);
+  }
+  const float* qp = xyz + (int64_t) samples[s] * stride;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));
+  build_rows(gv, qx, qy, qz, rpad, rt);  // (ends with barriers)
+  if (rt.bad || slot_s >= kHugePool)
+    return;  // (the status stays kStatusOverflow: loud)
+  float4* stage = pool_stage + (int64_t) slot_s * kHugeCap;
+  unsigned long long* key = pool_key + (int64_t) slot_s * kHugeCap;
+  // ---- the ball's points and their keys, in any order ----
+  for (int j = tid; j < rt.total; j += 256)
+  {
+    const float4 p = gv.sorted[row_lookup(rt, j)];
+    const float d2 = flann_d2(qx, qy, qz, p.x, p.y, p.z);
+    if (d2 < r2f)
+    {
+      const int k = atomicAdd(&count, 1);
+      if (k < kHugeCap)
+      {
+        stage[k] = p;
+        key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
+      }
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  const int n = count;
+  if (n > kHugeCap)
+  {
+    if (tid == 0)
+      nt[s] = n;  // (status stays kStatusOverflow)
+    return;
+  }
+  // ---- FLANN's sorted order, ascending (d2, index): a point's place is the number of smaller keys (the keys are distinct) ----
+  {
+    constexpr int kPer = (kHugeCap + 255) / 256;
+    unsigned long long mine[kPer];
+    int rank[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      const int g = tid + 256 * u;
+      mine[u] = g < n ? key[g] : ~0ull;
+      rank[u] = 0;
+    }
+    for (int t0 = 0; t0 < n; t0 += kKeyTile)
+    {
+      const int tn = min(kKeyTile, n - t0);
+      __syncthreads();
+      for (int k = tid; k < tn; k += 256)
+        ktile[k] = key[t0 + k];
+      __syncthreads();
+      for (int k = 0; k < tn; k++)
+      {
+        const unsigned long long kk = ktile[k];  // (the same word for every lane: an LDS broadcast)
+#pragma unroll
+        for (int u = 0; u < kPer; u++)
+          rank[u] += kk < mine[u] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+    {
+      const int g = tid + 256 * u;
+      if (g < n)
+        nbr[(int64_t) s * nbr_stride + rank[u]] = stage[g];
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  // ---- 37 sequential sums (quadric.cpp:40-131) over the sorted list: the term tile and add chain of k_taubin_moments ----
+  const float4* list = nbr + (int64_t) s * nbr_stride;
+  double acc = 0.0;
+  for (int c0 = 0; c0 < n; c0 += kChunk)
+  {
+    const int rows = min(kChunk, n - c0);
+    if (lane < rows && wave < 2)
+    {
+      const float4 p = list[c0 + lane];
+      const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
+      const double x2 = x * x, y2 = y * y, z2 = z * z;
+      const double xy = x * y, yz = y * z, xz = x * z;
+      double* t = &termbuf[lane];  // term-major tile: term k of row r at [k * kTS + r]
+      if (wave == 0)
+      {
+        t[0 * kTS] = x2 * x2;
+        t[1 * kTS] = x2 * y2;
+        t[2 * kTS] = x2 * z2;
+        t[3 * kTS] = x2 * xy;
+        t[4 * kTS] = x2 * yz;
+        t[5 * kTS] = x2 * xz;
+        t[6 * kTS] = x2 * x;
+        t[7 * kTS] = x2 * y;
+        t[8 * kTS] = x2 * z;
+        t[9 * kTS] = x2;
+        t[10 * kTS] = y2 * y2;
+        t[11 * kTS] = y2 * z2;
+        t[12 * kTS] = y2 * xy;
+        t[13 * kTS] = y2 * yz;
+        t[14 * kTS] = y2 * xz;
+        t[15 * kTS] = y2 * x;
+        t[16 * kTS] = y2 * y;
+        t[17 * kTS] = y2 * z;
+        t[18 * kTS] = y2;
+      }
+      else
+      {
+        t[19 * kTS] = z2 * z2;
+        t[20 * kTS] = z2 * xy;
+        t[21 * kTS] = z2 * yz;
+        t[22 * kTS] = z2 * xz;
+        t[23 * kTS] = z2 * x;
+        t[24 * kTS] = z2 * y;
+        t[25 * kTS] = z2 * z;
+        t[26 * kTS] = z2;
+        t[27 * kTS] = x * yz;
+        t[28 * kTS] = xy;
+        t[29 * kTS] = yz;
+        t[30 * kTS] = xz;
+        t[31 * kTS] = x;
+        t[32 * kTS] = y;
+        t[33 * kTS] = z;
+        t[34 * kTS] = x2 + y2;
+        t[35 * kTS] = y2 + z2;
+        t[36 * kTS] = x2 + z2;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < kNumSums)
+      for (int k = 0; k < rows; k++)  // (the adds stay in neighbour order)
+        acc += termbuf[lane * kTS + k];
+    __syncthreads();
+  }
+  if (wave == 0 && lane < kNumSums)
+    sums[(int64_t) s * kSumStride + lane] = acc;
+  if (tid == 0)
+  {
+    nt[s] = n;
+    status[s] = kStatusOk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K1b: quadric.cpp:134-153 + solveGeneralizedEigenProblem (330-363): the ONE eigenpair the reference uses of
 // M v = lambda N v (the smallest of "the first nine"), by the scheme the oracle states (solve_taubin): elimination of
 // the 10th unknown, Cholesky of N9 with deflation of rank-deficient coordinates, in-place reduction C = L^-1 S L^-T,
@@ -1296,6 +1467,14 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
     hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
       (int32_t*) nullptr, c->d_scloud, (long long*) nullptr);
+  if (c->huge_classes && c->d_huge_stage)
+  {
+    // (one slot of the pool per flagged sample, handed out by the kernel; the counter starts every launch at zero)
+    if (hipMemsetAsync(c->d_huge_count, 0, sizeof(int), st) != hipSuccess)
+      return AGH_ERR_HIP;
+    hipLaunchKernelGGL(k_taubin_moments_huge, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si, r2f, rpad,
+      c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->d_huge_stage, c->d_huge_key, c->d_huge_count);
+  }
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
     return AGH_OK;  // phase-timing aid: the truncated kernel left no usable sums behind
@@ -1369,6 +1548,8 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
       AGH_LAUNCH_FRAME(1152, 256, 0);
     if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
       AGH_LAUNCH_FRAME(4096, 256, 1152);
+    if (c->huge_classes)  // (its 24 bytes of LDS per normal still fit: 147 KB)
+      AGH_LAUNCH_FRAME(kHugeCap, 256, 4096);
   }
 #undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);

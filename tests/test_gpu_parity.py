@@ -278,14 +278,50 @@ def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
         assert np.array_equal(ctx.images(), ref["images"])
 
 
-def test_capacity_overflow_is_loud():
-    """A non-voxelised blob with > 2048 neighbours in the Taubin ball must raise, never return partial results."""
+@pytest.mark.parametrize("normals_mode", ["det", "rand50"])
+def test_unvoxelised_blob_beyond_4096_neighbours_bit_exact(normals_mode):
+    """kdtree.radiusSearch has max_nn = 0 (hand_search.cpp:85): the reference's test mains run on raw, un-voxelised captures.
+    A 6000-point blob puts ~5800 points into the Taubin ball -- beyond the LDS-resident classes (4096): the 6144 class (K1a
+    through global scratch, K1c in LDS; switched on by the call that needs it) must give the oracle's frames and hypotheses."""
     from agile_grasp_amd import binding
+    from oracle import oracle_py as O
 
     rng = np.random.default_rng(0)
     xyz = (rng.normal(0, 0.01, (6000, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
+    cam = (rng.random(6000) < 0.4).astype(np.int32)
+    cams = np.array([[0.0, 0.3, 0.5], [0.0, -0.3, 0.5]])
+    mode = binding.NORMALS_RAND50 if normals_mode == "rand50" else binding.NORMALS_DETERMINISTIC
+    ctx = binding.Context(cams, normals_mode=mode, rand_seed=3)
+    ctx.set_cloud(xyz, cam)
+    samples = np.array([5, 77, 1234, 5999], np.int32)
+    hyps = ctx.find_hands(samples)  # (the host entry point repeats by itself: larger classes, then the 6144 class)
+    omode = O.NORMALS_RAND50 if normals_mode == "rand50" else O.NORMALS_DETERMINISTIC
+    ref = O.find_hands(O.default_params(cams, normals_mode=omode, rand_seed=3), xyz, cam, samples)
+    assert ref["frames"]["n_nb"].max() > 4096 and ref["frames"]["n_nb"].max() <= 6144
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert_hyps_equal(hyps, ref["hyps"])
+    # ... and the context keeps working on ordinary clouds afterwards (its per-sample scratch was re-sized)
+    from agile_grasp_amd import synthetic
+
+    sc = synthetic.config("tiny")
+    ctx2 = binding.Context(sc.cam_origins)
+    ctx2.set_cloud(xyz, cam)
+    ctx2.find_hands(samples)
+    ctx2.set_cloud(sc.xyz, sc.cam)
+    got = ctx2.find_hands(sc.samples)
+    ref2 = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, sc.samples)
+    assert_hyps_equal(got, ref2["hyps"])
+
+
+def test_capacity_overflow_is_loud():
+    """Beyond the 6144 class (a 12000-point blob: ~11 600 neighbours in the Taubin ball) the call must raise, never return
+    partial results."""
+    from agile_grasp_amd import binding
+
+    rng = np.random.default_rng(0)
+    xyz = (rng.normal(0, 0.01, (12000, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
     ctx = binding.Context(np.zeros((2, 3)))
-    ctx.set_cloud(xyz, np.zeros(6000, np.int32))
+    ctx.set_cloud(xyz, np.zeros(12000, np.int32))
     with pytest.raises(binding.AghError) as e:
         ctx.find_hands(np.arange(4, dtype=np.int32))
     assert e.value.code == -4  # AGH_ERR_CAPACITY
