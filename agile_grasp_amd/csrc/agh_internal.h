@@ -100,7 +100,7 @@ enum SampleStatus : int
 constexpr int32_t kSampleSkip = INT32_MIN;
 constexpr int kBigCap = 4096;    // per-sample neighbour-list scratch (and the largest LDS-resident class of K1a) without ...
 constexpr int kHugeCap = 6144;   // ... and with the 6144 class (Ctx::huge_classes)
-constexpr int kHugePool = 512;   // samples of ONE launch that may need the 6144 class at once (AGH_ERR_CAPACITY beyond)
+constexpr int64_t kHugeEntries = 1ll << 21;  // pool of the neighbourhoods beyond 4096 points of ONE launch: points in all (AGH_ERR_CAPACITY beyond)
 
 // K-1 (voxelize.hip): per-camera voxel lattice of the preprocessing step
 constexpr unsigned long long kVoxMaxWords = 1ull << 28;  // 1 GiB of bitmap (a 6 m x 6 m x 3 m lattice at 3 mm)
@@ -262,9 +262,12 @@ struct Ctx
   int32_t* d_flags = nullptr;  // [0] any overflow, [1] ...
   bool huge_classes = false;  // ... and the 6144 class behind those (K1a through global scratch, K1c in LDS): neighbourhoods of up to
                               // kHugeCap points; enabled like big_classes, by the first call that needs it (AGH_ERR_RETRY once)
-  float4* d_huge_stage = nullptr;            // kHugePool x kHugeCap candidates of the 6144 class, unsorted
-  unsigned long long* d_huge_key = nullptr;  // ... and their (d2, index) keys
-  int* d_huge_count = nullptr;               // slots handed out in this call
+  float4* d_huge_stage = nullptr;            // kHugeEntries points of the neighbourhoods beyond 4096, unsorted
+  unsigned long long* d_huge_key = nullptr;  // ... their (d2, index) keys
+  float4* d_huge_sorted = nullptr;           // ... the sorted lists of those beyond the per-sample scratch (> kHugeCap)
+  double* d_huge_normals = nullptr;          // ... and their normals (3 x kHugeEntries: x | y | z), K1c beyond the LDS classes
+  long long* d_huge_base = nullptr;          // per sample: first pool entry of its neighbourhood (s_cap)
+  unsigned long long* d_huge_count = nullptr;  // entries handed out in this launch
   bool big_classes = false;  // launch the larger capacity classes of K1a / K1c too (sticky; set by the first call that
                              // met a neighbourhood beyond the first class, see AGH_ERR_RETRY)
   bool zero_flags_pending = false;  // the next k_taubin_moments launch clears d_flags first

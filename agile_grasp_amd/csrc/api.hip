@@ -208,11 +208,12 @@ int ensure_call_buffers(Ctx* c, int64_t S)
   if (c->huge_classes && !c->d_huge_stage)
   {
     int rc;
-    if ((rc = dev_alloc(c, &c->d_huge_stage, (size_t) kHugePool * kHugeCap)) ||
-        (rc = dev_alloc(c, &c->d_huge_key, (size_t) kHugePool * kHugeCap)) || (rc = dev_alloc(c, &c->d_huge_count, 4)))
+    if ((rc = dev_alloc(c, &c->d_huge_stage, (size_t) kHugeEntries)) || (rc = dev_alloc(c, &c->d_huge_key, (size_t) kHugeEntries)) ||
+        (rc = dev_alloc(c, &c->d_huge_sorted, (size_t) kHugeEntries)) || (rc = dev_alloc(c, &c->d_huge_normals, (size_t) kHugeEntries * 3)) ||
+        (rc = dev_alloc(c, &c->d_huge_count, 2)))
       return rc;
   }
-  if (S <= c->s_cap && c->nbr_stride == want_stride)
+  if (S <= c->s_cap && c->nbr_stride == want_stride && (!c->huge_classes || c->d_huge_base))
     return AGH_OK;
   const int64_t cap = std::max<int64_t>(std::max<int64_t>(S, c->s_cap), 1024);
   int rc;
@@ -244,6 +245,8 @@ int ensure_call_buffers(Ctx* c, int64_t S)
   if ((rc = dev_alloc(c, &c->d_out_own, cap * 8)))
     return rc;
   if ((rc = dev_alloc(c, &c->d_draw_ofs, cap)))
+    return rc;
+  if (c->huge_classes && (rc = dev_alloc(c, &c->d_huge_base, cap)))
     return rc;
   c->s_cap = cap;
   return AGH_OK;
@@ -525,7 +528,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_order_sweep, c->d_vmask, c->d_cloud_off, c->d_scloud, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count, c->d_huge_sorted, c->d_huge_normals, c->d_huge_base };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -1224,8 +1227,8 @@ static int flags_to_status(Ctx* c, const int32_t* flags_in)
     flags[0] &= ~1;
     if (flags[0] & kFlagShardHard)
     {
-      c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity; "
-               "voxelise the cloud (localization.cpp:43) or reduce the radii";
+      c->err = "the Taubin neighbourhoods (r = nn_radius_taubin) of more than 4096 points of one launch hold more than 2^21 points in "
+               "all; voxelise the cloud (localization.cpp:43) or reduce the radii";
       return AGH_ERR_CAPACITY;
     }
     if (flags[0] & (kFlagShardRetry | kFlagShardRetryHuge))
@@ -1257,8 +1260,8 @@ static int flags_to_status(Ctx* c, const int32_t* flags_in)
   }
   if (flags[0] & 1)
   {
-    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity (or more than 512 "
-             "samples of one call need the 6144 class); voxelise the cloud (localization.cpp:43) or reduce the radii";
+    c->err = "the Taubin neighbourhoods (r = nn_radius_taubin) of more than 4096 points of one launch hold more than 2^21 points in "
+             "all (the pool of the classes beyond the LDS-resident ones); voxelise the cloud (localization.cpp:43) or reduce the radii";
     return AGH_ERR_CAPACITY;
   }
   if ((flags[0] & 2) && !(flags[0] & 16))

@@ -891,7 +891,7 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
   // asks for is taken by all)
   if (flags[0] & kFlagShardHard)
   {
-    c->err = "a Taubin neighbourhood (r = nn_radius_taubin) holds more than 6144 points, the kernels' capacity";
+    c->err = "the Taubin neighbourhoods of more than 4096 points of one launch hold more than 2^21 points in all";
     return AGH_ERR_CAPACITY;
   }
   if (flags[0] & (kFlagShardRetry | kFlagShardRetryHuge))

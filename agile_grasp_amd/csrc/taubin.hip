@@ -414,43 +414,74 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1a, the 6144 class: neighbourhoods of 4097 .. kHugeCap points (un-voxelised captures: kdtree.radiusSearch has max_nn = 0,
-// hand_search.cpp:85).  They do not fit the LDS-resident kernel above (28 bytes of LDS per neighbour), and they are rare, so
-// this class trades speed for room: the ball's points and their (d2, index) keys go to a slot of a global pool, every point
-// finds its place in FLANN's order by counting the smaller keys (tiles of the key array through LDS: n^2 / 256 comparisons
-// per thread, ~0.3 ms for 6000 points), the sorted list is written to the sample's neighbour list like the other classes',
-// and the 37 sums run over it in that order with the term tile and the one-wave add chain of the kernel above -- the same
-// products, the same additions in the same order: bit-identical sums.  Launched only once a call has met such a
-// neighbourhood (Ctx::huge_classes), one work-group per sample, of which all but the flagged ones return at once.
+// K1a beyond the LDS-resident classes: neighbourhoods of more than 4096 points (un-voxelised captures: kdtree.radiusSearch has
+// max_nn = 0, hand_search.cpp:85).  They do not fit the kernel above (28 bytes of LDS per neighbour), and they are rare, so this
+// class trades speed for room: a first walk over the ball counts its points, the work-group reserves that many entries of a
+// global pool (kHugeEntries for all such neighbourhoods of a launch), a second walk stores the points and their (d2, index)
+// keys there, every point finds its place in FLANN's order by counting the smaller keys (tiles of the key array through LDS:
+// n^2 / 256 comparisons per thread, ~0.3 ms for 6000 points), the sorted list goes to the sample's neighbour list if it fits
+// (n <= nbr_stride: k_taubin_frame<6144> then works on it like the other classes do) or to the pool (k_taubin_frame_huge), and the
+// 37 sums run over it in that order with the term tile and the one-wave add chain of the kernel above -- the same products, the
+// same additions in the same order: bit-identical sums.  Launched only once a call has met such a neighbourhood
+// (Ctx::huge_classes), one work-group per sample, of which all but the flagged ones return at once.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, double* __restrict__ sums, int32_t* __restrict__ nt,
   int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, float4* __restrict__ pool_stage,
-  unsigned long long* __restrict__ pool_key, int* __restrict__ pool_count)
+  unsigned long long* __restrict__ pool_key, float4* __restrict__ pool_sorted, long long* __restrict__ huge_base,
+  unsigned long long* __restrict__ pool_count)
 {
   constexpr int kTS = kChunk + 2;
   constexpr int kKeyTile = 2048;
   __shared__ __attribute__((aligned(16))) double termbuf[kNumSums * kTS];
   __shared__ unsigned long long ktile[kKeyTile];
   __shared__ RowTable rt;
-  __shared__ int count, slot_s;
+  __shared__ int count;
+  __shared__ long long base_s;
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0)
+    huge_base[s] = -1;
   if (status[s] != kStatusOverflow)
     return;  // (an earlier class handled this sample, or it has no neighbourhood)
   if (tid == 0)
-  {
     count = 0;
-    slot_s = atomicAdd(pool_count, 1);
-  }
   const float* qp = xyz + (int64_t) samples[s] * stride;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));
   build_rows(gv, qx, qy, qz, rpad, rt);  // (ends with barriers)
-  if (rt.bad || slot_s >= kHugePool)
+  if (rt.bad)
     return;  // (the status stays kStatusOverflow: loud)
-  float4* stage = pool_stage + (int64_t) slot_s * kHugeCap;
-  unsigned long long* key = pool_key + (int64_t) slot_s * kHugeCap;
+  // ---- how many points the ball holds, then that many entries of the pool ----
+  {
+    int mine = 0;
+    for (int j = tid; j < rt.total; j += 256)
+    {
+      const float4 p = gv.sorted[row_lookup(rt, j)];
+      mine += flann_d2(qx, qy, qz, p.x, p.y, p.z) < r2f ? 1 : 0;
+    }
+    mine = wave_allsum_i32(mine);
+    if (lane == 0 && mine)
+      atomicAdd(&count, mine);
+  }
+  __syncthreads();
+  const int n = count;
+  if (tid == 0)
+  {
+    const unsigned long long b0 = atomicAdd(pool_count, (unsigned long long) n);
+    base_s = b0 + (unsigned long long) n <= (unsigned long long) kHugeEntries ? (long long) b0 : -1;
+    count = 0;
+  }
+  __syncthreads();
+  const long long base = base_s;
+  if (base < 0)
+  {
+    if (tid == 0)
+      nt[s] = n;  // (the pool is exhausted: the status stays kStatusOverflow)
+    return;
+  }
+  float4* stage = pool_stage + base;
+  unsigned long long* key = pool_key + base;
   // ---- the ball's points and their keys, in any order ----
   for (int j = tid; j < rt.total; j += 256)
   {
@@ -459,31 +490,27 @@ __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const 
     if (d2 < r2f)
     {
       const int k = atomicAdd(&count, 1);
-      if (k < kHugeCap)
-      {
-        stage[k] = p;
-        key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
-      }
+      stage[k] = p;
+      key[k] = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned long long) __float_as_uint(p.w);
     }
   }
   __threadfence();
   __syncthreads();
-  const int n = count;
-  if (n > kHugeCap)
-  {
-    if (tid == 0)
-      nt[s] = n;  // (status stays kStatusOverflow)
-    return;
-  }
+  // the sorted list: the sample's own neighbour list if it fits, else the pool
+  const bool in_pool = n > nbr_stride;
+  float4* const list_w = in_pool ? pool_sorted + base : nbr + (int64_t) s * nbr_stride;
+  if (tid == 0)
+    huge_base[s] = in_pool ? base : -1;
   // ---- FLANN's sorted order, ascending (d2, index): a point's place is the number of smaller keys (the keys are distinct) ----
+  for (int g0 = 0; g0 < n; g0 += 256 * 8)  // eight points per thread at a time
   {
-    constexpr int kPer = (kHugeCap + 255) / 256;
+    constexpr int kPer = 8;
     unsigned long long mine[kPer];
     int rank[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; u++)
     {
-      const int g = tid + 256 * u;
+      const int g = g0 + tid + 256 * u;
       mine[u] = g < n ? key[g] : ~0ull;
       rank[u] = 0;
     }
@@ -505,15 +532,15 @@ __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const 
 #pragma unroll
     for (int u = 0; u < kPer; u++)
     {
-      const int g = tid + 256 * u;
+      const int g = g0 + tid + 256 * u;
       if (g < n)
-        nbr[(int64_t) s * nbr_stride + rank[u]] = stage[g];
+        list_w[rank[u]] = stage[g];
     }
   }
   __threadfence();
   __syncthreads();
   // ---- 37 sequential sums (quadric.cpp:40-131) over the sorted list: the term tile and add chain of k_taubin_moments ----
-  const float4* list = nbr + (int64_t) s * nbr_stride;
+  const float4* list = list_w;
   double acc = 0.0;
   for (int c0 = 0; c0 < n; c0 += kChunk)
   {
@@ -829,7 +856,8 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S, int rand_mode,
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
   double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop,
-  const int* __restrict__ order, long long* __restrict__ dbg)
+  const int* __restrict__ order, long long* __restrict__ dbg, const float4* __restrict__ pool_sorted,
+  const long long* __restrict__ huge_base)
 {
 #ifdef AGH_DEBUG_HOOKS  // scripts/frame_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=frame)
 #define AGH_FSTAMP(i, t) do { if (dbg && threadIdx.x == (t)) dbg[(int64_t) order[blockIdx.x] * 8 + (i)] = wall_clock64(); } while (0)
@@ -866,7 +894,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   // writes the records of invalid samples
   const int ks_class = (rand_mode && n > 50) ? 50 : n;  // normals the sample needs room for
   if (ok ? (ks_class <= nmin || ks_class > CAP) : (nmin != 0))
-    return;
+    return;  // (deterministic mode, n beyond every class here: k_taubin_frame_huge)
   const bool valid = ok;
   const bool bad_index = status[s] == kStatusBadIndex || status[s] == kStatusSkipped;
   const float* qp = xyz + (int64_t) (bad_index ? 0 : samples[s]) * stride;
@@ -907,7 +935,9 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     bar3cnt = 0;
   }
   __syncthreads();
-  const float4* nb = nbr + (int64_t) s * nbr_stride;
+  // (a neighbourhood beyond the per-sample list lives in the pool of k_taubin_moments_huge: only the production mode, which
+  // needs 50 of its points, gets here with one)
+  const float4* nb = (huge_base && huge_base[s] >= 0) ? pool_sorted + huge_base[s] : nbr + (int64_t) s * nbr_stride;
   int cam1 = 0;  // this thread's neighbours seen by camera 1 (quadric.cpp:215-226)
   for (int t = tid; t < ks; t += THREADS)
   {
@@ -1412,6 +1442,213 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
 #undef AGH_FSTAMP
 }
 
+// K1c beyond the LDS-resident classes (deterministic normals, a neighbourhood in the pool of k_taubin_moments_huge: more than
+// nbr_stride points): the same steps on normals kept in GLOBAL memory -- quadric-gradient normals (quadric.cpp:238-247), the
+// majority camera, M3 in LaneSum64 order and its smallest eigenvector, and the column sums of quadric.cpp:283-284 for EVERY column
+// (no estimate phase: n^2 terms, ~15 ms for 12 000 points -- a rare path), each in LaneSum64 order, first maximum kept; then the
+// frame exactly as k_taubin_frame forms it.
+__global__ __launch_bounds__(256) void k_taubin_frame_huge(const float4* __restrict__ pool_sorted, double* __restrict__ pool_normals,
+  const long long* __restrict__ huge_base, const int32_t* __restrict__ nt, const double* __restrict__ eig,
+  const int32_t* __restrict__ status, const float* __restrict__ xyz, int64_t stride, const int32_t* __restrict__ samples, int S,
+  double cam0x, double cam0y, double cam0z, double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames,
+  double* __restrict__ normals_out)
+{
+  __shared__ int camcnt1, next_col;
+  __shared__ double sM3[6], sAxis[3];
+  __shared__ double wbest[4];
+  __shared__ int wbest_j[4];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long base = huge_base[s];
+  if (base < 0)
+    return;
+  const int n = nt[s];
+  const double* ev = eig + (int64_t) s * 12;
+  if (!(status[s] == kStatusOk && ev[11] != 0.0))
+    return;  // (k_taubin_frame's first class writes the records of samples without a frame)
+  const float4* nb = pool_sorted + base;
+  double* const nx = pool_normals + base;
+  double* const ny = pool_normals + kHugeEntries + base;
+  double* const nz = pool_normals + 2 * kHugeEntries + base;
+  const double a = ev[0], b = ev[1], c = ev[2];
+  const double d = 2.0 * ev[3], e = 2.0 * ev[4], f = 2.0 * ev[5];
+  const double g = ev[6], h = ev[7], i9 = ev[8];
+  if (tid == 0)
+  {
+    camcnt1 = 0;
+    next_col = 0;
+  }
+  __syncthreads();
+  int cam1 = 0;
+  for (int t = tid; t < n; t += 256)
+  {
+    const float4 p = nb[t];
+    const double x = (double) p.x, y = (double) p.y, z = (double) p.z;
+    const double fx = (((2.0 * a) * x + d * y) + f * z) + g;  // quadric.cpp:238-247
+    const double fy = (((2.0 * b) * y + d * x) + e * z) + h;
+    const double fz = (((2.0 * c) * z + e * y) + f * x) + i9;
+    const double mag = sqrt((fx * fx + fy * fy) + fz * fz);
+    nx[t] = fx / mag;
+    ny[t] = fy / mag;
+    nz[t] = fz / mag;
+    cam1 += (int) (__float_as_uint(p.w) & 1u);
+  }
+  cam1 = wave_allsum_i32(cam1);
+  if (lane == 0 && cam1)
+    atomicAdd(&camcnt1, cam1);
+  __threadfence();
+  __syncthreads();
+  if (wave == 0)  // M3 = normals * normals^T in the oracle's LaneSum64 order (quadric.cpp:266), then its smallest eigenvector
+  {
+    double m[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    for (int t = lane; t < n; t += 64)
+    {
+      const double x = nx[t], y = ny[t], z = nz[t];
+      m[0] += x * x;
+      m[1] += x * y;
+      m[2] += x * z;
+      m[3] += y * y;
+      m[4] += y * z;
+      m[5] += z * z;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+    {
+      m[k] = wave_allsum_f64(m[k]);
+      if (lane == 0)
+        sM3[k] = m[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0)
+    {
+      const double m3[6] = { sM3[0], sM3[1], sM3[2], sM3[3], sM3[4], sM3[5] };
+      double ax[3] = { 1.0, 0.0, 0.0 };
+      smallest_eigvec3(m3, ax);
+      sAxis[0] = ax[0];
+      sAxis[1] = ax[1];
+      sAxis[2] = ax[2];
+    }
+  }
+  // the exact sum of every column, four columns at a time per wave (a term's normal is read once and serves four columns)
+  double best = -1.0;
+  int best_j = 0x7fffffff;
+  for (;;)
+  {
+    int c0 = 0;
+    if (lane == 0)
+      c0 = atomicAdd(&next_col, 4);
+    c0 = __builtin_amdgcn_readfirstlane(c0);
+    if (c0 >= n)
+      break;
+    int jj[4];
+    double jx[4], jy[4], jz[4], acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+      jj[u] = min(c0 + u, n - 1);  // (a short last group repeats its last column; the repeats are not compared)
+      jx[u] = nx[jj[u]];
+      jy[u] = ny[jj[u]];
+      jz[u] = nz[jj[u]];
+      acc[u] = 0.0;
+    }
+    for (int t = lane; t < n; t += 64)
+    {
+      const double tx = nx[t], ty = ny[t], tz = nz[t];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+        const double gdot = (tx * jx[u] + ty * jy[u]) + tz * jz[u];
+        const double g2 = gdot * gdot;
+        acc[u] += (g2 * g2) * g2;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+      const double sum = wave_allsum_f64(acc[u]);
+      if (c0 + u < n && (sum > best || (sum == best && jj[u] < best_j) || best_j == 0x7fffffff))
+      {
+        best = sum;
+        best_j = jj[u];
+      }
+    }
+  }
+  if (lane == 0)
+  {
+    wbest[wave] = best;
+    wbest_j[wave] = best_j;
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    for (int w = 1; w < 4; w++)  // argmax with first-index tie-break (Eigen maxCoeff keeps the first maximum)
+    {
+      const double ob = wbest[w];
+      const int oj = wbest_j[w];
+      const bool take = (oj != 0x7fffffff) && (best_j == 0x7fffffff || ob > best || (ob == best && oj < best_j));
+      if (take)
+      {
+        best = ob;
+        best_j = oj;
+      }
+    }
+    const int max_index = best_j;
+    const float* qp = xyz + (int64_t) samples[s] * stride;
+    double axis[3] = { sAxis[0], sAxis[1], sAxis[2] };
+    const double nm[3] = { nx[max_index], ny[max_index], nz[max_index] };
+    // normal = normalise((I - a a^T) n_max) (quadric.cpp:285-288)
+    double np_[3];
+    for (int r = 0; r < 3; r++)
+    {
+      double pr[3];
+      for (int q = 0; q < 3; q++)
+        pr[q] = ((r == q) ? 1.0 : 0.0) - axis[r] * axis[q];
+      np_[r] = (pr[0] * nm[0] + pr[1] * nm[1]) + pr[2] * nm[2];
+    }
+    const double nn = sqrt((np_[0] * np_[0] + np_[1] * np_[1]) + np_[2] * np_[2]);
+    double normal[3] = { np_[0] / nn, np_[1] / nn, np_[2] / nn };
+    double binormal[3] = { axis[1] * normal[2] - axis[2] * normal[1], axis[2] * normal[0] - axis[0] * normal[2],
+      axis[0] * normal[1] - axis[1] * normal[0] };  // quadric.cpp:291
+    const int maj = (camcnt1 > n - camcnt1) ? 1 : 0;  // camera 1's count against camera 0's
+    const double sample[3] = { (double) qp[0], (double) qp[1], (double) qp[2] };
+    const double s2s[3] = { sample[0] - (maj ? cam1x : cam0x), sample[1] - (maj ? cam1y : cam0y),
+      sample[2] - (maj ? cam1z : cam0z) };
+    if ((normal[0] * s2s[0] + normal[1] * s2s[1]) + normal[2] * s2s[2] > 0)
+      for (int r = 0; r < 3; r++)
+        normal[r] *= -1.0;
+    if ((binormal[0] * s2s[0] + binormal[1] * s2s[1]) + binormal[2] * s2s[2] > 0)
+      for (int r = 0; r < 3; r++)
+        binormal[r] *= -1.0;
+    axis[0] = normal[1] * binormal[2] - normal[2] * binormal[1];  // quadric.cpp:304
+    axis[1] = normal[2] * binormal[0] - normal[0] * binormal[2];
+    axis[2] = normal[0] * binormal[1] - normal[1] * binormal[0];
+    agh_frame fr;
+    for (int r = 0; r < 3; r++)
+    {
+      fr.sample[r] = sample[r];
+      fr.normal[r] = normal[r];
+      fr.axis[r] = axis[r];
+      fr.binormal[r] = binormal[r];
+    }
+    for (int k = 0; k < 10; k++)
+      fr.params[k] = ev[k];
+    fr.eigenvalue = ev[10];
+    fr.n_nb = n;
+    fr.majority_cam = maj;
+    fr.max_index = max_index;
+    fr.valid = 1;
+    frames[s] = fr;
+    if (normals_out)
+    {
+      double* o = normals_out + 3 * (int64_t) samples[s];  // cloud_normals_.col(indices[i]) (hand_search.cpp:102)
+      o[0] = normal[0];
+      o[1] = normal[1];
+      o[2] = normal[2];
+    }
+  }
+}
+
 __global__ void k_draw_offsets(const int32_t* __restrict__ nt, int S, int32_t* __restrict__ draw_ofs,
   int32_t* __restrict__ total_io)
 {
@@ -1470,10 +1707,11 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   if (c->huge_classes && c->d_huge_stage)
   {
     // (one slot of the pool per flagged sample, handed out by the kernel; the counter starts every launch at zero)
-    if (hipMemsetAsync(c->d_huge_count, 0, sizeof(int), st) != hipSuccess)
+    if (hipMemsetAsync(c->d_huge_count, 0, sizeof(unsigned long long), st) != hipSuccess)
       return AGH_ERR_HIP;
     hipLaunchKernelGGL(k_taubin_moments_huge, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si, r2f, rpad,
-      c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->d_huge_stage, c->d_huge_key, c->d_huge_count);
+      c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->d_huge_stage, c->d_huge_key, c->d_huge_sorted, c->d_huge_base,
+      c->d_huge_count);
   }
   timing_mark(c, "taubin_moments", st);
   if (c->debug_stop_moments)
@@ -1529,7 +1767,8 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
   hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(Si), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,      \
     c->d_eig, c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], \
     co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, NMIN, c->debug_stop_frame,           \
-    (const int*) c->d_order, frame_dbg)
+    (const int*) c->d_order, frame_dbg, (const float4*) c->d_huge_sorted,                                              \
+    (const long long*) (c->huge_classes ? c->d_huge_base : nullptr))
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
   if (rand_mode && !small_class)
@@ -1549,7 +1788,13 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
     if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
       AGH_LAUNCH_FRAME(4096, 256, 1152);
     if (c->huge_classes)  // (its 24 bytes of LDS per normal still fit: 147 KB)
+    {
       AGH_LAUNCH_FRAME(kHugeCap, 256, 4096);
+      // ... and what is beyond that, from the pool (all but the pooled samples return at once)
+      hipLaunchKernelGGL(k_taubin_frame_huge, dim3(Si), dim3(256), 0, st, (const float4*) c->d_huge_sorted, c->d_huge_normals,
+        (const long long*) c->d_huge_base, (const int32_t*) d_nt, (const double*) c->d_eig, (const int32_t*) c->d_status, c->d_xyz,
+        c->stride_floats, d_samples, Si, co[0], co[1], co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr);
+    }
   }
 #undef AGH_LAUNCH_FRAME
   timing_mark(c, "taubin_frame", st);

@@ -278,26 +278,28 @@ def test_degenerate_and_ragged_clouds_bit_exact(kind, tiny_scene):
         assert np.array_equal(ctx.images(), ref["images"])
 
 
+@pytest.mark.parametrize("n_points", [6000, 12000])
 @pytest.mark.parametrize("normals_mode", ["det", "rand50"])
-def test_unvoxelised_blob_beyond_4096_neighbours_bit_exact(normals_mode):
+def test_unvoxelised_blob_beyond_4096_neighbours_bit_exact(normals_mode, n_points):
     """kdtree.radiusSearch has max_nn = 0 (hand_search.cpp:85): the reference's test mains run on raw, un-voxelised captures.
-    A 6000-point blob puts ~5800 points into the Taubin ball -- beyond the LDS-resident classes (4096): the 6144 class (K1a
-    through global scratch, K1c in LDS; switched on by the call that needs it) must give the oracle's frames and hypotheses."""
+    A 6000-point blob puts ~5800 points into the Taubin ball -- beyond the LDS-resident classes of K1a (4096): K1a through
+    global scratch, K1c's 6144 class in LDS; a 12000-point blob ~11 600 -- beyond every LDS class: K1c on normals in global
+    memory, every column summed.  Switched on by the call that needs them; frames and hypotheses must be the oracle's."""
     from agile_grasp_amd import binding
     from oracle import oracle_py as O
 
     rng = np.random.default_rng(0)
-    xyz = (rng.normal(0, 0.01, (6000, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
-    cam = (rng.random(6000) < 0.4).astype(np.int32)
+    xyz = (rng.normal(0, 0.01, (n_points, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
+    cam = (rng.random(n_points) < 0.4).astype(np.int32)
     cams = np.array([[0.0, 0.3, 0.5], [0.0, -0.3, 0.5]])
     mode = binding.NORMALS_RAND50 if normals_mode == "rand50" else binding.NORMALS_DETERMINISTIC
     ctx = binding.Context(cams, normals_mode=mode, rand_seed=3)
     ctx.set_cloud(xyz, cam)
-    samples = np.array([5, 77, 1234, 5999], np.int32)
-    hyps = ctx.find_hands(samples)  # (the host entry point repeats by itself: larger classes, then the 6144 class)
+    samples = np.array([5, 77, 1234, n_points - 1], np.int32)
+    hyps = ctx.find_hands(samples)  # (the host entry point repeats by itself: larger classes, then the classes beyond LDS)
     omode = O.NORMALS_RAND50 if normals_mode == "rand50" else O.NORMALS_DETERMINISTIC
     ref = O.find_hands(O.default_params(cams, normals_mode=omode, rand_seed=3), xyz, cam, samples)
-    assert ref["frames"]["n_nb"].max() > 4096 and ref["frames"]["n_nb"].max() <= 6144
+    assert ref["frames"]["n_nb"].max() > 4096 and (ref["frames"]["n_nb"].max() <= 6144) == (n_points == 6000)
     assert_frames_equal(ctx.frames(), ref["frames"])
     assert_hyps_equal(hyps, ref["hyps"])
     # ... and the context keeps working on ordinary clouds afterwards (its per-sample scratch was re-sized)
@@ -314,16 +316,16 @@ def test_unvoxelised_blob_beyond_4096_neighbours_bit_exact(normals_mode):
 
 
 def test_capacity_overflow_is_loud():
-    """Beyond the 6144 class (a 12000-point blob: ~11 600 neighbours in the Taubin ball) the call must raise, never return
-    partial results."""
+    """The neighbourhoods beyond 4096 points of ONE launch share a pool of 2^21 points: 400 samples of a 12000-point blob
+    (~11 600 neighbours each) exceed it (400 samples) -- the call must raise, never return partial results."""
     from agile_grasp_amd import binding
 
     rng = np.random.default_rng(0)
     xyz = (rng.normal(0, 0.01, (12000, 3)) + np.array([0.7, 0.0, 0.0])).astype(np.float32)
-    ctx = binding.Context(np.zeros((2, 3)))
+    ctx = binding.Context(np.zeros((2, 3)), normals_mode=binding.NORMALS_RAND50)
     ctx.set_cloud(xyz, np.zeros(12000, np.int32))
     with pytest.raises(binding.AghError) as e:
-        ctx.find_hands(np.arange(4, dtype=np.int32))
+        ctx.find_hands(np.arange(400, dtype=np.int32))
     assert e.value.code == -4  # AGH_ERR_CAPACITY
 
 
