@@ -233,6 +233,8 @@ struct Ctx
   uint8_t* d_vmask = nullptr;      // per sample: orientations with a hypothesis (k_hand_sweep -> concatenation)
   int* d_order = nullptr;          // samples by descending n_t: blockIdx -> sample of k_taubin_frame
   int* d_order_sweep = nullptr;    // blocks of 32 samples, heaviest first: blockIdx -> sample of k_hand_sweep (made by K1b)
+  int order_frame_s = 0;           // ... and the same for k_taubin_frame's longest-first order (d_order)
+  const int32_t* order_frame_samples = nullptr;
   int order_sweep_s = 0;           // the sample count / list that order was made for (0: none)
   const int32_t* order_sweep_samples = nullptr;
   float4* d_nbr = nullptr;         // s_cap * nbr_stride sorted neighbour lists

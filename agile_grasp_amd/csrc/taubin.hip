@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const 
 // scheme with the candidate count of the hand-search ball as weight until its gather was clipped to the hand's slab; it
 // now runs in sample order, see there.)
 constexpr int kOrderBins = 2048;
+constexpr int kOrderMaxSamples = 4096;  // scheduling orders are made for launches of at most this many samples
 __device__ __forceinline__ int order_bin(int w) { return kOrderBins - 1 - min(w >> 4, kOrderBins - 1); }  // 0 = heaviest
 
 __device__ void sample_order_block(const int* __restrict__ weight, int S, int* __restrict__ order, int* hist, int* wave_tot)
@@ -786,14 +787,18 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
   __shared__ int wave_tot[4];
   static_assert(kSweepBlocksMax <= kOrderBins, "the sweep's block weights reuse the histogram");
   const int n_solver_groups = (S * LPS + 255) / 256;
-  if ((int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling orders of the following kernels
+  // (order == nullptr: no scheduling orders -- beyond ~4000 samples a launch holds many rounds of work-groups, the orders buy
+  // nothing there (k_taubin_frame 130.19 against 130.18 us at C4 with and without; the sweep's block order neutral at C4 and in
+  // the batch), and the one sorter work-group WAS this kernel's duration: 32 us at C4's 8000 samples, 74 us at the batch's
+  // 16 000, against ~17 us for the solver itself)
+  if (order && (int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling orders of the following kernels
   {
     sample_order_block(weight, S, order, hist, wave_tot);
     if (order_sweep)
       sweep_order_block(weight, S, order_sweep, hist);
     return;
   }
-  if ((int) blockIdx.x > n_solver_groups)  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
+  if ((int) blockIdx.x >= n_solver_groups + (order ? 1 : 0))  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
   {                                        // instead of in a launch of their own (12 us at C2: a launch for one wave)
     if (threadIdx.x < 64)
       draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   const long long* __restrict__ huge_base)
 {
 #ifdef AGH_DEBUG_HOOKS  // scripts/frame_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=frame)
-#define AGH_FSTAMP(i, t) do { if (dbg && threadIdx.x == (t)) dbg[(int64_t) order[blockIdx.x] * 8 + (i)] = wall_clock64(); } while (0)
+#define AGH_FSTAMP(i, t) do { if (dbg && threadIdx.x == (t)) dbg[(int64_t) (order ? order[blockIdx.x] : (int) blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define AGH_FSTAMP(i, t) do { } while (0)
 #endif
@@ -885,7 +890,7 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     pad_[blockIdx.x % (AGH_FRAME_PAD / 4)] = 1;
 #endif
 
-  const int s = order[blockIdx.x];
+  const int s = order ? order[blockIdx.x] : (int) blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nt[s];
   const double* ev = eig + (int64_t) s * 12;
@@ -1719,23 +1724,29 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   // One sample per lane, or -- for up to 4096 samples: 512 waves, every second SIMD -- eight, which share the bisection
   // (taubin_eigen.h): C2 22.9 -> 18.5 us (HIP events); with C4's 8000 samples (1000 waves) it measured 24.7 against 22.6, so
   // C4, the 16 000 samples of a batch and the 300 000 of the all-points pass stay at one lane each.
-  const int lps = Si <= 4096 ? 8 : 1;
-  const int eig_groups = (Si * lps + 255) / 256 + 1;  // + the sorter work-group
+#ifndef AGH_LPS8_MAX
+#define AGH_LPS8_MAX 4096
+#endif
+  const int lps = Si <= AGH_LPS8_MAX ? 8 : 1;
+  const bool with_orders = Si <= kOrderMaxSamples;  // (see k_taubin_eigen: beyond, the sorter work-group would be the kernel)
+  const int eig_groups = (Si * lps + 255) / 256 + (with_orders ? 1 : 0);  // + the sorter work-group
   // (production mode: one more work-group computes the RAND50 draw offsets, unless the caller exchanges the counts
   // between the ranks first -- the sharded search)
   int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
   const int eig_grid = eig_groups + (dofs ? 1 : 0);
   // the hand sweep's block-wise order rides along (hand_sweep() uses it when it was made for exactly its launch)
-  const bool with_sweep_order = radius > 0.015 && (Si + kSweepBlock - 1) / kSweepBlock <= kSweepBlocksMax && Si >= 4 * kSweepBlock;
+  const bool with_sweep_order = with_orders && radius > 0.015 && (Si + kSweepBlock - 1) / kSweepBlock <= kSweepBlocksMax && Si >= 4 * kSweepBlock;
+  c->order_frame_s = with_orders ? Si : 0;
+  c->order_frame_samples = with_orders ? d_samples : nullptr;
   int* sweep_order = with_sweep_order ? c->d_order_sweep : nullptr;
   c->order_sweep_s = with_sweep_order ? Si : 0;
   c->order_sweep_samples = with_sweep_order ? d_samples : nullptr;
   if (lps == 8)
     hipLaunchKernelGGL(k_taubin_eigen<8>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2, sweep_order);
+      c->d_flags, (const int*) d_nt, with_orders ? c->d_order : (int*) nullptr, dofs, c->d_flags + 2, sweep_order);
   else
     hipLaunchKernelGGL(k_taubin_eigen<1>, dim3(eig_grid), dim3(256), 0, st, c->d_sums, d_nt, c->d_status, Si, c->d_eig,
-      c->d_flags, (const int*) d_nt, c->d_order, dofs, c->d_flags + 2, sweep_order);
+      c->d_flags, (const int*) d_nt, with_orders ? c->d_order : (int*) nullptr, dofs, c->d_flags + 2, sweep_order);
   timing_mark(c, "taubin_eigen", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
@@ -1763,11 +1774,13 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
     if (!strcmp(k, "frame") && !small_class)
       frame_dbg = c->d_dbg;
 #endif
+  // the longest-first order k_taubin_eigen's sorter made for exactly this launch (same sample list, same count), else sample order
+  const int* frame_order = (c->order_frame_s == Si && c->order_frame_samples == d_samples) ? (const int*) c->d_order : nullptr;
 #define AGH_LAUNCH_FRAME(CAP, THREADS, NMIN)                                                                            \
   hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(Si), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,      \
     c->d_eig, c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], \
     co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, NMIN, c->debug_stop_frame,           \
-    (const int*) c->d_order, frame_dbg, (const float4*) c->d_huge_sorted,                                              \
+    frame_order, frame_dbg, (const float4*) c->d_huge_sorted,                                                          \
     (const long long*) (c->huge_classes ? c->d_huge_base : nullptr))
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
