@@ -791,14 +791,20 @@ __global__ __launch_bounds__(256) void k_taubin_eigen(const double* __restrict__
   // nothing there (k_taubin_frame 130.19 against 130.18 us at C4 with and without; the sweep's block order neutral at C4 and in
   // the batch), and the one sorter work-group WAS this kernel's duration: 32 us at C4's 8000 samples, 74 us at the batch's
   // 16 000, against ~17 us for the solver itself)
-  if (order && (int) blockIdx.x == n_solver_groups)  // an extra work-group: scheduling orders of the following kernels
+  // two extra work-groups: the scheduling orders of the two following kernels, side by side (one work-group made both, one after
+  // the other, and was then the longest of the launch)
+  if (order && (int) blockIdx.x == n_solver_groups)
   {
     sample_order_block(weight, S, order, hist, wave_tot);
+    return;
+  }
+  if (order && (int) blockIdx.x == n_solver_groups + 1)
+  {
     if (order_sweep)
       sweep_order_block(weight, S, order_sweep, hist);
     return;
   }
-  if ((int) blockIdx.x >= n_solver_groups + (order ? 1 : 0))  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
+  if ((int) blockIdx.x >= n_solver_groups + (order ? 2 : 0))  // production mode, one more: the draw offsets k_taubin_frame needs ride along here
   {                                        // instead of in a launch of their own (12 us at C2: a launch for one wave)
     if (threadIdx.x < 64)
       draw_offsets_wave(nt, S, draw_ofs, draw_total_io);
@@ -1729,7 +1735,7 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
 #endif
   const int lps = Si <= AGH_LPS8_MAX ? 8 : 1;
   const bool with_orders = Si <= kOrderMaxSamples;  // (see k_taubin_eigen: beyond, the sorter work-group would be the kernel)
-  const int eig_groups = (Si * lps + 255) / 256 + (with_orders ? 1 : 0);  // + the sorter work-group
+  const int eig_groups = (Si * lps + 255) / 256 + (with_orders ? 2 : 0);  // + the two sorter work-groups
   // (production mode: one more work-group computes the RAND50 draw offsets, unless the caller exchanges the counts
   // between the ranks first -- the sharded search)
   int32_t* dofs = (with_draw_offsets && c->p.normals_mode == AGH_NORMALS_RAND50) ? c->d_draw_ofs : nullptr;
