@@ -162,14 +162,16 @@ __device__ __forceinline__ unsigned lowmask(int n)
 // hand needs 2 and 1, any admissible geometry at most kLutProbe.
 // MODE: 0 = occupancy sweep only; 1 = with the antipodal counts (cloud normals); 2 = mode 1 plus one image per camera
 // for the training instances createInstance(h, cam_pos, cam = 0 / 1) (learning.cpp:389-397).
-template <int MODE, int PX, int PY>
+// NT: threads of a work-group -- 256 (four waves, two orientations each, three work-groups per CU) or 512 (eight waves, an
+// orientation each, two work-groups per CU with a tile that holds every neighbourhood of the voxelised clouds in one piece).
+template <int MODE, int PX, int PY, int NT>
 #ifndef AGH_SWEEP_WGS
 #define AGH_SWEEP_WGS 3
 #endif
 #ifndef AGH_SWEEP_TILE
 #define AGH_SWEEP_TILE 2176
 #endif
-__global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
@@ -177,9 +179,10 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   uint32_t* __restrict__ images_cam)
 {
   constexpr bool NORMALS = MODE != 0, TRAIN = MODE == 2;
+  constexpr int NW = NT / 64, kOW = 8 / NW;  // waves; orientations a wave owns in the finger logic and the results
   constexpr int kImgPlanes = TRAIN ? 16 : 8;  // TRAIN: plane o = camera 0's points, plane 8 + o = camera 1's
   // the block must stay under a third of the CU's 160 KiB (512-B granules)
-  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : AGH_SWEEP_TILE);
+  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : (NT == 512 ? 3712 : AGH_SWEEP_TILE));
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   __shared__ double dep_s[24];
   __shared__ OriState ori[8];
   __shared__ unsigned regmask[8][44];
-  __shared__ __attribute__((aligned(16))) unsigned pre_s[4][88];
-  __shared__ unsigned suf_s[4][88];
+  __shared__ __attribute__((aligned(16))) unsigned pre_s[NW][88];
+  __shared__ unsigned suf_s[NW][88];
   __shared__ unsigned img[kImgPlanes][kImageWords + 2];
   // Pass A sets its (region, depth) bits in kRmCopies copies of the table, one per lane & 3, and the finger phase ORs them
   // together: neighbouring lanes hold neighbouring points, which mostly fall into the same table word, and an LDS atomic
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   constexpr int kRmCopies = 4, kRmOriStride = 48, kRmCopyStride = 8 * kRmOriStride + 8;
   static_assert(kRmCopies * kRmCopyStride <= kImgPlanes * (kImageWords + 2), "the table copies must fit the image planes");
   unsigned* const rmc = &img[0][0];
-  __shared__ double ypart[4][8];  // a wave's minimum of y over its quarter of the tile, per orientation (screening)
+  __shared__ double ypart[NW][8];  // a wave's minimum of y over its quarter of the tile, per orientation (screening)
   __shared__ int cnt_crop, any_hand, pending, tile_end;
 
   // blockIdx -> sample: blocks of 32 samples, heaviest first (K1b's sorter work-group: sweep_order_block), or sample order
@@ -210,11 +213,11 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   // The work-group's first microseconds are a chain of dependent loads (frame -> grid descriptor -> cell table -> points).
   // Everything that does not depend on the frame is ISSUED before the frame is waited for: the geometry words this thread
   // stages, the sample's grid descriptor, the hand angles.
-  constexpr int kGeomWords = (int) (sizeof(HandGeom) / 4), kGeomPer = (kGeomWords + 255) / 256;
+  constexpr int kGeomWords = (int) (sizeof(HandGeom) / 4), kGeomPer = (kGeomWords + NT - 1) / NT;
   unsigned gw[kGeomPer];
 #pragma unroll
   for (int k = 0; k < kGeomPer; k++)
-    gw[k] = (tid + 256 * k) < kGeomWords ? ((const unsigned*) geom_p)[tid + 256 * k] : 0u;
+    gw[k] = (tid + NT * k) < kGeomWords ? ((const unsigned*) geom_p)[tid + NT * k] : 0u;
   gv = grid_of_cloud(gv, cloud_of_point(gv, samples[s]));  // the sample's cloud of the batch
   const GridDesc gd = *gv.desc;
   const int to = tid / 9, tij = tid - 9 * to;  // thread (o, i, j) of the 72 entries of frame_ * rot^T (below)
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   // stage the geometry tables in LDS
 #pragma unroll
   for (int k = 0; k < kGeomPer; k++)
-    if ((tid + 256 * k) < kGeomWords)
-      ((unsigned*) &G)[tid + 256 * k] = gw[k];
+    if ((tid + NT * k) < kGeomWords)
+      ((unsigned*) &G)[tid + NT * k] = gw[k];
   if (tid == 0)
   {
     cnt_crop = 0;
@@ -242,9 +245,9 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     pending = 0;
     tile_end = 0x7fffffff;
   }
-  for (int k = tid; k < 8 * 44; k += 256)
+  for (int k = tid; k < 8 * 44; k += NT)
     (&regmask[0][0])[k] = 0u;
-  for (int k = tid; k < kImgPlanes * (kImageWords + 2); k += 256)
+  for (int k = tid; k < kImgPlanes * (kImageWords + 2); k += NT)
     (&img[0][0])[k] = 0u;
   const float sx = (float) F.sample[0], sy = (float) F.sample[1], sz = (float) F.sample[2];  // hand_search.cpp:141-144
   // frame_ << normal, normal x axis, axis (rotating_hand.cpp:24-25); column r of fr is fr[.][r]
@@ -416,12 +419,12 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
       int nr0 = cur_r0;
       float4 q0, q1;
       bool g0, g1;
-      seg_load(cur_j + 4, nr0, q0, q1, g0, g1);  // in flight while the current segment is consumed
+      seg_load(cur_j + NW, nr0, q0, q1, g0, g1);  // in flight while the current segment is consumed
       if (!consume2(p0, h0, p1, h1))
         full = true;
       else
       {
-        cur_j += 4;
+        cur_j += NW;
         cur_r0 = nr0;
         p0 = q0;
         p1 = q1;
@@ -467,11 +470,11 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     for (int o = 0; o < 8; o++)
       m[o] = INFINITY;
     double2 pn = pts[tid < nc ? tid : 0];
-    for (int b0 = 0; b0 < nc; b0 += 256)
+    for (int b0 = 0; b0 < nc; b0 += NT)
     {
       // (a lane past the end of the tile holds point 0 once more: the minimum is idempotent)
       const double2 p = pn;
-      const int tn = b0 + 256 + tid;
+      const int tn = b0 + NT + tid;
       pn = pts[tn < nc ? tn : 0];
 #pragma unroll
       for (int o = 0; o < 8; o++)
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     bool out = false;
     if (lane < 8)
     {
-      run_ymin = min_f64_raw(run_ymin, min_f64_raw(min_f64_raw(ypart[0][lane], ypart[1][lane]), min_f64_raw(ypart[2][lane], ypart[3][lane])));
+      for (int w = 0; w < NW; w++)
+        run_ymin = min_f64_raw(run_ymin, ypart[w][lane]);
       out = (run_ymin < G.depths[0]) && (run_ymin < G.backs[0]);  // finger_hand.cpp:29-42 at the initial bite
     }
     live &= ~(unsigned) __ballot(out);
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
       double2 pn[4];
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        pn[u] = pts[(tid + 256 * u) < nc ? tid + 256 * u : 0];
+        pn[u] = pts[(tid + NT * u) < nc ? tid + NT * u : 0];
       // one pass over U x 256 points, U points per lane; the tile's last pass takes the U that covers what is left (a pass of
       // four for 1.1 k points classified 2 k)
       auto pass = [&](auto Uc, int b0) {
@@ -520,12 +524,12 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
           xr[u] = cs * p.x + ms * p.y;  // rot * points_ (rotating_hand.cpp:91)
           yr[u] = sn * p.x + cs * p.y;
         }
-        if (U == 4 && b0 + 1024 < nc)
+        if (U == 4 && b0 + 4 * NT < nc)
         {
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
-            const int tn = b0 + 1024 + 256 * u + tid;
+            const int tn = b0 + 4 * NT + NT * u + tid;
             pn[u] = pts[tn < nc ? tn : 0];
           }
         }
@@ -572,14 +576,14 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
             atomicOr(&rmc[(lane & (kRmCopies - 1)) * kRmCopyStride + o * kRmOriStride + (key >> 1)], 1u << ((key & 1) * 16 + yk));
         }
       };
-      for (int b0 = 0; b0 < nc; b0 += 1024)
+      for (int b0 = 0; b0 < nc; b0 += 4 * NT)
       {
         const int left = nc - b0;
-        if (left > 768)
+        if (left > 3 * NT)
           pass(std::integral_constant<int, 4>{}, b0);
-        else if (left > 512)
+        else if (left > 2 * NT)
           pass(std::integral_constant<int, 3>{}, b0);
-        else if (left > 256)
+        else if (left > NT)
           pass(std::integral_constant<int, 2>{}, b0);
         else
           pass(std::integral_constant<int, 1>{}, b0);
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     {
       if (nspill + nc <= spill_cap)
       {
-        for (int t = tid; t < nc; t += 256)
+        for (int t = tid; t < nc; t += NT)
           spill[nspill + t] = pts[t];
         nspill += nc;
       }
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   // lane = region key for the prefix / suffix ORs, lane = finger slot for the finger masks, lane = depth for the
   // back-of-hand collision test.  All integer logic on the (region, depth) bit table.
   const int R = 2 * G.n_thr + 1;
-  for (int oo = 0; oo < 2; oo++)
+  for (int oo = 0; oo < kOW; oo++)
   {
-    const int o = wave + 4 * oo;
+    const int o = wave + NW * oo;
     if (ori[o].rejected)
     {
       // put out by a later tile after an earlier one had been classified: its table words go back to zero like those the
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     double wmin, wmax, ymax;
     int nbox, numl, numr, pad;
   };
-  static_assert(sizeof(PassBPart) * 32 <= sizeof(suf_s), "the partial results live on the suffix table");
+  static_assert(sizeof(PassBPart) * 8 * NW <= sizeof(suf_s), "the partial results live on the suffix table");
   PassBPart* const part = reinterpret_cast<PassBPart*>(&suf_s[0][0]);  // [wave][orientation]
   if (lane < 8)
     part[wave * 8 + lane] = PassBPart{ 100000.0, -100000.0, -INFINITY, 0, 0, 0, 0 };  // (a wave reads back only what it wrote)
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
       if (from_spill)
       {
         nc = min(kTile, nspill - spill_pos);
-        for (int t = tid; t < nc; t += 256)
+        for (int t = tid; t < nc; t += NT)
           pts[t] = spill[spill_pos + t];
         spill_pos += nc;
         all_done = spill_pos >= nspill;
@@ -804,17 +808,17 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
         const double sfx = surf[0], sfy = surf[1];
         double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
         int nbox = 0, numl = 0, numr = 0;
-        for (int t0 = tid; t0 < nc; t0 += 1024)
+        for (int t0 = tid; t0 < nc; t0 += 4 * NT)
         {
           // four independent points per lane in stages (straight-line code: the two exactly-rounded divisions of each point
           // overlap with those of the others; the image update is the only predicated part)
-          const bool full = (t0 - tid) + 1024 <= nc;
+          const bool full = (t0 - tid) + 4 * NT <= nc;
           double xr[4], yr[4];
           bool act[4];
 #pragma unroll
           for (int u = 0; u < 4; u++)
           {
-            const int t = t0 + 256 * u;
+            const int t = t0 + NT * u;
             act[u] = full || t < nc;
             const double2 p = pts[act[u] ? t : 0];
             xr[u] = cs * p.x + ms * p.y;
@@ -846,12 +850,12 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
             if (inbox[u])
             {
               if (TRAIN)  // pid = (index << 1) | camera
-                atomicOr(&img[o + 8 * (int) (pid[t0 + 256 * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
+                atomicOr(&img[o + 8 * (int) (pid[t0 + NT * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
               else
                 atomicOr(&img[o][bit[u] >> 5], 1u << (bit[u] & 31));
               if (NORMALS)
               {
-                const double* nn = normals + 3 * (int64_t) (pid[t0 + 256 * u] >> 1);
+                const double* nn = normals + 3 * (int64_t) (pid[t0 + NT * u] >> 1);
                 const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
                 const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
                 const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
@@ -893,9 +897,9 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
   if (debug_stop == 5)
     return;
   // ---- results ----
-  for (int oo = 0; oo < 2; oo++)
+  for (int oo = 0; oo < kOW; oo++)
   {
-    const int o = wave + 4 * oo;
+    const int o = wave + NW * oo;
     const OriState& O = ori[o];
     if (O.rejected || !O.has_hand)
       continue;  // (dead slots are not written: vmask tells the concatenation which are live -- 2.4 MB of stores less at C2)
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(256, AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, 
     h.orientation = o;
     double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
     int nbox = 0, numl = 0, numr = 0;
-    for (int w = 0; w < 4; w++)
+    for (int w = 0; w < NW; w++)
     {
       const PassBPart P = part[w * 8 + o];
       wmin = min_f64_raw(wmin, P.wmin);
@@ -1369,14 +1373,19 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   gv, dg, (const agh_frame*) c->d_frames, d_samples, (const int32_t*) c->d_cam, Si, r2f, rpad, nrm, img_cell, c->d_status, \
     c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg, order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr),   \
     (int) c->nbr_stride, c->d_images_cam
-#define AGH_LAUNCH_SWEEP(N, PX, PY)                                                                                     \
-  do                                                                                                                    \
-  {                                                                                                                     \
-    if (timed)                                                                                                          \
-      hipExtLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, ev_start, ev_stop, 0, AGH_SWEEP_ARGS); \
-    else                                                                                                                \
-      hipLaunchKernelGGL((k_hand_sweep<N, PX, PY>), dim3(Si), dim3(256), 0, st, AGH_SWEEP_ARGS);                          \
+#ifndef AGH_SWEEP_NT
+#define AGH_SWEEP_NT 256  // threads of the online variant's work-groups (512: eight waves, two per CU, one 3712-point tile -- measured, not faster)
+#endif
+#define AGH_LAUNCH_SWEEP_NT(N, PX, PY, NT)                                                                                  \
+  do                                                                                                                        \
+  {                                                                                                                         \
+    if (timed)                                                                                                              \
+      hipExtLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT>), dim3(Si), dim3(NT), 0, st, ev_start, ev_stop, 0, AGH_SWEEP_ARGS); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT>), dim3(Si), dim3(NT), 0, st, AGH_SWEEP_ARGS);                           \
   } while (0)
+  // (the variants with normals need more than the 128 registers that eight-wave work-groups, two per CU, leave a lane)
+#define AGH_LAUNCH_SWEEP(N, PX, PY) AGH_LAUNCH_SWEEP_NT(N, PX, PY, ((N) == 0 ? AGH_SWEEP_NT : 256))
   const bool train = nrm && c->training_images && c->d_images_cam;
   if (train)
     AGH_LAUNCH_SWEEP(2, kLutProbe, kLutProbe);  // (offline path: one instantiation covers every geometry)
@@ -1387,9 +1396,10 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   else if (few)
     AGH_LAUNCH_SWEEP(0, 2, 1);
   else
-    AGH_LAUNCH_SWEEP(0, kLutProbe, kLutProbe);
+    AGH_LAUNCH_SWEEP_NT(0, kLutProbe, kLutProbe, 256);  // (unusual hand geometries: the general probes spill at 128 registers)
   c->last_has_cam_images = train;
 #undef AGH_LAUNCH_SWEEP
+#undef AGH_LAUNCH_SWEEP_NT
 #undef AGH_SWEEP_ARGS
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
