@@ -80,7 +80,7 @@ assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200 and HANDLE_DTYP
 
 EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device", "agh_set_cloud_batch", "agh_set_cloud_batch_device",
-    "agh_preprocess", "agh_preprocess_device", "agh_localize", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_preprocess", "agh_preprocess_device", "agh_localize", "agh_localize_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_get_timing_counts", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
@@ -334,14 +334,20 @@ class Context:
         out = out[:n.value].copy()
         return out, idx[:int(out["n_inliers"].sum())].copy()
 
-    def localize(self, xyz: np.ndarray, size_left: int, workspace, samples=None, n_samples: int = 0, sample_seed: int = 1,
+    def localize(self, xyz, size_left: int, workspace, samples=None, n_samples: int = 0, sample_seed: int = 1,
                  classify: bool = True, min_inliers: int = 3, min_length: float = 0.005, cell_size: float = 0.003,
                  dense: bool = False):
         """agh_localize: raw capture -> voxels -> search -> SVM -> handles in one call with one synchronisation
         (grasp_localizer.cpp:95-103).  `samples`: indices into the voxelised cloud, or None: n_samples are drawn on the device.
         Returns a dict: handles, inlier_idx, hands (what the handle search ran on), samples, n_voxels, n_hypotheses."""
-        xyz = np.ascontiguousarray(xyz, np.float32)
-        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        on_device = hasattr(xyz, "is_cuda") and xyz.is_cuda  # a torch CUDA tensor (N, >= 3) float32: agh_localize_device
+        if on_device:
+            assert xyz.is_contiguous() and xyz.dim() == 2 and xyz.shape[1] >= 3
+            xyz_ptr, n_pts, stride_b = C.c_void_p(xyz.data_ptr()), int(xyz.shape[0]), int(xyz.stride(0)) * 4
+        else:
+            xyz = np.ascontiguousarray(xyz, np.float32)
+            assert xyz.ndim == 2 and xyz.shape[1] >= 3
+            xyz_ptr, n_pts, stride_b = _p(xyz, C.c_float), xyz.shape[0], xyz.shape[1] * 4
         lp = AghLocalizeParams()
         lp.size_left, lp.dense, lp.classify = size_left, 1 if dense else 0, 1 if classify else 0
         ws = np.ascontiguousarray(workspace, np.float64)
@@ -364,10 +370,10 @@ class Context:
                                      np.zeros(max(S, 1), np.int32))
         handles, idx, hands, sout = bufs
         res = AghLocalizeResult()
-        self._check(self.lib.agh_localize(self._h, _p(xyz, C.c_float), C.c_int64(xyz.shape[1] * 4), C.c_int64(xyz.shape[0]),
-                                          C.byref(lp), handles.ctypes.data_as(C.c_void_p), C.c_int64(hcap), _p(idx, C.c_int32),
-                                          C.c_int64(hcap), hands.ctypes.data_as(C.c_void_p), C.c_int64(hcap), _p(sout, C.c_int32),
-                                          C.byref(res)))
+        fn = self.lib.agh_localize_device if on_device else self.lib.agh_localize
+        self._check(fn(self._h, xyz_ptr, C.c_int64(stride_b), C.c_int64(n_pts), C.byref(lp), handles.ctypes.data_as(C.c_void_p),
+                       C.c_int64(hcap), _p(idx, C.c_int32), C.c_int64(hcap), hands.ctypes.data_as(C.c_void_p), C.c_int64(hcap),
+                       _p(sout, C.c_int32), C.byref(res)))
         self.n = res.n_voxels
         self.last_samples = S
         self.last_n = res.n_hypotheses

@@ -1478,7 +1478,27 @@ __global__ __launch_bounds__(1024) void k_compact_kept(const agh_hypothesis* __r
 }
 }  // namespace
 
+static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
+  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
+
 int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
+  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+{
+  return localize_impl(ctx, xyz, false, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
+    samples_out, result);
+}
+
+int agh_localize_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
+  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
+  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+{
+  return localize_impl(ctx, d_xyz, true, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
+    samples_out, result);
+}
+
+static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
   int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
 {
@@ -1509,26 +1529,32 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
   const int64_t S = lp->n_samples;
   hipStream_t st = c->stream;
   int rc;
-  // ---- 1. raw cloud up, voxelisation and grid build queued; the voxel count stays on the device when it can ----
+  // ---- 1. raw cloud up (unless it is on the device already: agh_localize_device, which reads it in place with the caller's
+  // stride), voxelisation and grid build queued; the voxel count stays on the device when it can ----
   const bool as_is = stride_bytes <= 32;  // (as agh_preprocess)
-  const int64_t dev_stride = as_is ? stride_bytes : 12;
-  const int64_t need = n * (dev_stride / 4);
-  if (need > c->raw_cap || !c->d_raw_xyz)
+  const int64_t dev_stride = (as_is || xyz_on_device) ? stride_bytes : 12;
+  const float* d_raw = xyz;
+  if (!xyz_on_device)
   {
-    if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
-      return rc;
-    c->raw_cap = need;
-  }
-  if (n > 0)
-  {
-    if (as_is)
-      HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, st));
-    else
-      HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, st));
+    const int64_t need = n * (dev_stride / 4);
+    if (need > c->raw_cap || !c->d_raw_xyz)
+    {
+      if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
+        return rc;
+      c->raw_cap = need;
+    }
+    if (n > 0)
+    {
+      if (as_is)
+        HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, st));
+      else
+        HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, st));
+    }
+    d_raw = c->d_raw_xyz;
   }
   bool deferred = false;
   int64_t nv = 0;
-  rc = preprocess_device_impl(ctx, c->d_raw_xyz, dev_stride, n, lp->size_left, lp->dense, lp->workspace, lp->cell_size, &nv, nullptr,
+  rc = preprocess_device_impl(ctx, d_raw, dev_stride, n, lp->size_left, lp->dense, lp->workspace, lp->cell_size, &nv, nullptr,
     true, &deferred);
   if (rc != AGH_OK)
     return rc;
@@ -1651,8 +1677,8 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
           (void) hipFree(c->d_vox_bitmap);
           c->d_vox_bitmap = nullptr;
           c->vox_bitmap_cap = 0;
-          return agh_localize(ctx, xyz, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
-            samples_out, result);
+          return localize_impl(ctx, xyz, xyz_on_device, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out,
+            hands_cap, samples_out, result);
         }
         c->err = "the voxel lattice of the kept points exceeds 2^33 cells (1 GiB bitmap): set a workspace "
                  "(Localization::setWorkspace) that bounds the scene";

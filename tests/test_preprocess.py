@@ -192,6 +192,17 @@ def test_localize_one_call_equals_the_four_call_chain_and_the_oracle(svm_model, 
             assert np.array_equal(got["inlier_idx"], oidx)
             for f in HANDLE_FIELDS:
                 assert np.array_equal(got["handles"][f], ohd[f]), f
+        if it in (2, 5):  # the raw capture already on the device (agh_localize_device), packed and with pcl's 32-byte stride
+            import torch
+
+            raw = rc.xyz if it == 2 else np.concatenate([rc.xyz, np.zeros((len(rc.xyz), 5), np.float32)], axis=1)
+            dev = one.localize(torch.from_numpy(np.ascontiguousarray(raw)).cuda(), rc.size_left, rc.workspace, samples=samples,
+                               classify=classify, min_inliers=2)
+            assert dev["n_voxels"] == nv_ref and np.array_equal(dev["inlier_idx"], idx)
+            for f in HYP_FIELDS:
+                assert np.array_equal(dev["hands"][f], h[f]), f
+            for f in HANDLE_FIELDS:
+                assert np.array_equal(dev["handles"][f], hd[f]), f
         # the context is left as after the separate calls
         xyz_v, cam_v = one.cloud()
         xyz_c, cam_c = chain.cloud()
