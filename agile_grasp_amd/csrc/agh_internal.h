@@ -141,6 +141,7 @@ struct Ctx
   hipEvent_t xyz_copied = nullptr;  // host-buffer agh_set_cloud from PINNED memory: recorded behind the coordinates' copy
   bool cam_copy_on_copy_stream = false;  // the last grid_build put the camera ids on copy_stream (copy_done was recorded)
   hipStream_t copy_stream = nullptr;  // host-buffer agh_set_cloud: the camera ids go up here while the grid build's first kernels run
+  bool copy_stream_failed = false;    // its creation failed once: not retried (the ids go up on the build's stream)
   std::string err;
 
   // cloud

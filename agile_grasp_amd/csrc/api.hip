@@ -864,7 +864,9 @@ static int preprocess_device_impl(agh_ctx* ctx, const float* d_xyz, int64_t stri
     {
       *deferred = true;
       c->defer_cloud_count = true;
-      return agh_set_cloud_device(ctx, c->d_vox_xyz, 12, c->d_vox_cam, n, hip_stream);
+      const int rc_set = agh_set_cloud_device(ctx, c->d_vox_xyz, 12, c->d_vox_cam, n, hip_stream);
+      c->defer_cloud_count = false;  // (also when the call left before it consumed the flag: it must never reach the caller's NEXT cloud)
+      return rc_set;
     }
     HIPCHK(c, hipStreamSynchronize(st));  // the voxel count sizes the search structure
     h = *c->h_vox_desc;
@@ -1559,22 +1561,50 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
   if (rc != AGH_OK)
     return rc;
   c->cloud_async = false;  // (everything below is queued on the context's own stream, and the call ends with its synchronisation)
+  // a failure between the launches and the synchronisation, while the host only knows a BOUND of the cloud's size: the context
+  // must not be left believing the bound is the cloud
+  auto drop_bound_cloud = [&]() {
+    if (c->n_is_bound)
+    {
+      c->n_is_bound = false;
+      c->has_cloud = false;
+      c->n = 0;
+      c->cloud_off_on_device = false;
+    }
+  };
+  // (every error return from here on first drains the stream -- a pinned source may still be in flight, the caller may free it
+  // as soon as the call returns -- and drops the bound)
+  auto fail = [&](int code) {
+    (void) hipStreamSynchronize(st);
+    drop_bound_cloud();
+    return code;
+  };
+#define LOC_HIPCHK(expr)                                                  \
+  do                                                                      \
+  {                                                                       \
+    hipError_t e__ = (expr);                                              \
+    if (e__ != hipSuccess)                                                \
+    {                                                                     \
+      c->err = std::string(#expr) + ": " + hipGetErrorString(e__);        \
+      return fail(AGH_ERR_HIP);                                           \
+    }                                                                     \
+  } while (0)
   // ---- 2. buffers for the bounds ----
   if ((rc = ensure_call_buffers(c, std::max<int64_t>(S, 1))) != AGH_OK)  // (S = 0: the later stages still want their buffers)
-    return rc;
+    return fail(rc);
   if (S > c->idx_cap || !c->d_idx_own)
   {
     if ((rc = dev_alloc(c, &c->d_idx_own, (size_t) std::max<int64_t>(S, 1024))))
-      return rc;
+      return fail(rc);
     c->idx_cap = std::max<int64_t>(S, 1024);
   }
   if ((rc = ensure_host_staging(c, S, 1024)) != AGH_OK)
-    return rc;
+    return fail(rc);
   int32_t* h_idx = reinterpret_cast<int32_t*>(c->h_pin + kPinHeaderBytes);
   const int64_t hyp_bound = 8 * S;
   const int64_t hand_bound = std::min<int64_t>(hyp_bound, 8192);
   if ((rc = ensure_handle_buffers(c, hand_bound)) != AGH_OK)
-    return rc;
+    return fail(rc);
   if (lp->classify && c->s_cap * 8 > c->keep_cap)
   {
     if (c->d_keep)
@@ -1584,8 +1614,8 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     c->d_keep = nullptr;
     c->d_svm_sums = nullptr;
     c->keep_cap = 0;
-    HIPCHK(c, hipMalloc((void**) &c->d_keep, (size_t) (c->s_cap * 8)));
-    HIPCHK(c, hipMalloc((void**) &c->d_svm_sums, (size_t) (c->s_cap * 8) * sizeof(double)));
+    LOC_HIPCHK(hipMalloc((void**) &c->d_keep, (size_t) (c->s_cap * 8)));
+    LOC_HIPCHK(hipMalloc((void**) &c->d_svm_sums, (size_t) (c->s_cap * 8) * sizeof(double)));
     c->keep_cap = c->s_cap * 8;
   }
   int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
@@ -1600,29 +1630,18 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     if (lp->sample_idx)
     {
       std::memcpy(h_idx, lp->sample_idx, sizeof(int32_t) * (size_t) S);
-      HIPCHK(c, hipMemcpyAsync(c->d_idx_own, h_idx, sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+      LOC_HIPCHK(hipMemcpyAsync(c->d_idx_own, h_idx, sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
     }
     else
     {
       hipLaunchKernelGGL(k_draw_samples, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, (const int*) c->d_cloud_off, 1, (int) S,
         (unsigned long long) lp->sample_seed, c->d_idx_own, h_idx);
-      HIPCHK(c, hipGetLastError());
+      LOC_HIPCHK(hipGetLastError());
     }
   }
   // ---- 4. search -> classification -> kept hands -> handle search, then the one synchronisation ----
   VoxDesc h;
   bool handles_only = false;
-  // a failure between the launches and the synchronisation, while the host only knows a BOUND of the cloud's size: the context
-  // must not be left believing the bound is the cloud
-  auto drop_bound_cloud = [&]() {
-    if (c->n_is_bound)
-    {
-      c->n_is_bound = false;
-      c->has_cloud = false;
-      c->n = 0;
-      c->cloud_off_on_device = false;
-    }
-  };
   for (int attempt = 0;; attempt++)
   {
     for (int k = 0; k < (handles_only ? 4 : 8); k++)  // ([4..6], the search's counts, outlive a repeat of the handle search alone)
@@ -1646,7 +1665,7 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
       hipLaunchKernelGGL(k_compact_kept, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_out_own, (const int64_t*) c->d_nout,
         c->s_cap * 8, lp->classify ? 1 : 0, c->d_h_hands, (int) hand_bound, d_hcount, h_hands, (int) c->h_pin_handles_cap, h_counts,
         (const int32_t*) c->d_flags);
-      HIPCHK(c, hipGetLastError());
+      LOC_HIPCHK(hipGetLastError());
     }
     timing_begin(c, st);
     rc = handle_search(c, hand_bound, x1, x2, lp->min_inliers, lp->min_length, st, hm, with_sequential, d_hcount);
@@ -1743,6 +1762,7 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     std::memcpy(hands_out, h_hands, sizeof(agh_hypothesis) * (size_t) n_kept);
   return AGH_OK;
 }
+#undef LOC_HIPCHK
 
 int agh_synchronize(agh_ctx* ctx)
 {

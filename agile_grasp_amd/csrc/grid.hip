@@ -362,13 +362,23 @@ int grid_build(Ctx* c, hipStream_t st)
   bool cam_gate = false;
   if (c->pending_cam_host)
   {
-    if (!c->copy_stream && (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->copy_gate, hipEventDisableTiming) != hipSuccess))
+    if (!c->copy_stream && !c->copy_stream_failed &&
+        (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&c->copy_gate, hipEventDisableTiming) != hipSuccess))
     {
+      // whatever was created goes again, and the failure is remembered: the camera ids then go up on the build's own stream
+      // for the rest of the context's life instead of retrying (and leaking) on every build
+      if (c->copy_gate)
+        (void) hipEventDestroy(c->copy_gate);
+      if (c->copy_done)
+        (void) hipEventDestroy(c->copy_done);
       if (c->copy_stream)
         (void) hipStreamDestroy(c->copy_stream);
+      c->copy_gate = nullptr;
+      c->copy_done = nullptr;
       c->copy_stream = nullptr;
+      c->copy_stream_failed = true;
     }
     if (c->copy_stream)
       cam_gate = hipEventRecord(c->copy_gate, st) == hipSuccess && hipStreamWaitEvent(c->copy_stream, c->copy_gate, 0) == hipSuccess;

@@ -120,7 +120,20 @@ Rccl* rccl()
 }
 
 // n contexts of one process exchanging through device copies (agh_comm_init_local)
-constexpr int kLocalBarrierTimeoutS = 120;
+// How long a rank of the in-process communicator waits for its peers before it declares the group dead: 600 s, or
+// AGH_LOCAL_BARRIER_TIMEOUT_S (a legitimately slow rank -- the first call's 134 MB pool allocation, an all-points antipodal pass on a
+// big cloud, a debugger -- must not break the group; 0 = wait for ever).  A group that timed out or was aborted stays dead: every
+// later collective returns AGH_ERR_STATE at once ("communicator unusable", distinct from a HIP failure).
+inline long local_barrier_timeout_s()
+{
+  static const long t = [] {
+    const char* e = std::getenv("AGH_LOCAL_BARRIER_TIMEOUT_S");
+    char* end = nullptr;
+    const long v = e ? std::strtol(e, &end, 10) : 600;
+    return (e && end != e && v >= 0) ? v : 600;
+  }();
+  return t;
+}
 struct LocalGroup
 {
   int n = 0;
@@ -143,12 +156,24 @@ struct LocalGroup
       generation++;
       cv.notify_all();
     }
-    else if (!cv.wait_for(lk, std::chrono::seconds(kLocalBarrierTimeoutS), [&] { return generation != g || failed; }))
+    else
     {
-      // a rank never came (it returned before the collective on an error its peers did not share -- a broken precondition,
-      // e.g. no cloud on one rank): fail every waiter instead of hanging the process; the group is unusable afterwards
-      failed = true;
-      cv.notify_all();
+      const long tmo = local_barrier_timeout_s();
+      auto done = [&] { return generation != g || failed; };
+      bool came = true;
+      if (tmo == 0)
+        cv.wait(lk, done);
+      else
+        came = cv.wait_for(lk, std::chrono::seconds(tmo), done);
+      if (!came)
+      {
+        // a rank never came (it returned before the collective on an error its peers did not share -- a broken precondition):
+        // fail every waiter instead of hanging the process; the group is unusable afterwards, whoever arrives later
+        // (`arrived` is cleared so that a late rank cannot complete a generation of a dead group)
+        failed = true;
+        arrived = 0;
+        cv.notify_all();
+      }
     }
     return !failed;
   }
@@ -156,6 +181,7 @@ struct LocalGroup
   {
     std::lock_guard<std::mutex> lk(m);
     failed = true;
+    arrived = 0;
     cv.notify_all();
   }
 };

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const 
   __shared__ __attribute__((aligned(16))) double termbuf[kNumSums * kTS];
   __shared__ unsigned long long ktile[kKeyTile];
   __shared__ RowTable rt;
-  __shared__ int count;
+  __shared__ int count, n_s;
   __shared__ long long base_s;
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -465,14 +465,18 @@ __global__ __launch_bounds__(256) void k_taubin_moments_huge(GridView gv, const 
       atomicAdd(&count, mine);
   }
   __syncthreads();
-  const int n = count;
+  // (`count` becomes the second walk's cursor below: the first walk's total is published through a word of its own, so that no
+  // wave can read the counter after thread 0 has cleared it -- the barrier above orders the atomics, not that store)
   if (tid == 0)
   {
-    const unsigned long long b0 = atomicAdd(pool_count, (unsigned long long) n);
-    base_s = b0 + (unsigned long long) n <= (unsigned long long) kHugeEntries ? (long long) b0 : -1;
+    const int n0 = count;
+    n_s = n0;
+    const unsigned long long b0 = atomicAdd(pool_count, (unsigned long long) n0);
+    base_s = b0 + (unsigned long long) n0 <= (unsigned long long) kHugeEntries ? (long long) b0 : -1;
     count = 0;
   }
   __syncthreads();
+  const int n = n_s;
   const long long base = base_s;
   if (base < 0)
   {

@@ -342,3 +342,102 @@ def train_svm(features, labels, C=1.0, max_iter=1000, eps=float(np.finfo(np.floa
     alpha_out[order] = a
     return dict(w=v.astype(np.float32), rho=rho, iterations=min(it, max_iter), n_sv=int((np.abs(a) > 0).sum()),
                 alpha=alpha_out, sv_order=order[np.abs(a) > 0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# An INDEPENDENT HOG (row a18: cv::HOGDescriptor::compute, call site learning.cpp:194-195,220), written from the PUBLISHED
+# algorithm (Dalal & Triggs 2005 with OpenCV's documented parameters: 64x64 window, 16x16 blocks at stride 8, 8x8 cells,
+# 9 unsigned orientation bins, Gaussian block window sigma = 4, L2-Hys 0.2, sqrt gamma) -- NOT from OpenCV's source layout:
+# no PixData tables, no count1/2/4 pixel groups, no per-block accumulation order.  Every vote is spelled out: for each pixel
+# of each block, its Gaussian weight, its two orientation bins (linear interpolation), its up-to-four cells (bilinear
+# interpolation; cells outside the block get nothing), accumulated in float64 in plain raster order.  The arrays run over
+# the IMAGES (axis 0), the loops over windows, blocks and pixels -- so the structure of the sum is the textbook one.
+#
+# `angle`: "exact" = atan2 of the gradient (the algorithm as published); "opencv24" = the documented polynomial of OpenCV
+# 2.4's fastAtan2 ("accuracy about 0.3 degrees"), which cartToPolar uses there -- the one place where the library's
+# arithmetic, not the algorithm, decides digits: on a binary image the gradient has eight directions, the axis-aligned
+# four are exact in both, the diagonals differ by 1.7e-4 rad, i.e. 4.8e-4 of a bin.
+# ---------------------------------------------------------------------------------------------------------------------
+def _reflect101(p, n):
+    return -p if p < 0 else (2 * n - 2 - p if p >= n else p)
+
+
+def _fast_atan2_deg(y, x):
+    """OpenCV 2.4 fastAtan2 (documented 7th-order odd polynomial on the octant), float32, degrees in [0, 360)."""
+    f = np.float32
+    sc = f(180.0 / np.pi)
+    p1, p3, p5, p7 = (f(0.9997878412794807) * sc, f(-0.3258083974640975) * sc, f(0.1555786518463281) * sc,
+                      f(-0.04432655554792128) * sc)
+    ax, ay = np.abs(x), np.abs(y)
+    eps = f(2.2204460492503131e-16)
+    swap = ax < ay
+    num = np.where(swap, ax, ay)
+    den = np.where(swap, ay, ax) + eps
+    c = (num / den).astype(f)
+    c2 = c * c
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    a = np.where(swap, f(90.0) - a, a)
+    a = np.where(x < 0, f(180.0) - a, a)
+    a = np.where(y < 0, f(360.0) - a, a)
+    return a.astype(f)
+
+
+def hog_bruteforce(images, angle="opencv24"):
+    """images: (n, 80, 100) uint8 -> (n, 3528) float32 descriptors, layout window / block (x-major) / cell (x-major) / bin."""
+    f = np.float32
+    img = np.asarray(images, np.uint8).reshape(-1, 80, 100)
+    n, H, W = img.shape
+    g = np.sqrt(img.astype(f))  # gamma correction
+    # centred differences, reflect-101 at the image border, on the WHOLE image (OpenCV computes the gradient image first)
+    xs_p = [_reflect101(x + 1, W) for x in range(W)]
+    xs_m = [_reflect101(x - 1, W) for x in range(W)]
+    ys_p = [_reflect101(y + 1, H) for y in range(H)]
+    ys_m = [_reflect101(y - 1, H) for y in range(H)]
+    dx = (g[:, :, xs_p] - g[:, :, xs_m]).astype(f)
+    dy = (g[:, ys_p, :] - g[:, ys_m, :]).astype(f)
+    mag = np.sqrt(dx * dx + dy * dy).astype(f)
+    if angle == "exact":
+        th = np.arctan2(dy.astype(np.float64), dx.astype(np.float64))
+        th = np.where(th < 0, th + 2 * np.pi, th)
+        a = th * (9.0 / np.pi) - 0.5
+        h0 = np.floor(a)
+        w1 = (a - h0)
+    else:
+        deg = _fast_atan2_deg(dy, dx)
+        a = (deg * f(np.pi / 180)).astype(f) * f(9 / np.pi) - f(0.5)
+        h0 = np.floor(a)
+        w1 = (a - h0.astype(f)).astype(f)
+    b0 = np.mod(h0.astype(np.int64), 9)
+    b1 = np.mod(b0 + 1, 9)
+    v0 = (mag * (f(1) - w1.astype(f))).astype(f)  # the two votes of a pixel, before the spatial weights
+    v1 = (mag * w1.astype(f)).astype(f)
+    out = np.zeros((n, 2, 7, 7, 2, 2, 9), np.float64)  # window, block x, block y, cell x, cell y, bin
+    rows = np.arange(n)
+    for win in range(2):
+        wx = 32 * win
+        for bx in range(7):
+            for by in range(7):
+                hist = out[:, win, bx, by]
+                for i in range(16):  # row inside the block
+                    for j in range(16):  # column inside the block
+                        gw = f(np.exp(f(-((i - 8.0) ** 2 + (j - 8.0) ** 2) / (2.0 * 4.0 * 4.0))))
+                        cxf = (j + 0.5) / 8.0 - 0.5
+                        cyf = (i + 0.5) / 8.0 - 0.5
+                        x0, y0 = int(np.floor(cxf)), int(np.floor(cyf))
+                        fx, fy = f(cxf - x0), f(cyf - y0)
+                        py, px = by * 8 + i, wx + bx * 8 + j
+                        for cx, wxc in ((x0, f(1) - fx), (x0 + 1, fx)):
+                            if cx < 0 or cx > 1:
+                                continue
+                            for cy, wyc in ((y0, f(1) - fy), (y0 + 1, fy)):
+                                if cy < 0 or cy > 1:
+                                    continue
+                                wgt = f(gw * f(wxc * wyc))
+                                np.add.at(hist[:, cx, cy], (rows, b0[:, py, px]), (v0[:, py, px] * wgt).astype(f))
+                                np.add.at(hist[:, cx, cy], (rows, b1[:, py, px]), (v1[:, py, px] * wgt).astype(f))
+    blk = out.reshape(n, 2 * 49, 36).astype(f)
+    # L2-Hys: normalise, clip at 0.2, normalise again
+    s = (1.0 / (np.sqrt((blk.astype(np.float64) ** 2).sum(-1)) + 36 * 0.1)).astype(f)
+    blk = np.minimum(blk * s[..., None], f(0.2))
+    s = (1.0 / (np.sqrt((blk.astype(np.float64) ** 2).sum(-1)) + 1e-3)).astype(f)
+    return (blk * s[..., None]).astype(f).reshape(n, 3528)
