@@ -85,6 +85,82 @@ def cpu_baseline(sc, n_sub: int, normals_mode: int, classify: bool, svm):
             "host_cores": cores}
 
 
+def timed_intervals(step, fence, steps: int, reps: int = 5):
+    """`reps` back-to-back intervals of `steps` steps each, every interval bracketed by `fence` (a device synchronisation): the
+    spread of ONE measurement.  A figure that is a single interval cannot tell a stall of the box (a clock ramp after seconds of
+    host work, a driver query from another process, a page fault of the first use) from a regression (the driver's
+    `batched` line, 4.13 ms against 1.20 in every other run); the median of several can, and min / max / first say which it was."""
+    ms = []
+    for _ in range(reps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        ms.append((time.perf_counter() - t0) / steps * 1e3)
+    return {"median_ms": statistics.median(ms), "min_ms": min(ms), "max_ms": max(ms), "first_ms": ms[0],
+            "intervals": reps, "steps_per_interval": steps, "all_ms": [round(x, 5) for x in ms]}
+
+
+def spin(step, fence, seconds: float):
+    """The same step untimed for `seconds`: brings the clocks to their steady state after host-side work (scene generation takes
+    seconds per cloud, the GPU idles meanwhile) and takes every first-use allocation out of what follows."""
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        for _ in range(10):
+            step()
+        fence()
+
+
+def static_traffic(key: str):
+    """Per-kernel HBM-side bytes per launch from the newest committed PMC pass of this workload (profiles/rNN_pmc_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied by scripts/pmc_traffic.py).  Static: counters
+    cannot be collected inside the timed run.  Returns ({kernel: bytes}, source string)."""
+    import hashlib
+
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+        tf = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tf):
+            continue
+        try:
+            blob = open(tf, "rb").read()
+            ks = json.loads(blob).get(key, {}).get("kernels")
+        except Exception:  # noqa: BLE001
+            ks = None
+        if ks:
+            return ({k: v["hbm_bytes_per_launch"] for k, v in ks.items()},
+                    f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (separate rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE passes over this workload, gfx950 corrections applied); not measured in this run")
+    return {}, None
+
+
+def taubin_stage_rooflines(k_ms, sum_nt: float, n_samples: int, args, distributed: bool):
+    """The Taubin stage (K1a + K1b + K1c: longer than the sweep) on the roofline like the sweep.  Algorithmic
+    bytes per launch, DESIGN.md section 4: K1a k_taubin_moments reads 16 B per r = 0.03 neighbour and writes the sorted list back
+    (16 * sum n_t each way); K1c k_taubin_frame reads the list and writes a 200-byte frame per sample; K1b k_taubin_eigen reads 296 B
+    and writes 96 B per sample (a latency chain: listed for completeness).  Times: HIP events of the untimed all-phase pass."""
+    traffic, src = static_traffic(f"{args.config}:{args.normals}") if not distributed else ({}, None)
+
+    def tr(prefix):
+        v = [b for k, b in traffic.items() if k.startswith(prefix)]
+        return sum(v) if v else None
+
+    out = []
+    for phase, kernel, nbytes, why in (
+            ("taubin_moments", "k_taubin_moments", 32.0 * sum_nt,
+             "gather latency + the reference's sequential summation order (37 dependent fp64 add chains per sample)"),
+            ("taubin_eigen", "k_taubin_eigen", 392.0 * n_samples, "one lane's ~5000-instruction dependent chain per sample"),
+            ("taubin_frame", "k_taubin_frame", 16.0 * sum_nt + 200.0 * n_samples, "fp64 VALU + LDS (n_t^2 pow6 terms when exhaustive)")):
+        ms = k_ms.get(phase, 0.0)
+        if ms <= 0:
+            continue
+        ach = nbytes / (ms * 1e-3) / 1e9
+        out.append({"kernel": kernel, "bound": "hbm", "limited_by": why, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "traffic": tr(kernel),
+                    "traffic_source": src})
+    return out
+
+
 def batched_throughput(args, dev, stream, normals_mode, classify, svm):
     """BASELINE config C5's batch on ONE GPU: the clouds with seeds 10.. (each as large as C2, 2000 samples each) laid end to
     end in one context (agh_set_cloud_batch_device), one launch set per step for all of them -- grid builds, Taubin
@@ -115,15 +191,12 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
             ctx.classify_torch(keep_t, stream=stream)
 
     settle(ctx, step, torch.cuda.synchronize)
+    spin(step, torch.cuda.synchronize, min(args.spin_seconds, 0.3))
     for _ in range(max(args.warmup, 3)):
         step()
-    torch.cuda.synchronize()
     steps = max(5, args.steps // 2)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    spread = timed_intervals(step, torch.cuda.synchronize, steps, 5)
+    dt = spread["median_ms"] * 1e-3
     ctx.synchronize()
     n_hyp = int(nout_t.item())
     ctx.set_profile(1)
@@ -137,6 +210,7 @@ def batched_throughput(args, dev, stream, normals_mode, classify, svm):
     ctx.close()
     return {"workload": f"C5 batch: {C} two-view 300000-point clouds (seeds 10..{9 + C}), 2000 samples each, one context, one launch "
                         "set per step", "clouds": C, "samples": S, "hypotheses": n_hyp, "steps": steps, "ms_per_batch": dt * 1e3,
+            "ms_per_batch_spread": spread, "kernel_ms_sum": sum(v for k, v in k_ms.items() if not k.startswith("total")),
             "ms_per_cloud": dt * 1e3 / C, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_batch": k_ms,
             "roofline": {"kernel": "k_hand_sweep", "achieved": sweep_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sweep_bytes / sweep_s / 1e9 / HBM_PEAK_GBS) if sweep_s > 0 else 0.0,
@@ -168,15 +242,12 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
             ctx.classify_torch(keep_t, stream=stream)
 
     settle(ctx, step, torch.cuda.synchronize)
+    spin(step, torch.cuda.synchronize, min(args.spin_seconds, 0.2))
     for _ in range(max(args.warmup, 5)):
         step()
-    torch.cuda.synchronize()
     steps = steps or max(10, args.steps // 2)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    spread = timed_intervals(step, torch.cuda.synchronize, steps, 5)
+    dt = spread["median_ms"] * 1e-3
     ctx.synchronize()
     n_hyp = int(nout_t.item())
     valid = int((ctx.frames()["valid"] != 0).sum())
@@ -198,7 +269,8 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
                     "launch_ms": k_ms["hand_sweep"], "note": "HIP events of an untimed pass of the same steps"}
     ctx.close()
     res = {"workload": label, "points": sc.n, "samples": S, "frames": valid, "hypotheses": n_hyp, "steps": steps,
-           "ms_per_step": dt * 1e3, "value": n_hyp / dt, "unit": "hypotheses/s", "kernel_ms_per_step": k_ms}
+           "ms_per_step": dt * 1e3, "ms_per_step_spread": spread, "value": n_hyp / dt, "unit": "hypotheses/s",
+           "kernel_ms_per_step": k_ms}
     if kept is not None:
         res["svm_kept"] = kept
     if roof is not None:
@@ -219,18 +291,22 @@ def host_api_extra(args, dev, sc, normals_mode):
         hyps = ctx.find_hands(sc.samples)
     calls = max(10, args.steps // 2)
     t_set = t_find = 0.0
+    per = []
     for _ in range(calls):
         t0 = time.perf_counter()
         ctx.set_cloud(sc.xyz, sc.cam)
         t1 = time.perf_counter()
         hyps = ctx.find_hands(sc.samples)
+        t2 = time.perf_counter()
         t_set += t1 - t0
-        t_find += time.perf_counter() - t1
+        t_find += t2 - t1
+        per.append(t2 - t0)
     ctx.close()
-    dt = (t_set + t_find) / calls
+    dt = statistics.median(per)
     return {"what": "agh_set_cloud (H2D of 12 B/point + camera ids, grid build) + agh_find_hands (search; count, flags and 160-byte "
                     "records land in pinned host memory), host numpy buffers in and out, Python binding", "calls": calls,
-            "ms_per_call": dt * 1e3,
+            "ms_per_call": dt * 1e3, "ms_per_call_min": min(per) * 1e3, "ms_per_call_max": max(per) * 1e3,
+            "ms_per_call_mean": sum(per) / calls * 1e3,
             "ms_set_cloud": t_set / calls * 1e3, "ms_find_hands": t_find / calls * 1e3, "value": len(hyps) / dt,
             "unit": "hypotheses/s", "hypotheses": int(len(hyps))}
 
@@ -278,7 +354,7 @@ def sq_issue_figures(kernel: str):
     Static like roofline.traffic: counters cannot be collected inside the timed run."""
     import hashlib
 
-    for name in ("r05_c2_sq_counters.txt", "r04_c2_sq_counters.txt"):
+    for name in ("r06_c2_sq_counters.txt", "r05_c2_sq_counters.txt", "r04_c2_sq_counters.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -293,16 +369,22 @@ def sq_issue_figures(kernel: str):
         need = ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
         if not all(k in tab for k in need) or tab["SQ_WAVES"] <= 0 or tab["SQ_WAVE_CYCLES"] <= 0:
             continue
-        waves_per_simd = 3  # three 256-thread work-groups per CU (LDS), a wave of each on every SIMD
-        return {"valu_insts_per_wave": tab["SQ_INSTS_VALU"] / tab["SQ_WAVES"], "waves": int(tab["SQ_WAVES"]) * 32,
-                "wave_issuing_frac": tab["SQ_ACTIVE_INST_ANY"] / tab["SQ_WAVE_CYCLES"],
-                "wave_valu_frac": tab["SQ_ACTIVE_INST_VALU"] / tab["SQ_WAVE_CYCLES"],
-                "resident_waves_per_simd": waves_per_simd,
-                "simd_issue_frac": waves_per_simd * tab["SQ_ACTIVE_INST_ANY"] / tab["SQ_WAVE_CYCLES"],
-                "simd_valu_frac": waves_per_simd * tab["SQ_ACTIVE_INST_VALU"] / tab["SQ_WAVE_CYCLES"],
-                "source": f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (SQ counters of a separate "
-                          "rocprofv3 --pmc pass over this workload; simd_* = resident waves per SIMD x the fraction of a wave's "
-                          "lifetime it issues [any / VALU] instructions: ~1 means the SIMD's issue port is saturated)"}
+        # Per shader engine (the table holds per-SE averages; 32 SEs x 8 CUs x 4 SIMDs): SQ_ACTIVE_INST_VALU counts, in units of
+        # four cycles, the time a wave's VALU instruction occupies its SIMD; a SIMD executes one at a time, so
+        # 4 x SQ_ACTIVE_INST_VALU / (32 SIMDs x SQ_BUSY_CYCLES) is the fraction of the kernel's duration the average SIMD's vector
+        # ALU is busy -- it cannot exceed 1 (the old `simd_issue_frac` = resident waves x a wave's issuing share did).
+        simds_per_se = 32.0
+        out = {"valu_insts_per_wave": tab["SQ_INSTS_VALU"] / tab["SQ_WAVES"], "waves": int(tab["SQ_WAVES"]) * 32,
+               "wave_issuing_frac": tab["SQ_ACTIVE_INST_ANY"] / tab["SQ_WAVE_CYCLES"],
+               "wave_valu_frac": tab["SQ_ACTIVE_INST_VALU"] / tab["SQ_WAVE_CYCLES"],
+               "source": f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (SQ counters of a separate "
+                         "rocprofv3 --pmc pass over this workload, per-dispatch averages per shader engine)"}
+        if tab.get("SQ_BUSY_CYCLES", 0) > 0:
+            out["simd_valu_busy_frac"] = 4.0 * tab["SQ_ACTIVE_INST_VALU"] / (simds_per_se * tab["SQ_BUSY_CYCLES"])
+            # SQ_WAVE_CYCLES is tallied in the same four-cycle units: resident wave-time over SIMD-time (<= 3 here: LDS bounds
+            # the kernel to three work-groups per CU, one wave of each on every SIMD; what is missing from 3 is the tail)
+            out["mean_resident_waves_per_simd"] = 4.0 * tab["SQ_WAVE_CYCLES"] / (simds_per_se * tab["SQ_BUSY_CYCLES"])
+        return out
     return None
 
 
@@ -353,7 +435,8 @@ def pipeline_extra(steps: int):
                         "(grasp_localizer.cpp:95-103), host buffers in and out",
             "voxels": int(nv), "hypotheses": int(t1[-1][1]), "svm_kept": int(t1[-1][2]), "handles": int(t1[-1][3]),
             "four_calls_ms": statistics.median(t[0] for t in t4) * 1e3, "agh_localize_ms": statistics.median(t[0] for t in t1) * 1e3,
-            "agh_localize_min_ms": min(t[0] for t in t1) * 1e3,
+            "agh_localize_min_ms": min(t[0] for t in t1) * 1e3, "agh_localize_max_ms": max(t[0] for t in t1) * 1e3,
+            "four_calls_min_ms": min(t[0] for t in t4) * 1e3, "four_calls_max_ms": max(t[0] for t in t4) * 1e3,
             "agh_localize_device_ms": statistics.median(t[0] for t in td) * 1e3, "calls": steps}
 
 
@@ -811,6 +894,8 @@ def main():
             break
         seg[0] = 8 * S
     ctx.synchronize()  # raises if any neighbourhood overflowed the kernels' capacity
+    # the spread of the figure above: five more intervals of the same K steps (the contract's `value` stays the ONE interval above)
+    spread = timed_intervals(step, fence, args.steps, 5) if not distributed else None
     # HIP events on the launch stream bracket k_hand_sweep inside the timed region -- on every fourth step (profile level 3):
     # an event record between two dependent kernels costs ~3 us, two per step 6.3 us of a 0.24 ms step (measured: 0.2436
     # against 0.2373 ms), and bracketing all six phases ~35 us, so the full breakdown comes from a second, untimed pass.
@@ -907,21 +992,11 @@ def main():
         achieved = sweep_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
         traffic, traffic_src = None, None
         if not distributed:
-            import hashlib
-
-            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
-                tf = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tf):
-                    try:
-                        blob = open(tf, "rb").read()
-                        traffic = json.loads(blob).get(f"{args.config}:{args.normals}", {}).get("hand_sweep_bytes_per_launch")
-                    except Exception:
-                        traffic = None
-                    if traffic is not None:
-                        traffic_src = (f"static: profiles/{name} sha256 {hashlib.sha256(blob).hexdigest()[:16]} (separate rocprofv3 --pmc "
-                                       "FETCH_SIZE / WRITE_SIZE passes over this workload, gfx950 corrections applied); not measured in this run")
-                        break
+            tmap, traffic_src = static_traffic(f"{args.config}:{args.normals}")
+            hs = [b for k, b in tmap.items() if k.startswith("k_hand_sweep")]
+            traffic = hs[0] if hs else None
         issue = sq_issue_figures("k_hand_sweep") if not distributed else None
+        stage_roof = taubin_stage_rooflines(k_ms, float(nt.sum()), n_local_samples, args, distributed)
         # whole-path algorithmic bytes (B_alg of BASELINE.md section 4), of this rank's share
         b_alg = 16.0 * sc.n + 16.0 * float(nt.sum() + nh.sum()) + 160.0 * n_local_hyp + (14112 if classify else 0)
         # --shard clouds (the default; N = 1 is its first member: one cloud on one GPU): one more cloud per GPU -- per-GPU work
@@ -954,13 +1029,17 @@ def main():
             # "bound": what the counters say limits the kernel -- its SIMDs' instruction issue, not HBM (traffic is BELOW the
             # algorithmic bytes: the cloud is cache resident).  achieved / peak / frac stay the contract's HBM figures; the
             # issue-slot figures beside them show what an instruction cut can still buy.
-            "roofline": {"bound": "valu-issue" if issue else "hbm", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "limited_by": "wave occupancy and VALU time, not bandwidth: see `issue` (the SIMD's vector ALU "
+                         "busy fraction and the mean resident waves per SIMD of the committed SQ pass) -- the cloud is cache resident and "
+                         "the kernel's HBM-side traffic is BELOW its algorithmic bytes", "kernel": "k_hand_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "issue": issue,
                          "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": k_ms.get("hand_sweep", 0.0),
                          "launches_timed": sweep_timed, "launches_timed_note": "HIP events around every fourth k_hand_sweep "
                          "launch of the timed region (two event records per step cost 6 us of a 0.24 ms step)",
                          "launch_samples": n_local_samples},
+            "roofline_stages": stage_roof,
+            "ms_per_step_spread": spread,
             "kernel_ms_per_step": k_ms,
             "path_algorithmic_bytes": b_alg,
             "path_GBps": b_alg / (dt / args.steps) / 1e9,
