@@ -80,12 +80,12 @@ assert HYP_DTYPE.itemsize == 160 and FRAME_DTYPE.itemsize == 200 and HANDLE_DTYP
 
 EXPORTS = [
     "agh_default_params", "agh_create", "agh_destroy", "agh_last_error", "agh_set_cloud", "agh_set_cloud_device", "agh_set_cloud_batch", "agh_set_cloud_batch_device",
-    "agh_preprocess", "agh_preprocess_device", "agh_localize", "agh_localize_device", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
+    "agh_preprocess", "agh_preprocess_device", "agh_localize", "agh_localize_device", "agh_localize_begin", "agh_localize_stage", "agh_localize_end", "agh_get_cloud", "agh_find_handles", "agh_find_hands", "agh_find_hands_device", "agh_load_svm", "agh_load_svm_file", "agh_classify",
     "agh_classify_device", "agh_get_frames", "agh_get_neighbor_counts", "agh_get_images", "agh_get_hog",
     "agh_get_normals", "agh_get_timing", "agh_get_timing_counts", "agh_set_profile", "agh_synchronize", "agh_selftest_math",
     "agh_set_training_images", "agh_get_training_images", "agh_hog_images", "agh_train_svm", "agh_save_svm_file",
     "agh_load_svm_model", "agh_get_learning_points", "agh_get_epoch", "agh_get_packed_images", "agh_classify_images", "agh_comm_rccl_origin",
-    "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_last_exchange", "agh_comm_set_segment_records",
+    "agh_save_svm_file_ex", "agh_comm_unique_id", "agh_comm_init", "agh_comm_init_local", "agh_comm_destroy", "agh_comm_rank", "agh_comm_last_count", "agh_comm_last_exchange", "agh_comm_set_segment_records", "agh_comm_inject_fault",
     "agh_shard_slice", "agh_find_hands_sharded_device", "agh_find_hands_sharded", "agh_classify_sharded_device",
     "agh_classify_sharded",
 ]
@@ -336,7 +336,7 @@ class Context:
 
     def localize(self, xyz, size_left: int, workspace, samples=None, n_samples: int = 0, sample_seed: int = 1,
                  classify: bool = True, min_inliers: int = 3, min_length: float = 0.005, cell_size: float = 0.003,
-                 dense: bool = False):
+                 dense: bool = False, phase: str = "both"):
         """agh_localize: raw capture -> voxels -> search -> SVM -> handles in one call with one synchronisation
         (grasp_localizer.cpp:95-103).  `samples`: indices into the voxelised cloud, or None: n_samples are drawn on the device.
         Returns a dict: handles, inlier_idx, hands (what the handle search ran on), samples, n_voxels, n_hypotheses."""
@@ -370,10 +370,47 @@ class Context:
                                      np.zeros(max(S, 1), np.int32))
         handles, idx, hands, sout = bufs
         res = AghLocalizeResult()
+        if phase == "begin":  # agh_localize_begin: everything queued; localize_end() collects
+            assert not on_device
+            self._loc_keep = (xyz, samples, lp)  # (the capture must stay valid until the end call)
+            self._loc_S = S
+            self._check(self.lib.agh_localize_begin(self._h, xyz_ptr, C.c_int64(stride_b), C.c_int64(n_pts), C.byref(lp)))
+            return None
         fn = self.lib.agh_localize_device if on_device else self.lib.agh_localize
         self._check(fn(self._h, xyz_ptr, C.c_int64(stride_b), C.c_int64(n_pts), C.byref(lp), handles.ctypes.data_as(C.c_void_p),
                        C.c_int64(hcap), _p(idx, C.c_int32), C.c_int64(hcap), hands.ctypes.data_as(C.c_void_p), C.c_int64(hcap),
                        _p(sout, C.c_int32), C.byref(res)))
+        return self._localize_result(res, S)
+
+    def localize_begin(self, xyz, size_left: int, workspace, **kw):
+        """agh_localize_begin: the chain of this capture queued, nothing waited for (see include/agh.h)."""
+        return self.localize(xyz, size_left, workspace, phase="begin", **kw)
+
+    def localize_stage(self, xyz):
+        """agh_localize_stage: the NEXT capture up on a second stream, beside the chain in flight.  Pass the same array object to
+        the next localize_begin (the library recognises the capture by pointer, stride and count)."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        self._stage_keep = xyz
+        self._check(self.lib.agh_localize_stage(self._h, _p(xyz, C.c_float), C.c_int64(xyz.shape[1] * 4), C.c_int64(xyz.shape[0])))
+        return xyz
+
+    def localize_end(self):
+        """agh_localize_end: the one synchronisation and the results of the chain localize_begin queued."""
+        if getattr(self, "_loc_bufs", None) is None:  # (no begin before: the library says so)
+            self._loc_bufs = (np.zeros(1, HANDLE_DTYPE), np.zeros(1, np.int32), np.zeros(1, HYP_DTYPE), np.zeros(1, np.int32))
+            self._loc_S = 0
+        handles, idx, hands, sout = self._loc_bufs
+        hcap = handles.shape[0]
+        res = AghLocalizeResult()
+        self._check(self.lib.agh_localize_end(self._h, handles.ctypes.data_as(C.c_void_p), C.c_int64(hcap), _p(idx, C.c_int32),
+                                              C.c_int64(hcap), hands.ctypes.data_as(C.c_void_p), C.c_int64(hcap),
+                                              _p(sout, C.c_int32), C.byref(res)))
+        self._loc_keep = None
+        return self._localize_result(res, self._loc_S)
+
+    def _localize_result(self, res, S):
+        handles, idx, hands, sout = self._loc_bufs
         self.n = res.n_voxels
         self.last_samples = S
         self.last_n = res.n_hypotheses
@@ -524,6 +561,10 @@ class Context:
 
     def comm_set_segment_records(self, records: int):
         self._check(self.lib.agh_comm_set_segment_records(self._h, C.c_int64(records)))
+
+    def comm_inject_fault(self, sites: int):
+        """agh_comm_inject_fault (testing aid): this rank fails on its own at the named sites of its next sharded call."""
+        self._check(self.lib.agh_comm_inject_fault(self._h, C.c_int32(sites)))
 
     def comm_rank(self):
         r, n = C.c_int32(0), C.c_int32(0)

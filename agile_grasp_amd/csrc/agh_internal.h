@@ -130,6 +130,24 @@ struct HostMirror
   int64_t* hdr;         // [0] hypotheses found, [1] flags[0] as the kernel saw it
 };
 
+// agh_localize_begin / _stage / _end (api.hip): the one chain in flight and the capture staged for the next one
+struct LocalizeState
+{
+  bool active = false;        // a chain is queued and agh_localize_end has not collected it
+  bool repeated = false;      // inside the one repeat of a whole call (the voxel lattice outgrew the speculative bitmap)
+  bool deferred = false;      // the voxel count is still on the device
+  bool classify = false, with_sequential = false, explicit_samples = false;
+  int64_t S = 0, nv = 0;
+  int32_t min_inliers = 0;
+  double min_length = 0.0, x1 = 0.0, x2 = 0.0;
+  agh_localize_params lp{};   // (sample_idx cleared: the list lives in the pinned staging)
+  const float* d_raw = nullptr;  // where the chain read the raw capture (the context's raw buffer or the caller's device memory)
+  int64_t dev_stride = 0, n_raw = 0;
+  bool staged = false;        // agh_localize_stage: a capture is (being) copied into d_stage_xyz
+  const float* staged_src = nullptr;
+  int64_t staged_stride = 0, staged_n = 0;
+};
+
 struct Ctx
 {
   agh_params p;
@@ -180,6 +198,11 @@ struct Ctx
   int32_t* d_vox_cam = nullptr;
   int64_t vox_cap = 0;
   float* d_raw_xyz = nullptr;      // device copy of a raw host cloud
+  float* d_stage_xyz = nullptr;    // ... and of the NEXT one (agh_localize_stage); the two change places when it is adopted
+  int64_t stage_cap = 0;           // floats
+  hipStream_t stage_stream = nullptr;
+  hipEvent_t stage_done = nullptr;
+  LocalizeState loc;
   int64_t raw_cap = 0;             // floats
 
   // handle search (K5)
@@ -315,6 +338,7 @@ struct Ctx
   bool shard_symmetric_error = false;  // the last sharded device call failed on something every rank saw alike, after the ranks
                                        // had met in a collective: nobody is left waiting, the communicator stays usable
   int64_t shard_seg_override = 0;    // agh_comm_set_segment_records
+  int shard_inject = 0;              // agh_comm_inject_fault (testing aid): sites that fail on this rank, one shot each
   bool shard_full_exchange = false;  // exchange all 8 slots per sample instead of the 2-per-sample prefix
   int64_t shard_seg_records = 0, shard_seg_bytes = 0, shard_S = 0;
   agh_hypothesis* shard_out = nullptr;  // the caller's merged list of the last sharded search
@@ -358,6 +382,11 @@ inline hipError_t order_after_cloud(Ctx* c, hipStream_t st)
 // classes needs them), kFlagShardHard (some rank that had launched them still overflowed), kFlagSharded (a merge ran: the
 // decision comes from these bits, the rank's own bit 0 is ignored).
 constexpr int kFlagShardRetry = 32, kFlagShardHard = 64, kFlagSharded = 128, kFlagShardRetryHuge = 256;
+// ... and two for a rank that took part in the call's collectives without doing its share (shard.hip, "no rank leaves alone"):
+// kFlagShardPeerFailed (a rank's own failure: memory, a launch), kFlagShardPeerNoCloud (a rank holds no cloud) -- from the header
+// bits kHdrRankFailed / kHdrRankNoCloud of its segment
+constexpr int kFlagShardPeerFailed = 512, kFlagShardPeerNoCloud = 1024;
+constexpr int kHdrRankFailed = 32, kHdrRankNoCloud = 64;
 // word 1 of a segment header: an overflow of the capacity classes the rank had launched -- 1 with the larger classes off (level
 // 0: a retry with them helps), 8 with them on (level 1: a retry with the 6144 class helps), 16 with that on too (level 2: hard)
 // -- and 4 = bad sample index

@@ -528,7 +528,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_order_sweep, c->d_vmask, c->d_cloud_off, c->d_scloud, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count, c->d_huge_sorted, c->d_huge_normals, c->d_huge_base };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count, c->d_huge_sorted, c->d_huge_normals, c->d_huge_base, c->d_stage_xyz };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);
@@ -550,6 +550,10 @@ void agh_destroy(agh_ctx* ctx)
     (void) hipEventDestroy(c->xyz_copied);
   if (c->copy_stream)
     (void) hipStreamDestroy(c->copy_stream);
+  if (c->stage_done)
+    (void) hipEventDestroy(c->stage_done);
+  if (c->stage_stream)
+    (void) hipStreamDestroy(c->stage_stream);
   if (c->stream)
     (void) hipStreamDestroy(c->stream);
   delete ctx;
@@ -1266,6 +1270,16 @@ static int flags_to_status(Ctx* c, const int32_t* flags_in)
              "all (the pool of the classes beyond the LDS-resident ones); voxelise the cloud (localization.cpp:43) or reduce the radii";
     return AGH_ERR_CAPACITY;
   }
+  if (flags[0] & kFlagShardPeerNoCloud)
+  {
+    c->err = "a rank of the communicator holds no cloud (agh_set_cloud* on every rank first); no list";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (flags[0] & kFlagShardPeerFailed)
+  {
+    c->err = "a rank of the communicator could not do its share of the call (its own agh_last_error says why); no list";
+    return AGH_ERR_STATE;
+  }
   if ((flags[0] & 2) && !(flags[0] & 16))
   {
     c->err = "output buffer too small for the hypotheses found";
@@ -1480,38 +1494,203 @@ __global__ __launch_bounds__(1024) void k_compact_kept(const agh_hypothesis* __r
 }
 }  // namespace
 
-static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
-  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
-  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
+// agh_localize = agh_localize_begin (everything queued) + agh_localize_end (the one synchronisation, the results, the rare
+// repeats).  Between the two the caller may stage the NEXT capture (agh_localize_stage: upload on a second stream into a second
+// raw buffer, under this cloud's kernels), which the next begin adopts instead of uploading.  One chain is in flight at a time:
+// the context's device buffers, pinned mirrors and host-side cloud state are single.
+static int localize_begin_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n,
+  const agh_localize_params* lp);
+static int localize_end_impl(agh_ctx* ctx, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
+  agh_hypothesis* hands_out, int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
+
+static int localize_check_outputs(Ctx* c, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
+  agh_hypothesis* hands_out, int64_t hands_cap)
+{
+  if (handle_cap < 0 || idx_cap < 0 || hands_cap < 0 || (handle_cap > 0 && !handles_out) || (idx_cap > 0 && !inlier_idx_out) ||
+      (hands_cap > 0 && !hands_out))
+  {
+    c->err = "agh_localize: bad arguments (see include/agh.h)";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  return AGH_OK;
+}
 
 int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
   int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
 {
-  return localize_impl(ctx, xyz, false, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
-    samples_out, result);
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (result)
+    *result = agh_localize_result{ 0, 0, 0, 0, 0 };
+  int rc = localize_check_outputs(&ctx->c, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap);
+  if (rc == AGH_OK)
+    rc = localize_begin_impl(ctx, xyz, false, stride_bytes, n, lp);
+  if (rc != AGH_OK)
+    return rc;
+  return localize_end_impl(ctx, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap, samples_out, result);
 }
 
 int agh_localize_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
   int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
 {
-  return localize_impl(ctx, d_xyz, true, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap,
-    samples_out, result);
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (result)
+    *result = agh_localize_result{ 0, 0, 0, 0, 0 };
+  int rc = localize_check_outputs(&ctx->c, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap);
+  if (rc == AGH_OK)
+    rc = localize_begin_impl(ctx, d_xyz, true, stride_bytes, n, lp);
+  if (rc != AGH_OK)
+    return rc;
+  return localize_end_impl(ctx, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap, samples_out, result);
 }
 
-static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
-  agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
-  int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+int agh_localize_begin(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp)
+{
+  return localize_begin_impl(ctx, xyz, false, stride_bytes, n, lp);
+}
+
+int agh_localize_end(agh_ctx* ctx, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
+  agh_hypothesis* hands_out, int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  if (result)
+    *result = agh_localize_result{ 0, 0, 0, 0, 0 };
+  Ctx* c = &ctx->c;
+  if (!c->loc.active)
+  {
+    c->err = "agh_localize_end: no agh_localize_begin in flight";
+    return AGH_ERR_STATE;
+  }
+  const int rc = localize_check_outputs(c, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap);
+  if (rc != AGH_OK)
+  {
+    // (the chain is queued: drain it, leave the context as a failed call does)
+    (void) hipStreamSynchronize(c->stream);
+    c->loc.active = false;
+    if (c->n_is_bound)
+    {
+      c->n_is_bound = false;
+      c->has_cloud = false;
+      c->n = 0;
+      c->cloud_off_on_device = false;
+    }
+    return rc;
+  }
+  return localize_end_impl(ctx, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap, samples_out, result);
+}
+
+// The NEXT capture up, beside the chain in flight: into the context's second raw buffer, on a stream of its own.  A pageable
+// source makes the call last as long as the copy (the kernels of the chain in flight run meanwhile: that is the overlap); a
+// pinned one returns at once.  The source must stay valid until the copy is done: until the agh_localize_begin that adopts the
+// capture has returned (it makes the chain wait for the copy; the copy itself is then behind a host-side event wait).
+int agh_localize_stage(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
-  if (result)
-    *result = agh_localize_result{ 0, 0, 0, 0, 0 };
+  if (n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz))
+  {
+    c->err = "agh_localize_stage: bad arguments";
+    return AGH_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->loc.staged = false;
+  if (!c->stage_stream)
+  {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
+    if (hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming) != hipSuccess)
+    {
+      (void) hipStreamDestroy(c->stage_stream);
+      c->stage_stream = nullptr;
+      c->err = "agh_localize_stage: no event";
+      return AGH_ERR_HIP;
+    }
+  }
+  const bool as_is = stride_bytes <= 32;
+  const int64_t dev_stride = as_is ? stride_bytes : 12;
+  const int64_t need = n * (dev_stride / 4);
+  if (need > c->stage_cap || !c->d_stage_xyz)
+  {
+    // (nobody reads this buffer now: the chain in flight reads d_raw_xyz)
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_stage_xyz, (size_t) std::max<int64_t>(need, 1))))
+      return rc;
+    c->stage_cap = need;
+  }
+  if (n > 0)
+  {
+    if (as_is)
+      HIPCHK(c, hipMemcpyAsync(c->d_stage_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, c->stage_stream));
+    else
+      HIPCHK(c, hipMemcpy2DAsync(c->d_stage_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, c->stage_stream));
+  }
+  HIPCHK(c, hipEventRecord(c->stage_done, c->stage_stream));
+  c->loc.staged = true;
+  c->loc.staged_src = xyz;
+  c->loc.staged_stride = stride_bytes;
+  c->loc.staged_n = n;
+  return AGH_OK;
+}
+
+// search -> classification -> kept hands -> handle search, queued on the context's stream (handles_only: the handle search alone,
+// once more, on the hands that are already there)
+static int localize_queue(agh_ctx* ctx, bool handles_only)
+{
+  Ctx* c = &ctx->c;
+  LocalizeState& L = c->loc;
+  hipStream_t st = c->stream;
+  int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
+  agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
+  agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
+  int32_t* h_hidx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
+  const HandleMirror hm{ h_handles, (int) c->h_pin_handles_cap, h_hidx, (int) c->h_pin_handles_cap, h_counts };
+  int* d_hcount = c->d_h_counts + 4;  // (behind the HandleCounts record)
+  const int64_t hand_bound = std::min<int64_t>(8 * L.S, 8192);
+  int rc;
+  for (int k = 0; k < (handles_only ? 4 : 8); k++)  // ([4..6], the search's counts, outlive a repeat of the handle search alone)
+    h_counts[k] = 0;
+  L.with_sequential = c->handles_sequential;
+  if (!handles_only)
+  {
+    c->mirror = HostMirror{ nullptr, 0, nullptr };
+    if ((rc = agh_find_hands_device(ctx, c->d_idx_own, L.S, 0, c->d_out_own, c->s_cap * 8, c->d_nout, st)) != AGH_OK)
+      return rc;
+    if (L.classify && (rc = agh_classify_device(ctx, c->d_keep, st)) != AGH_OK)
+      return rc;
+    hipLaunchKernelGGL(k_compact_kept, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_out_own, (const int64_t*) c->d_nout,
+      c->s_cap * 8, L.classify ? 1 : 0, c->d_h_hands, (int) hand_bound, d_hcount, h_hands, (int) c->h_pin_handles_cap, h_counts,
+      (const int32_t*) c->d_flags);
+    if (hipGetLastError() != hipSuccess)
+    {
+      c->err = "k_compact_kept launch failed";
+      return AGH_ERR_HIP;
+    }
+  }
+  timing_begin(c, st);
+  rc = handle_search(c, hand_bound, L.x1, L.x2, L.min_inliers, L.min_length, st, hm, L.with_sequential, d_hcount);
+  timing_mark(c, "handle_search", st);
+  if (rc != AGH_OK)
+    c->err = "handle search launch failed";
+  return rc;
+}
+
+static int localize_begin_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int64_t stride_bytes, int64_t n, const agh_localize_params* lp)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  Ctx* c = &ctx->c;
+  LocalizeState& L = c->loc;
+  if (L.active)
+  {
+    c->err = "agh_localize_begin: a chain is in flight (agh_localize_end first)";
+    return AGH_ERR_STATE;
+  }
   if (!lp || n < 0 || n >= (1ll << 30) || stride_bytes < 12 || (stride_bytes % 4) != 0 || (n > 0 && !xyz) || !(lp->cell_size > 0.0) ||
-      lp->size_left < 0 || lp->n_samples < 0 || lp->n_samples > (1 << 24) || lp->min_inliers < 1 || handle_cap < 0 || idx_cap < 0 ||
-      hands_cap < 0 || (handle_cap > 0 && !handles_out) || (idx_cap > 0 && !inlier_idx_out) || (hands_cap > 0 && !hands_out))
+      lp->size_left < 0 || lp->n_samples < 0 || lp->n_samples > (1 << 24) || lp->min_inliers < 1)
   {
     c->err = "agh_localize: bad arguments (see include/agh.h)";
     return AGH_ERR_INVALID_ARGUMENT;
@@ -1521,8 +1700,7 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     c->err = "agh_localize: classify needs a loaded SVM (agh_load_svm*)";
     return AGH_ERR_NO_SVM;
   }
-  double x1 = 0, x2 = 0;
-  if (!handle_thresholds(&x1, &x2))
+  if (!handle_thresholds(&L.x1, &L.x2))
   {
     c->err = "agh_localize: this libm's acos is not monotone around the 0.34 rad thresholds";
     return AGH_ERR_INVALID_ARGUMENT;
@@ -1532,32 +1710,55 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
   hipStream_t st = c->stream;
   int rc;
   // ---- 1. raw cloud up (unless it is on the device already: agh_localize_device, which reads it in place with the caller's
-  // stride), voxelisation and grid build queued; the voxel count stays on the device when it can ----
+  // stride -- or was staged: agh_localize_stage), voxelisation and grid build queued; the voxel count stays on the device when it
+  // can ----
   const bool as_is = stride_bytes <= 32;  // (as agh_preprocess)
   const int64_t dev_stride = (as_is || xyz_on_device) ? stride_bytes : 12;
   const float* d_raw = xyz;
   if (!xyz_on_device)
   {
-    const int64_t need = n * (dev_stride / 4);
-    if (need > c->raw_cap || !c->d_raw_xyz)
+    if (L.staged && L.staged_src == xyz && L.staged_stride == stride_bytes && L.staged_n == n && c->d_stage_xyz)
     {
-      if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
-        return rc;
-      c->raw_cap = need;
+      // the capture is (or is about to be) in the second raw buffer: the two buffers change places, the chain waits for the copy
+      std::swap(c->d_raw_xyz, c->d_stage_xyz);
+      std::swap(c->raw_cap, c->stage_cap);
+      L.staged = false;
+      HIPCHK(c, hipStreamWaitEvent(st, c->stage_done, 0));
     }
-    if (n > 0)
+    else
     {
-      if (as_is)
-        HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, st));
-      else
-        HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, st));
+      L.staged = false;  // (a staged capture that is not this one is dropped)
+      const int64_t need = n * (dev_stride / 4);
+      if (need > c->raw_cap || !c->d_raw_xyz)
+      {
+        if ((rc = dev_alloc(c, &c->d_raw_xyz, (size_t) need)))
+          return rc;
+        c->raw_cap = need;
+      }
+      if (n > 0)
+      {
+        if (as_is)
+          HIPCHK(c, hipMemcpyAsync(c->d_raw_xyz, xyz, (size_t) (n * stride_bytes - (stride_bytes - 12)), hipMemcpyHostToDevice, st));
+        else
+          HIPCHK(c, hipMemcpy2DAsync(c->d_raw_xyz, 12, xyz, (size_t) stride_bytes, 12, (size_t) n, hipMemcpyHostToDevice, st));
+      }
     }
     d_raw = c->d_raw_xyz;
   }
-  bool deferred = false;
-  int64_t nv = 0;
-  rc = preprocess_device_impl(ctx, d_raw, dev_stride, n, lp->size_left, lp->dense, lp->workspace, lp->cell_size, &nv, nullptr,
-    true, &deferred);
+  L.S = S;
+  L.classify = lp->classify != 0;
+  L.min_inliers = lp->min_inliers;
+  L.min_length = lp->min_length;
+  L.lp = *lp;
+  L.lp.sample_idx = nullptr;  // (the list is copied below; a repeat of the whole call reads it from the pinned copy)
+  L.explicit_samples = lp->sample_idx != nullptr;
+  L.d_raw = d_raw;
+  L.dev_stride = dev_stride;
+  L.n_raw = n;
+  L.deferred = false;
+  L.nv = 0;
+  rc = preprocess_device_impl(ctx, d_raw, dev_stride, n, lp->size_left, lp->dense, lp->workspace, lp->cell_size, &L.nv, nullptr,
+    true, &L.deferred);
   if (rc != AGH_OK)
     return rc;
   c->cloud_async = false;  // (everything below is queued on the context's own stream, and the call ends with its synchronisation)
@@ -1618,18 +1819,13 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     LOC_HIPCHK(hipMalloc((void**) &c->d_svm_sums, (size_t) (c->s_cap * 8) * sizeof(double)));
     c->keep_cap = c->s_cap * 8;
   }
-  int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
-  agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
-  agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
-  int32_t* h_hidx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
-  const HandleMirror hm{ h_handles, (int) c->h_pin_handles_cap, h_hidx, (int) c->h_pin_handles_cap, h_counts };
-  int* d_hcount = c->d_h_counts + 4;  // (behind the HandleCounts record)
   // ---- 3. the sample list ----
   if (S > 0)
   {
     if (lp->sample_idx)
     {
-      std::memcpy(h_idx, lp->sample_idx, sizeof(int32_t) * (size_t) S);
+      if (lp->sample_idx != h_idx)  // (a repeat of the whole call hands the pinned copy back in)
+        std::memcpy(h_idx, lp->sample_idx, sizeof(int32_t) * (size_t) S);
       LOC_HIPCHK(hipMemcpyAsync(c->d_idx_own, h_idx, sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
     }
     else
@@ -1639,73 +1835,91 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
       LOC_HIPCHK(hipGetLastError());
     }
   }
-  // ---- 4. search -> classification -> kept hands -> handle search, then the one synchronisation ----
-  VoxDesc h;
+  // ---- 4. search -> classification -> kept hands -> handle search: queued; agh_localize_end waits ----
+  if ((rc = localize_queue(ctx, false)) != AGH_OK)
+    return fail(rc);
+  L.active = true;
+  return AGH_OK;
+}
+#undef LOC_HIPCHK
+
+static int localize_end_impl(agh_ctx* ctx, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
+  agh_hypothesis* hands_out, int64_t hands_cap, int32_t* samples_out, agh_localize_result* result)
+{
+  Ctx* c = &ctx->c;
+  LocalizeState& L = c->loc;
+  hipStream_t st = c->stream;
+  L.active = false;
+  const int64_t S = L.S;
+  int* h_counts = reinterpret_cast<int*>(c->h_pin_handles);
+  agh_hypothesis* h_hands = reinterpret_cast<agh_hypothesis*>(c->h_pin_handles + 256);
+  agh_handle* h_handles = reinterpret_cast<agh_handle*>(h_hands + c->h_pin_handles_cap);
+  int32_t* h_hidx = reinterpret_cast<int32_t*>(h_handles + c->h_pin_handles_cap);
+  int32_t* h_idx = reinterpret_cast<int32_t*>(c->h_pin + kPinHeaderBytes);
+  auto drop_bound_cloud = [&]() {
+    if (c->n_is_bound)
+    {
+      c->n_is_bound = false;
+      c->has_cloud = false;
+      c->n = 0;
+      c->cloud_off_on_device = false;
+    }
+  };
+  int rc;
   bool handles_only = false;
   for (int attempt = 0;; attempt++)
   {
-    for (int k = 0; k < (handles_only ? 4 : 8); k++)  // ([4..6], the search's counts, outlive a repeat of the handle search alone)
-      h_counts[k] = 0;
-    const bool with_sequential = c->handles_sequential;
-    if (!handles_only)
+    if (attempt > 0)  // (attempt 0 was queued by agh_localize_begin)
     {
-      c->mirror = HostMirror{ nullptr, 0, nullptr };
-      if ((rc = agh_find_hands_device(ctx, c->d_idx_own, S, 0, c->d_out_own, c->s_cap * 8, c->d_nout, st)) != AGH_OK)
+      if ((rc = localize_queue(ctx, handles_only)) != AGH_OK)
       {
         (void) hipStreamSynchronize(st);
         drop_bound_cloud();
         return rc;
       }
-      if (lp->classify && (rc = agh_classify_device(ctx, c->d_keep, st)) != AGH_OK)
-      {
-        (void) hipStreamSynchronize(st);
-        drop_bound_cloud();
-        return rc;
-      }
-      hipLaunchKernelGGL(k_compact_kept, dim3(1), dim3(1024), 0, st, (const agh_hypothesis*) c->d_out_own, (const int64_t*) c->d_nout,
-        c->s_cap * 8, lp->classify ? 1 : 0, c->d_h_hands, (int) hand_bound, d_hcount, h_hands, (int) c->h_pin_handles_cap, h_counts,
-        (const int32_t*) c->d_flags);
-      LOC_HIPCHK(hipGetLastError());
     }
-    timing_begin(c, st);
-    rc = handle_search(c, hand_bound, x1, x2, lp->min_inliers, lp->min_length, st, hm, with_sequential, d_hcount);
-    timing_mark(c, "handle_search", st);
-    if (rc != AGH_OK)
+    const bool with_sequential = L.with_sequential;
+    if (hipStreamSynchronize(st) != hipSuccess)
     {
-      (void) hipStreamSynchronize(st);
       drop_bound_cloud();
-      c->err = "handle search launch failed";
-      return rc;
+      c->err = "agh_localize: hipStreamSynchronize failed";
+      return AGH_ERR_HIP;
     }
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (deferred)  // the descriptor of the speculative voxelisation, now on the host
+    if (L.deferred)  // the descriptor of the speculative voxelisation, now on the host
     {
-      deferred = false;
-      h = *c->h_vox_desc;
-      nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
+      L.deferred = false;
+      const VoxDesc h = *c->h_vox_desc;
+      L.nv = (int64_t) (h.n_vox[0] + h.n_vox[1]);
       c->n_is_bound = false;
       if (h.error)
       {
         // error 2: the lattice outgrew the bitmap kept from the previous cloud -- the whole call once more, sized from this
-        // cloud's lattice (the context then has no bitmap to speculate with: the preprocessing takes its own round trips)
+        // cloud's lattice (the context then has no bitmap to speculate with: the preprocessing takes its own round trips).  The
+        // raw capture is still where the chain read it: in the context's raw buffer, or in the caller's device memory.
         c->has_cloud = false;
         c->n = 0;
         c->cloud_off_on_device = false;
-        if (h.error == 2 && attempt == 0)
+        if (h.error == 2 && !L.repeated)
         {
           (void) hipFree(c->d_vox_bitmap);
           c->d_vox_bitmap = nullptr;
           c->vox_bitmap_cap = 0;
-          return localize_impl(ctx, xyz, xyz_on_device, stride_bytes, n, lp, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out,
-            hands_cap, samples_out, result);
+          agh_localize_params lp = L.lp;
+          lp.sample_idx = L.explicit_samples ? h_idx : nullptr;
+          L.repeated = true;
+          rc = localize_begin_impl(ctx, L.d_raw, true, L.dev_stride, L.n_raw, &lp);
+          if (rc == AGH_OK)
+            rc = localize_end_impl(ctx, handles_out, handle_cap, inlier_idx_out, idx_cap, hands_out, hands_cap, samples_out, result);
+          c->loc.repeated = false;
+          return rc;
         }
         c->err = "the voxel lattice of the kept points exceeds 2^33 cells (1 GiB bitmap): set a workspace "
                  "(Localization::setWorkspace) that bounds the scene";
         return AGH_ERR_CAPACITY;
       }
       c->vox_last_words = (int64_t) h.n_words;
-      c->n = nv;
-      c->cloud_off.assign({ (int64_t) 0, nv });
+      c->n = L.nv;
+      c->cloud_off.assign({ (int64_t) 0, L.nv });
       c->cloud_off_on_device = true;  // ({0, nv}: what the voxeliser wrote)
       c->n_clouds = 1;
     }
@@ -1745,7 +1959,7 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
   const int64_t n_hyp = h_counts[4], n_kept = h_counts[5];
   c->last_nout = std::min<int64_t>(n_hyp, c->s_cap * 8);
   if (result)
-    *result = agh_localize_result{ nv, n_hyp, n_kept, h_counts[0], h_counts[1] };
+    *result = agh_localize_result{ L.nv, n_hyp, n_kept, h_counts[0], h_counts[1] };
   if (samples_out && S > 0)
     std::memcpy(samples_out, h_idx, sizeof(int32_t) * (size_t) S);
   if (h_counts[0] > handle_cap || h_counts[1] > idx_cap || (hands_out && n_kept > hands_cap))
@@ -1762,7 +1976,6 @@ static int localize_impl(agh_ctx* ctx, const float* xyz, bool xyz_on_device, int
     std::memcpy(hands_out, h_hands, sizeof(agh_hypothesis) * (size_t) n_kept);
   return AGH_OK;
 }
-#undef LOC_HIPCHK
 
 int agh_synchronize(agh_ctx* ctx)
 {

@@ -23,8 +23,10 @@ __device__ void desc_finish(GridDesc* d, double base_cell, int64_t n, const floa
   double mn[3], mx[3];
   for (int a = 0; a < 3; a++)
   {
-    mn[a] = n > 0 ? (double) lo[a] : 0.0;
-    mx[a] = n > 0 ? (double) hi[a] : 0.0;
+    // (an empty cloud, or one without a single finite point, leaves the sentinels: a one-cell grid at the origin)
+    const bool any = n > 0 && lo[a] <= hi[a];
+    mn[a] = any ? (double) lo[a] : 0.0;
+    mx[a] = any ? (double) hi[a] : 0.0;
   }
   double cell = base_cell;
   int dim[3];
@@ -72,10 +74,13 @@ __global__ __launch_bounds__(kBboxThreads) void k_bbox(const float* __restrict__
     const float* p = xyz + i * stride;
     const float* q = xyz + (i + step < n ? i + step : i) * stride;
     const float pv[3] = { p[0], p[1], p[2] }, qv[3] = { q[0], q[1], q[2] };
+    // a point with a non-finite coordinate is no point of the search structure (pcl::KdTreeFLANN::setInputCloud drops it:
+    // it can be nobody's neighbour) and does not stretch the box
+    const bool pf = isfinite(pv[0]) && isfinite(pv[1]) && isfinite(pv[2]), qf = isfinite(qv[0]) && isfinite(qv[1]) && isfinite(qv[2]);
     for (int a = 0; a < 3; a++)
     {
-      mn[a] = fminf(mn[a], fminf(pv[a], qv[a]));
-      mx[a] = fmaxf(mx[a], fmaxf(pv[a], qv[a]));
+      mn[a] = fminf(mn[a], fminf(pf ? pv[a] : INFINITY, qf ? qv[a] : INFINITY));
+      mx[a] = fmaxf(mx[a], fmaxf(pf ? pv[a] : -INFINITY, qf ? qv[a] : -INFINITY));
     }
   }
   constexpr int kW = kBboxThreads / 64;
@@ -186,6 +191,11 @@ __global__ __launch_bounds__(256) void k_cell_count(const float* __restrict__ xy
       const int cx = cell_coord(g, (double) p[0], 0), cy = cell_coord(g, (double) p[1], 1),
                 cz = cell_coord(g, (double) p[2], 2);
       c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+      // A non-finite point keeps its place in the index space (the callers' indices do not move) and its own coordinates in the
+      // sorted array, where every query's float32 distance test rejects it (NaN and Inf compare false with `< r^2`); which cell
+      // it lies in is therefore free -- spread over the cells by index, so that no cell collects a sensor's drop-outs.
+      if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])))
+        c = (int) (i % (int64_t) g.ncell);
     }
     const int prev = __shfl_up(c, 1);
     const bool head = (lane == 0) || (c != prev);

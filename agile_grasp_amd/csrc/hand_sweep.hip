@@ -175,8 +175,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_swee
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
-  const int* __restrict__ order, uint8_t* __restrict__ vmask, double2* __restrict__ spill_all, int spill_cap,
-  uint32_t* __restrict__ images_cam)
+  const int* __restrict__ order, uint8_t* __restrict__ vmask, uint32_t* __restrict__ images_cam)
 {
   constexpr bool NORMALS = MODE != 0, TRAIN = MODE == 2;
   constexpr int NW = NT / 64, kOW = 8 / NW;  // waves; orientations a wave owns in the finger logic and the results
@@ -590,13 +589,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_swee
       }
     }
   };
-  // A neighbourhood that needs more than one tile would have to be gathered again for pass B (filter, rotation and
-  // crop of every candidate a second time).  Instead its cropped points are parked in the sample's neighbour-list
-  // scratch (dead since K1c; 16 bytes per point, spill_cap points) while pass A streams through them, and pass B reads
-  // them back with plain coalesced loads.  Only if they do not fit does pass B gather again.
-  double2* spill = spill_all + (int64_t) s * spill_cap;
-  int ntiles = 0, nc = 0, nspill = 0, ncrop_all = 0;
-  bool spill_ok = !NORMALS;  // (the normals variant also needs the point ids: it keeps the second gather)
+  // A neighbourhood that needs more than one tile is gathered again for pass B -- by the few work-groups that get there: an
+  // orientation with a hand is the exception (a fifth of the samples).  (Until round 5 every multi-tile neighbourhood parked its
+  // cropped points in global memory during pass A, 14 MB per launch at C2 written to be read back by a fifth of them.)
+  int ntiles = 0, nc = 0, ncrop_all = 0;
   for (;;)
   {
     bool all_done = false;
@@ -605,17 +601,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_swee
       AGH_STAMP(2);
     if (debug_stop == 2)
       return;
-    if (spill_ok && (ntiles > 0 || !all_done))
-    {
-      if (nspill + nc <= spill_cap)
-      {
-        for (int t = tid; t < nc; t += NT)
-          spill[nspill + t] = pts[t];
-        nspill += nc;
-      }
-      else
-        spill_ok = false;
-    }
     if (ntiles == 0)
       for (int o = 0; o < 8; o++)
         live |= ori[o].rejected ? 0u : (1u << o);
@@ -766,130 +751,122 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_swee
     }
     pos_x = ((O.binormal[0] * s2c[0] + O.binormal[1] * s2c[1]) + O.binormal[2] * s2c[2]) > 0;
   };
-  if (any_hand)
-  {
-    const bool refill = ntiles > 1;  // a single tile is still resident in LDS
-    const bool from_spill = refill && spill_ok;
-    int spill_pos = 0;
-    if (refill)
+  // one tile's share of pass B for every orientation with a hand
+  auto pass_b_tile = [&](int nc) {
+    for (int o = 0; o < 8; o++)
     {
-      next_tile();
-      gather_reset();
-      if (from_spill)
-        __threadfence();  // the parked points were written by this work-group: make them visible to all its waves
-    }
-    for (;;)
-    {
-      bool all_done = true;
-      if (from_spill)
+      const OriState& O = ori[o];
+      if (O.rejected || !O.has_hand)
+        continue;
+      const int e = O.e, last = O.last;
+      const double cs = O.cs, ms = -1.0 * O.sn, sn = O.sn;
+      const double left = G.fs[e], right = G.fs[10 + e];
+      const double box_y = G.boxy[last];
+      const double bite = G.init_bite;
+      double surf[3], hor_pos_;
+      bool pos_x;
+      ori_consts(o, surf, pos_x, hor_pos_);
+      const double sfx = surf[0], sfy = surf[1];
+      double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
+      int nbox = 0, numl = 0, numr = 0;
+      for (int t0 = tid; t0 < nc; t0 += 4 * NT)
       {
-        nc = min(kTile, nspill - spill_pos);
-        for (int t = tid; t < nc; t += NT)
-          pts[t] = spill[spill_pos + t];
-        spill_pos += nc;
-        all_done = spill_pos >= nspill;
-        __syncthreads();
-      }
-      else if (refill)
-        nc = gather_tile(all_done);
-      for (int o = 0; o < 8; o++)
-      {
-        const OriState& O = ori[o];
-        if (O.rejected || !O.has_hand)
-          continue;
-        const int e = O.e, last = O.last;
-        const double cs = O.cs, ms = -1.0 * O.sn, sn = O.sn;
-        const double left = G.fs[e], right = G.fs[10 + e];
-        const double box_y = G.boxy[last];
-        const double bite = G.init_bite;
-        double surf[3], hor_pos_;
-        bool pos_x;
-        ori_consts(o, surf, pos_x, hor_pos_);
-        const double sfx = surf[0], sfy = surf[1];
-        double wmin = 100000.0, wmax = -100000.0, ymax = -INFINITY;
-        int nbox = 0, numl = 0, numr = 0;
-        for (int t0 = tid; t0 < nc; t0 += 4 * NT)
+        // four independent points per lane in stages (straight-line code: the two exactly-rounded divisions of each point
+        // overlap with those of the others; the image update is the only predicated part)
+        const bool full = (t0 - tid) + 4 * NT <= nc;
+        double xr[4], yr[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
         {
-          // four independent points per lane in stages (straight-line code: the two exactly-rounded divisions of each point
-          // overlap with those of the others; the image update is the only predicated part)
-          const bool full = (t0 - tid) + 4 * NT <= nc;
-          double xr[4], yr[4];
-          bool act[4];
+          const int t = t0 + NT * u;
+          act[u] = full || t < nc;
+          const double2 p = pts[act[u] ? t : 0];
+          xr[u] = cs * p.x + ms * p.y;
+          yr[u] = sn * p.x + cs * p.y;
+          ymax = max_f64_raw(ymax, yr[u]);  // (an inactive lane holds point 0 once more: idempotent)
+        }
+        int bit[4];
+        bool inbox[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            const int t = t0 + NT * u;
-            act[u] = full || t < nc;
-            const double2 p = pts[act[u] ? t : 0];
-            xr[u] = cs * p.x + ms * p.y;
-            yr[u] = sn * p.x + cs * p.y;
-            ymax = max_f64_raw(ymax, yr[u]);  // (an inactive lane holds point 0 once more: idempotent)
-          }
-          int bit[4];
-          bool inbox[4];
+        for (int u = 0; u < 4; u++)
+        {
+          const bool inw = act[u] & (yr[u] < bite) & (xr[u] > left) & (xr[u] < right);  // finger_hand.cpp:158-167
+          wmin = min_f64_raw(wmin, inw ? xr[u] : 100000.0);   // (the sentinels are the initial values: no-ops)
+          wmax = max_f64_raw(wmax, inw ? xr[u] : -100000.0);
+          const double bx = xr[u] - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
+          const double by = yr[u] - sfy;
+          const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
+          const double vy = (by - 0.0) / img_cell;
+          inbox[u] = act[u] & (yr[u] < box_y);  // rotating_hand.cpp:125-130
+          int hc = (int) floor(hx), vc = (int) floor(vy);
+          hc = min(99, max(0, hc));
+          vc = min(79, max(0, vc));
+          bit[u] = (79 - vc) * 100 + hc;
+          nbox += inbox[u] ? 1 : 0;
+        }
 #pragma unroll
-          for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 4; u++)
+        {
+          if (inbox[u])
           {
-            const bool inw = act[u] & (yr[u] < bite) & (xr[u] > left) & (xr[u] < right);  // finger_hand.cpp:158-167
-            wmin = min_f64_raw(wmin, inw ? xr[u] : 100000.0);   // (the sentinels are the initial values: no-ops)
-            wmax = max_f64_raw(wmax, inw ? xr[u] : -100000.0);
-            const double bx = xr[u] - sfx;  // rotating_hand.cpp:138 (world-frame offset, as in the reference)
-            const double by = yr[u] - sfy;
-            const double hx = pos_x ? (bx - (-0.05)) / img_cell : (-bx - (-0.05)) / img_cell;  // learning.cpp:330-333
-            const double vy = (by - 0.0) / img_cell;
-            inbox[u] = act[u] & (yr[u] < box_y);  // rotating_hand.cpp:125-130
-            int hc = (int) floor(hx), vc = (int) floor(vy);
-            hc = min(99, max(0, hc));
-            vc = min(79, max(0, vc));
-            bit[u] = (79 - vc) * 100 + hc;
-            nbox += inbox[u] ? 1 : 0;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-          {
-            if (inbox[u])
+            if (TRAIN)  // pid = (index << 1) | camera
+              atomicOr(&img[o + 8 * (int) (pid[t0 + NT * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
+            else
+              atomicOr(&img[o][bit[u] >> 5], 1u << (bit[u] & 31));
+            if (NORMALS)
             {
-              if (TRAIN)  // pid = (index << 1) | camera
-                atomicOr(&img[o + 8 * (int) (pid[t0 + NT * u] & 1u)][bit[u] >> 5], 1u << (bit[u] & 31));
-              else
-                atomicOr(&img[o][bit[u] >> 5], 1u << (bit[u] & 31));
-              if (NORMALS)
-              {
-                const double* nn = normals + 3 * (int64_t) (pid[t0 + NT * u] >> 1);
-                const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
-                const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
-                const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
-                const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
-                numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
-                numr += (nxr > G.cos_antipodal) ? 1 : 0;
-              }
+              const double* nn = normals + 3 * (int64_t) (pid[t0 + NT * u] >> 1);
+              const double n0 = nn[0], n1 = nn[1], n2 = nn[2];
+              const double nxp = (fr[0][0] * n0 + fr[1][0] * n1) + fr[2][0] * n2;  // frame_^T * normals (33)
+              const double nyp = (fr[0][1] * n0 + fr[1][1] * n1) + fr[2][1] * n2;
+              const double nxr = cs * nxp + ms * nyp;  // rot * normals_ (92)
+              numl += (-1.0 * nxr > G.cos_antipodal) ? 1 : 0;  // antipodal.cpp:28,38
+              numr += (nxr > G.cos_antipodal) ? 1 : 0;
             }
           }
         }
-        // this wave's share of the tile, folded into its slot (the tiles of a neighbourhood come one after the other)
-        wmin = wave_min_f64(wmin);
-        wmax = wave_max_f64(wmax);
-        ymax = wave_max_f64(ymax);
-        nbox = wave_sum_i32(nbox);
-        if (NORMALS)
-        {
-          numl = wave_sum_i32(numl);
-          numr = wave_sum_i32(numr);
-        }
-        if (lane == 0)
-        {
-          PassBPart& P = part[wave * 8 + o];
-          P.wmin = min_f64_raw(P.wmin, wmin);
-          P.wmax = max_f64_raw(P.wmax, wmax);
-          P.ymax = max_f64_raw(P.ymax, ymax);
-          P.nbox += nbox;
-          P.numl += numl;
-          P.numr += numr;
-        }
       }
-      if (!refill || all_done)
-        break;
+      // this wave's share of the tile, folded into its slot (the tiles of a neighbourhood come one after the other)
+      wmin = wave_min_f64(wmin);
+      wmax = wave_max_f64(wmax);
+      ymax = wave_max_f64(ymax);
+      nbox = wave_sum_i32(nbox);
+      if (NORMALS)
+      {
+        numl = wave_sum_i32(numl);
+        numr = wave_sum_i32(numr);
+      }
+      if (lane == 0)
+      {
+        PassBPart& P = part[wave * 8 + o];
+        P.wmin = min_f64_raw(P.wmin, wmin);
+        P.wmax = max_f64_raw(P.wmax, wmax);
+        P.ymax = max_f64_raw(P.ymax, ymax);
+        P.nbox += nbox;
+        P.numl += numl;
+        P.numr += numr;
+      }
+    }
+  };
+  if (any_hand)
+  {
+    // A neighbourhood that fitted one tile is still in LDS; one that streamed through the tile in pass A is gathered again.
+    if (ntiles == 1)
+      pass_b_tile(nc);
+    else
+    {
       next_tile();
+      gather_reset();
+      for (;;)
+      {
+        bool all_done = true;
+        nc = gather_tile(all_done);
+        pass_b_tile(nc);
+        if (all_done)
+          break;
+        next_tile();
+      }
     }
   }
   __syncthreads();  // every wave's share of pass B (partials, image bits) is in LDS
@@ -1371,8 +1348,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   const bool timed = timing_launch_events(c, "hand_sweep", &ev_start, &ev_stop);
 #define AGH_SWEEP_ARGS                                                                                                  \
   gv, dg, (const agh_frame*) c->d_frames, d_samples, (const int32_t*) c->d_cam, Si, r2f, rpad, nrm, img_cell, c->d_status, \
-    c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg, order, c->d_vmask, reinterpret_cast<double2*>(c->d_nbr),   \
-    (int) c->nbr_stride, c->d_images_cam
+    c->d_slots, c->d_images, c->debug_stop_sweep, sweep_dbg, order, c->d_vmask, c->d_images_cam
 #ifndef AGH_SWEEP_NT
 #define AGH_SWEEP_NT 256  // threads of the online variant's work-groups (512: eight waves, two per CU, one 3712-point tile -- measured, not faster)
 #endif

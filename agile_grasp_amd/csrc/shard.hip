@@ -265,10 +265,16 @@ __host__ __device__ inline int64_t shard_lo(int64_t n, int64_t r, int64_t G)
 }
 
 // header of an empty slice: no hypotheses, and the rank's findings (shard_header_word) as k_compact_* would write them
-__global__ void k_shard_empty_header(int64_t* __restrict__ hdr, const int32_t* __restrict__ flags, int big)
+// (extra: kHdrRankFailed / kHdrRankNoCloud -- this rank took part in the call's collectives without searching)
+__global__ void k_shard_empty_header(int64_t* __restrict__ hdr, const int32_t* __restrict__ flags, int big, int extra)
 {
   hdr[0] = 0;
-  hdr[1] = shard_header_word(flags[0], big);
+  hdr[1] = shard_header_word(flags[0], big) | extra;
+}
+// a rank whose classification failed on its own: its records travel as they are, its header says so
+__global__ void k_shard_flag_header(int64_t* __restrict__ hdr, int extra)
+{
+  hdr[1] |= extra;
 }
 
 // RAND50: draws my slice consumes (50 per neighbourhood of more than 50 points, quadric.cpp:177-193)
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
     for (int q = 0; q < G; q++)
     {
       int64_t cnt = *reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes);
-      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & 29);  // shard_header_word
+      need |= (int) (reinterpret_cast<const int64_t*>(xbuf + (int64_t) q * seg_bytes)[1] & (29 | kHdrRankFailed | kHdrRankNoCloud));  // shard_header_word
       if (cnt > seg_records)
       {
         ov = 1;
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(256) void k_shard_merge(const uint8_t* __restrict__
         atomicOr(&flags[0], 16);
       // what the ranks found, the same word on every rank (agh_internal.h: kFlagShard*)
       atomicOr(&flags[0], kFlagSharded | ((need & 1) ? kFlagShardRetry : 0) | ((need & 8) ? kFlagShardRetryHuge : 0) |
-                            ((need & 16) ? kFlagShardHard : 0) | (need & 4));
+                            ((need & 16) ? kFlagShardHard : 0) | (need & 4) | ((need & kHdrRankFailed) ? kFlagShardPeerFailed : 0) |
+                            ((need & kHdrRankNoCloud) ? kFlagShardPeerNoCloud : 0));
       if (o > cap)
         atomicOr(&flags[0], 2);
     }
@@ -417,6 +424,55 @@ int exchange_and_merge(Ctx* c, uint8_t* d_keep, hipStream_t st)
   hipLaunchKernelGGL(k_shard_merge, dim3(256), dim3(256), 0, st, (const uint8_t*) c->d_xbuf, c->shard_seg_bytes, c->shard_seg_records,
     cm->n_ranks, c->shard_S, c->shard_out, c->shard_cap, c->shard_nout, d_keep, c->d_flags, c->epoch);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
+}
+
+// One word per rank, all-gathered and read back: does EVERY rank say yes?  For decisions that must be the same on every rank and
+// that only some ranks can make (an allocation that failed here): 8 bytes per rank and a host round trip, so only on the calls
+// that grow an exchange buffer (the first of a size) and in the offline all-points pass.  `word` travels too (the cloud's size).
+int shard_agree(Ctx* c, hipStream_t st, bool mine_ok, int64_t word, bool* all_ok, int64_t* words_out)
+{
+  Comm* cm = c->comm;
+  const int G = cm->n_ranks, r = cm->rank;
+  const int64_t mine = (word << 1) | (mine_ok ? 1 : 0);
+  int64_t all[64];
+  HIPCHK(c, hipMemcpyAsync(c->d_xcnt + 64 + r, &mine, sizeof(int64_t), hipMemcpyHostToDevice, st));
+  const int rc = all_gather(c, c->d_xcnt + 64, sizeof(int64_t), st);
+  if (rc != AGH_OK)
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(all, c->d_xcnt + 64, sizeof(int64_t) * (size_t) G, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  *all_ok = true;
+  for (int q = 0; q < G; q++)
+  {
+    *all_ok = *all_ok && (all[q] & 1);
+    if (words_out)
+      words_out[q] = all[q] >> 1;
+  }
+  return AGH_OK;
+}
+
+// Every rank of a NEW communicator starts without exchange buffers, so that "does this call grow one" -- which decides whether the
+// ranks meet in shard_agree first -- is the same question on every rank, whatever the contexts did before.
+void drop_exchange_buffers(Ctx* c)
+{
+  if (c->d_xbuf)
+    (void) hipFree(c->d_xbuf);
+  if (c->d_nbuf)
+    (void) hipFree(c->d_nbuf);
+  c->d_xbuf = nullptr;
+  c->d_nbuf = nullptr;
+  c->xbuf_bytes = 0;
+  c->nbuf_doubles = 0;
+  c->shard_out = nullptr;
+}
+
+// agh_comm_inject_fault (testing aid): does the site fail now?  One shot per set bit.
+bool injected(Ctx* c, int site)
+{
+  if (!(c->shard_inject & site))
+    return false;
+  c->shard_inject &= ~site;
+  return true;
 }
 }  // namespace
 
@@ -515,6 +571,7 @@ int agh_comm_init(agh_ctx* ctx, int32_t rank, int32_t n_ranks, const uint8_t id[
     c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
     return AGH_ERR_HIP;
   }
+  drop_exchange_buffers(c);
   c->comm = new Comm();
   c->comm->rank = rank;
   c->comm->n_ranks = n_ranks;
@@ -569,6 +626,13 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
         ctxs[k]->c.err = kParamsDiffer;
       return AGH_ERR_INVALID_ARGUMENT;
     }
+  for (int q = 0; q < n_ranks; q++)  // (the words the ranks agree through: allocated here, where a failure fails the init alike)
+    if (!ctxs[q]->c.d_xcnt)
+    {
+      int64_t have = 0;
+      if (hipSetDevice(ctxs[q]->c.device) != hipSuccess || grow(&ctxs[q]->c, &ctxs[q]->c.d_xcnt, &have, 128) != AGH_OK)
+        return AGH_ERR_HIP;
+    }
   std::shared_ptr<LocalGroup> g(new LocalGroup());
   g->n = n_ranks;
   g->send.assign((size_t) n_ranks, nullptr);
@@ -578,8 +642,20 @@ int agh_comm_init_local(agh_ctx* const* ctxs, int32_t n_ranks)
     cm->rank = q;
     cm->n_ranks = n_ranks;
     cm->local = g;
+    drop_exchange_buffers(&ctxs[q]->c);
     ctxs[q]->c.comm = cm;
   }
+  return AGH_OK;
+}
+
+// Testing aid: the next time the context passes one of these sites of a sharded call it fails there ON ITS OWN, as an
+// out-of-memory or a launch error would (one shot per bit): 1 = the per-call buffers (device variant), 2 = the Taubin launch,
+// 4 = the exchange buffer's growth, 8 = the HOG / SVM launch of agh_classify_sharded, 16 = the per-call buffers (host variant).
+int agh_comm_inject_fault(agh_ctx* ctx, int32_t sites)
+{
+  if (!ctx)
+    return AGH_ERR_INVALID_ARGUMENT;
+  ctx->c.shard_inject = sites;
   return AGH_OK;
 }
 
@@ -650,21 +726,35 @@ static void shard_release_peers(agh_ctx* ctx, int rc, bool entered)
     ctx->c.comm->local->abort();
 }
 
+// `pre_rc`: a failure of THIS rank that the caller (the host variant) already knows -- it could not size its buffers, it holds no
+// cloud.  The rank still takes part: see "degraded" below.
 static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
-  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered);
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered, int pre_rc, const char* pre_err);
 
 int agh_find_hands_sharded_device(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
   agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream)
 {
   bool entered = false;
   const int rc = find_hands_sharded_device_impl(ctx, d_sample_idx, n_samples, calculates_antipodal, d_out, cap, d_n_out, hip_stream,
-    &entered);
+    &entered, AGH_OK, nullptr);
   shard_release_peers(ctx, rc, entered);
   return rc;
 }
 
+// NO RANK LEAVES ALONE (round 6).  Once the argument checks (the same on every rank) are passed, a rank reaches every collective
+// of the call whatever happens to it:
+//  * a rank that cannot do its share -- no cloud (a caller's bug), its per-call buffers could not be allocated, a kernel launch
+//    failed -- is DEGRADED: it skips its kernels, contributes an empty segment whose header says so (kHdrRankFailed /
+//    kHdrRankNoCloud) and issues every all-gather of the call with the agreed byte counts; the merge kernel turns the header bit
+//    into a flag every rank reads, so every rank returns AGH_ERR_STATE / AGH_ERR_NO_CLOUD for this call -- the failing rank at
+//    once, with its own error text -- and the communicator stays usable;
+//  * the buffers the collectives themselves need (the exchange buffer, and in the offline all-points pass the normals buffers) are
+//    grown FIRST and the outcome is agreed on (shard_agree: 8 bytes per rank and a host round trip -- only on a call that grows
+//    one, which the ranks decide alike because they made the same sharded calls before, and in the all-points pass, which
+//    exchanges the cloud sizes that way anyway): a rank that is out of memory makes every rank return AGH_ERR_HIP together.
+// What is left outside: a HIP runtime or RCCL call that fails INSIDE a collective (the device or the fabric is gone).
 static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_idx, int64_t n_samples, int calculates_antipodal,
-  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered)
+  agh_hypothesis* d_out, int64_t cap, int64_t* d_n_out, void* hip_stream, bool* entered, int pre_rc, const char* pre_err)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
@@ -673,11 +763,6 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   {
     c->err = "agh_find_hands_sharded: no communicator (agh_comm_init)";
     return AGH_ERR_STATE;
-  }
-  if (!c->has_cloud)
-  {
-    c->err = "agh_find_hands_sharded: no cloud set";
-    return AGH_ERR_NO_CLOUD;
   }
   if (n_samples < 0 || n_samples > (1 << 24) || (n_samples > 0 && (!d_sample_idx || !d_out)) || !d_n_out || cap < 0)
   {
@@ -694,14 +779,30 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   }
   *entered = true;  // from here on a failure is this rank's own
   c->shard_symmetric_error = false;
+  // the first failure of this rank's own: from then on it is degraded (no kernels of its own, every collective still issued)
+  int local_rc = pre_rc;
+  std::string local_err = pre_err ? pre_err : "";
+  int hdr_extra = pre_rc != AGH_OK ? kHdrRankFailed : 0;
+  auto degrade = [&](int rc_, const std::string& what, int extra) {
+    if (local_rc == AGH_OK)
+    {
+      local_rc = rc_;
+      local_err = what;
+      hdr_extra = extra;
+    }
+  };
+  if (!c->has_cloud)  // a caller's bug on this rank: it takes part like a rank with an empty cloud, and every rank hears of it
+    degrade(AGH_ERR_NO_CLOUD, "agh_find_hands_sharded: no cloud set", kHdrRankNoCloud);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   HIPCHK(c, order_after_cloud(c, st));
   const int G = c->comm->n_ranks, r = c->comm->rank;
   const int64_t S = n_samples;
+  const int64_t n_cloud = c->has_cloud ? c->n : 0;
   // (a rank whose cloud is EMPTY -- possible when every rank searches a cloud of its own -- takes part with an empty slice: it
   // must still join every collective of the call, or the others wait for it for ever)
-  const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G), Sr = c->n == 0 ? 0 : hi - lo;
+  const int64_t lo = shard_lo(S, r, G), hi = shard_lo(S, r + 1, G);
+  int64_t Sr = n_cloud == 0 ? 0 : hi - lo;
   const int64_t Smax = (S + G - 1) / G;
   if (Smax > 65536)  // the same on every rank: slices this long launch every capacity class from the start
     c->big_classes = true;
@@ -711,26 +812,95 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
   if (c->shard_full_exchange)
     seg_records = 8 * Smax;
   const int64_t seg_bytes = kHeaderBytes + seg_records * (int64_t) sizeof(agh_hypothesis);
-  const int64_t pcnt = (c->n + G - 1) / G;  // points per rank of the all-points pass
-  int rc = ensure_call_buffers(c, std::max<int64_t>(Smax, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
-  if (rc != AGH_OK)
-    return rc;
-  if ((rc = grow(c, &c->d_xbuf, &c->xbuf_bytes, (int64_t) G * seg_bytes)) != AGH_OK)
-    return rc;
-  if (!c->d_xcnt)
+  const int64_t pcnt = (n_cloud + G - 1) / G;  // points per rank of the all-points pass
+  int rc;
+  // ---- the rank's own per-call buffers: a failure degrades it ----
+  if (local_rc == AGH_OK)
   {
-    int64_t have = 0;
-    if ((rc = grow(c, &c->d_xcnt, &have, 128)) != AGH_OK)
-      return rc;
+    rc = injected(c, 1) ? AGH_ERR_HIP : ensure_call_buffers(c, std::max<int64_t>(Smax, calculates_antipodal ? std::min<int64_t>(n_cloud, kNormalsChunk) : 0));
+    if (rc != AGH_OK)
+      degrade(rc, rc == AGH_ERR_HIP && c->err.empty() ? "out of device memory for the per-call buffers" : c->err, kHdrRankFailed);
   }
   // (a communicator of one may run the all-points pass in the production mode: its rand() stream runs through all N
   // points before the samples, exactly as in agh_find_hands_device)
-  if (rand_mode && (rc = ensure_draws(c, 50 * (S + (calculates_antipodal ? c->n : 0)), st)) != AGH_OK)
-    return rc;
+  if (local_rc == AGH_OK && rand_mode && (rc = ensure_draws(c, 50 * (S + (calculates_antipodal ? n_cloud : 0)), st)) != AGH_OK)
+    degrade(rc, c->err, kHdrRankFailed);
+  // ---- the buffers the collectives need: grown first, the outcome agreed on ----
+  const bool grow_x = (int64_t) G * seg_bytes > c->xbuf_bytes || !c->d_xbuf;  // (the same on every rank: same calls before)
+  bool grown = true;
+  if (grow_x)
+    grown = !injected(c, 4) && grow(c, &c->d_xbuf, &c->xbuf_bytes, (int64_t) G * seg_bytes) == AGH_OK;
+  const int64_t seg_d = 4 * Smax;  // doubles per rank of the sample normals' exchange
+  if (calculates_antipodal && G > 1)
+  {
+    // hand_search.cpp:13-26 sharded by point range; the buffer is padded to G equal ranges for the in-place all-gather
+    if (grown && ((int64_t) G * pcnt > c->normals_cap || !c->d_normals))  // (normals_cap counts points)
+    {
+      if (c->d_normals)
+        (void) hipFree(c->d_normals);
+      c->d_normals = nullptr;
+      c->normals_cap = 0;
+      if (hipMalloc((void**) &c->d_normals, sizeof(double) * 3 * (size_t) std::max<int64_t>(G * pcnt, 1)) == hipSuccess)
+        c->normals_cap = (int64_t) G * pcnt;
+      else
+        grown = false;
+    }
+    if (grown)
+      grown = grow(c, &c->d_nbuf, &c->nbuf_doubles, (int64_t) G * seg_d) == AGH_OK;
+  }
+  if (G > 1 && (grow_x || calculates_antipodal))
+  {
+    // The all-points pass is sharded by POINT range, so every rank must hold the same cloud here -- unlike the plain search,
+    // where a cloud per rank is a supported mode.  A rank cannot see another rank's cloud: with different point counts the
+    // byte counts of the normals' all-gather below would differ from rank to rank (a hang or silent garbage under RCCL).
+    // The counts travel with the outcome of the allocations and every rank refuses alike.
+    bool all_ok = false;
+    int64_t sizes[64];
+    if ((rc = shard_agree(c, st, grown, n_cloud, &all_ok, sizes)) != AGH_OK)
+      return rc;
+    *entered = false;  // (every rank saw the same words and returns here or nobody does: nobody is left in a collective)
+    if (!all_ok)
+    {
+      // (every rank drops its exchange buffer: the next call's "does it grow" is then the same question on every rank again)
+      if (c->d_xbuf)
+        (void) hipFree(c->d_xbuf);
+      c->d_xbuf = nullptr;
+      c->xbuf_bytes = 0;
+      c->err = grown ? "agh_find_hands_sharded: another rank of the communicator could not allocate its exchange buffers"
+                     : "agh_find_hands_sharded: out of device memory for the exchange buffers (every rank returns with this call)";
+      c->shard_symmetric_error = true;
+      return AGH_ERR_HIP;
+    }
+    if (calculates_antipodal)
+      for (int q = 0; q < G; q++)
+        if (sizes[q] != sizes[0])
+        {
+          c->err = "agh_find_hands_sharded: calculates_antipodal shards the all-points pass by point range and needs the SAME "
+                   "cloud on every rank (the ranks hold clouds of different sizes)";
+          c->shard_symmetric_error = true;
+          return AGH_ERR_STATE;
+        }
+    *entered = true;
+  }
+  else if (!grown)  // a communicator of one, or a rank alone with its memory: nobody is waiting
+  {
+    c->err = "out of device memory for the shard exchange buffers";
+    *entered = false;
+    return AGH_ERR_HIP;
+  }
+  if (calculates_antipodal && G == 1 && (pcnt > c->normals_cap || !c->d_normals))
+  {
+    if (c->d_normals)
+      (void) hipFree(c->d_normals);
+    c->d_normals = nullptr;
+    c->normals_cap = 0;
+    HIPCHK(c, hipMalloc((void**) &c->d_normals, sizeof(double) * 3 * (size_t) std::max<int64_t>(pcnt, 1)));
+    c->normals_cap = pcnt;
+  }
   timing_begin(c, st);
   c->zero_flags_pending = true;
   c->epoch = next_epoch();
-  c->last_s = Sr;
+  c->last_s = local_rc == AGH_OK ? Sr : 0;
   c->last_nout = -1;
   c->shard_seg_records = seg_records;
   c->shard_seg_bytes = seg_bytes;
@@ -753,153 +923,145 @@ static int find_hands_sharded_device_impl(agh_ctx* ctx, const int32_t* d_sample_
     HIPCHK(c, hipMemsetAsync(d_n_out, 0, sizeof(int64_t), st));
     HIPCHK(c, hipMemsetAsync(c->d_xbuf, 0, (size_t) G * seg_bytes, st));
     c->last_s = 0;
+    if (local_rc != AGH_OK)
+    {
+      c->err = local_err;
+      *entered = false;
+      return local_rc;
+    }
     return AGH_OK;
   }
   const int32_t* my_idx = d_sample_idx + lo;
+  auto ok = [&]() { return local_rc == AGH_OK; };
   if (calculates_antipodal)
   {
-    if (G > 1)
-    {
-      // The all-points pass is sharded by POINT range, so every rank must hold the same cloud here -- unlike the plain search,
-      // where a cloud per rank is a supported mode.  A rank cannot see another rank's cloud: with different point counts the
-      // byte counts of the normals' all-gather below would differ from rank to rank (a hang or silent garbage under RCCL).
-      // The counts are exchanged first (8 bytes per rank, an offline pass) and every rank refuses alike.
-      int64_t mine = c->n, all[64];
-      HIPCHK(c, hipMemcpyAsync(c->d_xcnt + 64 + r, &mine, sizeof(int64_t), hipMemcpyHostToDevice, st));
-      if ((rc = all_gather(c, c->d_xcnt + 64, sizeof(int64_t), st)) != AGH_OK)
-        return rc;
-      HIPCHK(c, hipMemcpyAsync(all, c->d_xcnt + 64, sizeof(int64_t) * (size_t) G, hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipStreamSynchronize(st));
-      for (int q = 0; q < G; q++)
-        if (all[q] != all[0])
-        {
-          c->err = "agh_find_hands_sharded: calculates_antipodal shards the all-points pass by point range and needs the SAME "
-                   "cloud on every rank (the ranks hold clouds of different sizes)";
-          *entered = false;  // (every rank saw the same counts and returns here: nobody is left in a collective)
-          c->shard_symmetric_error = true;
-          return AGH_ERR_STATE;
-        }
-    }
-    // hand_search.cpp:13-26 sharded by point range; the buffer is padded to G equal ranges for the in-place all-gather
-    if ((int64_t) G * pcnt > c->normals_cap || !c->d_normals)  // (normals_cap counts points)
-    {
-      if (c->d_normals)
-        (void) hipFree(c->d_normals);
-      c->d_normals = nullptr;
-      c->normals_cap = 0;
-      HIPCHK(c, hipMalloc((void**) &c->d_normals, sizeof(double) * 3 * (size_t) (G * pcnt)));
-      c->normals_cap = (int64_t) G * pcnt;
-    }
     HIPCHK(c, hipMemsetAsync(c->d_normals, 0, sizeof(double) * 3 * (size_t) (G * pcnt), st));
-    const int64_t p0 = std::min<int64_t>(c->n, (int64_t) r * pcnt), p1 = std::min<int64_t>(c->n, (int64_t) (r + 1) * pcnt);
-    if ((rc = normals_pass(c, p0, p1, st)) != AGH_OK)
-    {
-      c->err = "normals pass launch failed";
-      return rc;
-    }
+    const int64_t p0 = std::min<int64_t>(n_cloud, (int64_t) r * pcnt), p1 = std::min<int64_t>(n_cloud, (int64_t) (r + 1) * pcnt);
+    if (ok() && (rc = normals_pass(c, p0, p1, st)) != AGH_OK)
+      degrade(rc, "normals pass launch failed", kHdrRankFailed);
     if ((rc = all_gather(c, c->d_normals, sizeof(double) * 3 * (size_t) pcnt, st)) != AGH_OK)
       return rc;
     c->has_normals = true;
   }
-  if (Sr > 0)
+  if (ok() && Sr > 0)
   {
-    if ((rc = taubin_moments_eigen(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_nt, st)) != AGH_OK)
-    {
-      c->err = "taubin launch failed";
-      return rc;
-    }
+    if ((rc = injected(c, 2) ? AGH_ERR_HIP : taubin_moments_eigen(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_nt, st)) != AGH_OK)
+      degrade(rc, "taubin launch failed", kHdrRankFailed);
   }
-  else if (c->zero_flags_pending)
+  if (c->zero_flags_pending)  // (no Taubin launch cleared them: an empty or a degraded slice)
   {
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), st));
     c->zero_flags_pending = false;
   }
   if (rand_mode && G > 1)
   {
-    hipLaunchKernelGGL(k_shard_draw_count, dim3(1), dim3(64), 0, st, (const int32_t*) c->d_nt, (int) Sr, c->d_xcnt + r);
+    hipLaunchKernelGGL(k_shard_draw_count, dim3(1), dim3(64), 0, st, (const int32_t*) c->d_nt, ok() ? (int) Sr : 0, c->d_xcnt + r);
     if ((rc = all_gather(c, c->d_xcnt, sizeof(int64_t), st)) != AGH_OK)
       return rc;
     hipLaunchKernelGGL(k_shard_draw_base, dim3(1), dim3(1), 0, st, (const int64_t*) c->d_xcnt, r, c->d_flags + 2);
   }
-  if (Sr > 0 && (rc = taubin_frame_stage(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_frames, c->d_nt, calculates_antipodal != 0, st)) != AGH_OK)
-  {
-    c->err = "taubin launch failed";
-    return rc;
-  }
+  if (ok() && Sr > 0 && (rc = taubin_frame_stage(c, my_idx, Sr, c->p.nn_radius_taubin, c->d_frames, c->d_nt, calculates_antipodal != 0, st)) != AGH_OK)
+    degrade(rc, "taubin launch failed", kHdrRankFailed);
   if (calculates_antipodal && G > 1)
   {
-    const int64_t seg_d = 4 * Smax;
-    if ((rc = grow(c, &c->d_nbuf, &c->nbuf_doubles, (int64_t) G * seg_d)) != AGH_OK)
-      return rc;
-    if (Sr > 0)
+    if (ok() && Sr > 0)
       hipLaunchKernelGGL(k_shard_pack_normals, dim3((unsigned) ((Sr + 255) / 256)), dim3(256), 0, st, (const agh_frame*) c->d_frames,
         (int) Sr, c->d_nbuf + (int64_t) r * seg_d);
+    else  // (nothing of this rank's: every "valid" word zero)
+      HIPCHK(c, hipMemsetAsync(c->d_nbuf + (int64_t) r * seg_d, 0, sizeof(double) * (size_t) seg_d, st));
     if ((rc = all_gather(c, c->d_nbuf, sizeof(double) * (size_t) seg_d, st)) != AGH_OK)
       return rc;
-    hipLaunchKernelGGL(k_shard_scatter_normals, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, (const double*) c->d_nbuf, seg_d,
-      d_sample_idx, S, G, c->d_normals, (int) c->n);
+    if (ok())  // (a degraded rank searches nothing: it needs nobody's normals -- and its sample list may not exist)
+      hipLaunchKernelGGL(k_shard_scatter_normals, dim3((unsigned) ((S + 255) / 256)), dim3(256), 0, st, (const double*) c->d_nbuf, seg_d,
+        d_sample_idx, S, G, c->d_normals, (int) n_cloud);
   }
-  if (Sr > 0)
+  if (ok() && Sr > 0)
   {
     if ((rc = hand_sweep(c, my_idx, Sr, calculates_antipodal != 0, st)) != AGH_OK)
-    {
-      c->err = "hand sweep launch failed";
-      return rc;
-    }
+      degrade(rc, "hand sweep launch failed", kHdrRankFailed);
     // K4 straight into my segment of the exchange buffer; an overflow of the segment shows as count > seg_records
-    if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st, my_count + 1)) != AGH_OK)
-    {
-      c->err = "compaction launch failed";
-      return rc;
-    }
+    else if ((rc = compact_hypotheses(c, Sr, my_out, seg_records, my_count, st, my_count + 1)) != AGH_OK)
+      degrade(rc, "compaction launch failed", kHdrRankFailed);
   }
-  else  // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must
-        // learn of a capacity-class retry from EVERY rank, or this one would repeat the collective alone)
+  if (!ok() || Sr == 0)
   {
-    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags, class_level(c));
+    // an empty slice: count 0 -- and still the flag its share of the all-points pass may have raised (the other ranks must learn
+    // of a capacity-class retry from EVERY rank, or this one would repeat the collective alone); a degraded rank: count 0 and
+    // the word that makes the call fail on every rank
+    hipLaunchKernelGGL(k_shard_empty_header, dim3(1), dim3(1), 0, st, my_count, (const int32_t*) c->d_flags, class_level(c), hdr_extra);
     HIPCHK(c, hipGetLastError());
   }
+  if (!ok())
+    c->shard_cap = 0;  // (the merged list is not this rank's to keep: its output buffer may not exist)
   if ((rc = exchange_and_merge(c, nullptr, st)) != AGH_OK)
     return rc;
   timing_mark(c, "shard_merge", st);
+  if (!ok())
+  {
+    // this rank's own failure, reported at once; its peers read it from the merged flags -- every collective has been issued
+    c->err = local_err;
+    c->last_s = 0;
+    *entered = false;
+    c->shard_symmetric_error = true;
+    return local_rc;
+  }
   return AGH_OK;
 }
 
-static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered);
+static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered, int pre_rc, const char* pre_err);
 
 int agh_classify_sharded_device(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream)
 {
   bool entered = false;
-  const int rc = classify_sharded_device_impl(ctx, d_keep, hip_stream, &entered);
+  const int rc = classify_sharded_device_impl(ctx, d_keep, hip_stream, &entered, AGH_OK, nullptr);
   shard_release_peers(ctx, rc, entered);
   return rc;
 }
 
-static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered)
+// (as the search: a rank that cannot classify -- no SVM loaded on it, a launch failure, no room for the labels -- still takes part
+// in the exchange, with a header that makes the call fail on every rank)
+static int classify_sharded_device_impl(agh_ctx* ctx, uint8_t* d_keep, void* hip_stream, bool* entered, int pre_rc, const char* pre_err)
 {
   if (!ctx)
     return AGH_ERR_INVALID_ARGUMENT;
   Ctx* c = &ctx->c;
-  if (!c->comm || !c->shard_out)
+  if (!c->comm || !c->shard_out || !c->d_xbuf)
   {
     c->err = "agh_classify_sharded: needs a preceding agh_find_hands_sharded";
     return AGH_ERR_STATE;
   }
-  if (!c->has_svm)
-  {
-    c->err = "agh_classify_sharded: no SVM loaded";
-    return AGH_ERR_NO_SVM;
-  }
   *entered = true;
+  int local_rc = pre_rc;
+  std::string local_err = pre_err ? pre_err : "";
+  if (local_rc == AGH_OK && !c->has_svm)
+  {
+    local_rc = AGH_ERR_NO_SVM;
+    local_err = "agh_classify_sharded: no SVM loaded";
+  }
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t) hip_stream : c->stream;
   // K3 on my own hypotheses: their images are here, svm_keep lands in my segment's records
-  int rc = hog_svm(c, std::min<int64_t>(c->last_s * 8, c->shard_seg_records), nullptr, st);
-  if (rc != AGH_OK)
-    return rc;
-  if ((rc = exchange_and_merge(c, d_keep, st)) != AGH_OK)
+  int rc;
+  if (local_rc == AGH_OK && (rc = injected(c, 8) ? AGH_ERR_HIP : hog_svm(c, std::min<int64_t>(c->last_s * 8, c->shard_seg_records), nullptr, st)) != AGH_OK)
+  {
+    local_rc = rc;
+    local_err = "HOG / SVM launch failed";
+  }
+  if (local_rc != AGH_OK)
+  {
+    hipLaunchKernelGGL(k_shard_flag_header, dim3(1), dim3(1), 0, st, c->d_nout_last, kHdrRankFailed);
+    HIPCHK(c, hipGetLastError());
+  }
+  if ((rc = exchange_and_merge(c, local_rc == AGH_OK ? d_keep : nullptr, st)) != AGH_OK)
     return rc;
   timing_mark(c, "shard_merge", st);
+  if (local_rc != AGH_OK)
+  {
+    c->err = local_err;
+    *entered = false;
+    c->shard_symmetric_error = true;
+    return local_rc;
+  }
   return AGH_OK;
 }
 
@@ -928,6 +1090,16 @@ static int shard_flags(Ctx* c, hipStream_t st, int64_t* n)
     c->err = "a Taubin neighbourhood exceeds the capacity classes launched so far; the contexts of the communicator now launch the "
              "larger classes as well: repeat the call";
     return AGH_ERR_RETRY;
+  }
+  if (flags[0] & kFlagShardPeerNoCloud)
+  {
+    c->err = "a rank of the communicator holds no cloud (agh_set_cloud* on every rank first); no list";
+    return AGH_ERR_NO_CLOUD;
+  }
+  if (flags[0] & kFlagShardPeerFailed)
+  {
+    c->err = "a rank of the communicator could not do its share of the call (its own agh_last_error says why); no list";
+    return AGH_ERR_STATE;
   }
   if (flags[0] & 2)
   {
@@ -972,50 +1144,65 @@ static int find_hands_sharded_host_impl(agh_ctx* ctx, const int32_t* sample_idx,
              "through all N points in order); use deterministic normals or one GPU for this offline pass";
     return AGH_ERR_STATE;
   }
-  if (!c->has_cloud)
-  {
-    c->err = "agh_find_hands_sharded: no cloud set";
-    return AGH_ERR_NO_CLOUD;
-  }
   if (n_samples < 0 || (n_samples > 0 && !sample_idx) || cap < 0 || (cap > 0 && !out))
   {
     c->err = "agh_find_hands_sharded: bad arguments";
     return AGH_ERR_INVALID_ARGUMENT;
   }
   *entered = true;  // every rank passed the same checks on the same arguments: what fails from here on fails on this rank alone
+  // ... and a rank it fails on does not leave: it hands its failure to the device variant (pre_rc), which takes part in every
+  // collective with an empty, flagged segment -- so does a rank without a cloud (checked there)
+  int pre_rc = AGH_OK;
+  std::string pre_err;
+  auto pre_fail = [&](int rc_, const std::string& what) {
+    if (pre_rc == AGH_OK)
+    {
+      pre_rc = rc_;
+      pre_err = what;
+    }
+  };
   // (The sample indices are NOT range-checked here.  A rank reads only its slice of the list -- when every rank searches a cloud
   // of its own the other slices index other clouds -- so a host-side check could only ever fail on ONE rank, which would then
   // leave before the collectives the others wait in.  The kernels validate every index they read
   // (kStatusBadIndex), the finding travels in the rank's segment header, and every rank returns AGH_ERR_INVALID_ARGUMENT
   // together after the exchange.)
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0));
+  const int64_t n_cloud = c->has_cloud ? c->n : 0;
+  int rc = injected(c, 16) ? AGH_ERR_HIP : ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(n_cloud, kNormalsChunk) : 0));
   if (rc != AGH_OK)
-    return rc;
-  if (n_samples > c->idx_cap || !c->d_idx_own)
+    pre_fail(rc, c->err.empty() ? "out of device memory for the per-call buffers" : c->err);
+  if (pre_rc == AGH_OK && (n_samples > c->idx_cap || !c->d_idx_own))
   {
     if (c->d_idx_own)
       (void) hipFree(c->d_idx_own);
     c->d_idx_own = nullptr;
     c->idx_cap = 0;
-    HIPCHK(c, hipMalloc((void**) &c->d_idx_own, sizeof(int32_t) * (size_t) std::max<int64_t>(n_samples, 1024)));
-    c->idx_cap = std::max<int64_t>(n_samples, 1024);
+    if (hipMalloc((void**) &c->d_idx_own, sizeof(int32_t) * (size_t) std::max<int64_t>(n_samples, 1024)) == hipSuccess)
+      c->idx_cap = std::max<int64_t>(n_samples, 1024);
+    else
+      pre_fail(AGH_ERR_HIP, "out of device memory for the sample list");
   }
-  if (n_samples > 0)
-    HIPCHK(c, hipMemcpyAsync(c->d_idx_own, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream));
+  if (pre_rc == AGH_OK && n_samples > 0 &&
+      hipMemcpyAsync(c->d_idx_own, sample_idx, sizeof(int32_t) * n_samples, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    pre_fail(AGH_ERR_HIP, "the sample list could not be copied to the device");
   int64_t n = 0;
   for (int attempt = 0; attempt < 4; attempt++)  // (at most two repeats for the capacity classes, one for the segment size)
   {
     // (a retry may have switched a capacity class on that wants larger per-sample scratch: sized here, not under the device call)
-    if ((rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(c->n, kNormalsChunk) : 0))) != AGH_OK)
-      return rc;
-    // (s_cap >= n_samples, so d_out_own holds the complete list: 8 slots per sample)
-    rc = agh_find_hands_sharded_device(ctx, c->d_idx_own, n_samples, calculates_antipodal, c->d_out_own, c->s_cap * 8, c->d_nout,
-      c->stream);
+    if (pre_rc == AGH_OK &&
+        (rc = ensure_call_buffers(c, std::max<int64_t>(n_samples, calculates_antipodal ? std::min<int64_t>(n_cloud, kNormalsChunk) : 0))) != AGH_OK)
+      pre_fail(rc, c->err);
+    // (s_cap >= n_samples, so d_out_own holds the complete list: 8 slots per sample.  A rank that failed above hands over
+    // pointers nobody reads: a degraded rank launches nothing on the sample list and keeps no list)
+    const bool usable = pre_rc == AGH_OK;
+    bool in_coll = false;
+    rc = find_hands_sharded_device_impl(ctx, usable ? c->d_idx_own : reinterpret_cast<const int32_t*>(c->d_flags), n_samples,
+      calculates_antipodal, usable ? c->d_out_own : reinterpret_cast<agh_hypothesis*>(c->d_flags), usable ? c->s_cap * 8 : 0,
+      c->d_nout, c->stream, &in_coll, pre_rc, pre_err.c_str());
     if (rc != AGH_OK)
     {
       (void) hipStreamSynchronize(c->stream);
-      *entered = !c->shard_symmetric_error;
+      *entered = in_coll && !c->shard_symmetric_error;
       return rc;
     }
     rc = shard_flags(c, c->stream, &n);
@@ -1077,13 +1264,10 @@ static int classify_sharded_host_impl(agh_ctx* ctx, agh_hypothesis* out, uint8_t
     c->err = "agh_classify_sharded: needs a preceding agh_find_hands_sharded (host variant)";
     return AGH_ERR_STATE;
   }
-  if (!c->has_svm)
-  {
-    c->err = "agh_classify_sharded: no SVM loaded";
-    return AGH_ERR_NO_SVM;
-  }
   *entered = true;
   HIPCHK(c, hipSetDevice(c->device));
+  int pre_rc = AGH_OK;
+  const char* pre_err = nullptr;
   const int64_t room = c->s_cap * 8;
   if (room > c->keep_cap)
   {
@@ -1094,13 +1278,23 @@ static int classify_sharded_host_impl(agh_ctx* ctx, agh_hypothesis* out, uint8_t
     c->d_keep = nullptr;
     c->d_svm_sums = nullptr;
     c->keep_cap = 0;
-    HIPCHK(c, hipMalloc((void**) &c->d_keep, (size_t) room));
-    HIPCHK(c, hipMalloc((void**) &c->d_svm_sums, (size_t) room * sizeof(double)));
-    c->keep_cap = room;
+    if (hipMalloc((void**) &c->d_keep, (size_t) room) == hipSuccess &&
+        hipMalloc((void**) &c->d_svm_sums, (size_t) room * sizeof(double)) == hipSuccess)
+      c->keep_cap = room;
+    else
+    {
+      pre_rc = AGH_ERR_HIP;  // (this rank still takes part in the exchange: agh_classify_sharded_device's comment)
+      pre_err = "out of device memory for the labels";
+    }
   }
-  int rc = agh_classify_sharded_device(ctx, c->d_keep, c->stream);
+  bool in_coll = false;
+  int rc = classify_sharded_device_impl(ctx, c->d_keep, c->stream, &in_coll, pre_rc, pre_err);
   if (rc != AGH_OK)
+  {
+    (void) hipStreamSynchronize(c->stream);
+    *entered = in_coll && !c->shard_symmetric_error;
     return rc;
+  }
   int64_t n = 0;
   rc = shard_flags(c, c->stream, &n);
   *entered = rc == AGH_ERR_HIP;  // (the collective is over; what is reported from here on is the same on every rank)

@@ -102,6 +102,18 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     if (first_class && tid == 0)
       scloud[s] = cloud;
   }
+  // A sample AT a non-finite point (reachable only by calling the search on a raw capture: Localization removes NaNs first,
+  // localization.cpp:27): PCL's kd-tree holds no such point and its radiusSearch asserts on such a query; here, as for an empty
+  // neighbourhood: no frame, no hypotheses, no error.
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)))
+  {
+    if (tid == 0)
+    {
+      status[s] = kStatusOk;
+      nt[s] = 0;
+    }
+    return;
+  }
   if (tid == 0)
     count = 0;
   for (int k = tid; k < kSortBins; k += 256)
@@ -1290,50 +1302,82 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   double best = -1.0;
   int best_j = 0x7fffffff;
   // Many candidates -- an exactly planar neighbourhood, where every normal is +-n and no estimate can tell the columns apart:
-  // all n of them, n^2 terms -- take them FOUR at a time: a term's normal is read from LDS once and serves four columns
-  // (one column at a time the phase is bound by LDS bandwidth: 24 bytes per 9 flops; 275 us at the axis-aligned C2).
+  // all n of them, n^2 terms -- take them EIGHT at a time: a term's normal is read from LDS once and serves eight columns (one
+  // column at a time the phase is bound by LDS bandwidth: 24 bytes per 9 flops; 275 us at the axis-aligned C2), and the eight
+  // LaneSum64 butterflies run as ONE transposed butterfly: at the strides 32, 16 and 8 a lane hands on the half of its partial
+  // sums its partner keeps (v_permlane32_swap / v_permlane16_swap / row_ror:8), so 4 + 2 + 1 + 3 additions do what 8 x 6 did,
+  // every one of them the same pair (p[l], p[l ^ o]) the separate butterflies add: lane l ends with the total of column l >> 3,
+  // bit for bit.  (Round 5 took four columns with four separate butterflies: 201 us at the axis-aligned C2.)
+  // What bounds the phase: 9 separately rounded fp64 operations per term (the oracle's (x x' + y y') + z z', squared, cubed,
+  // added) -- n^2 terms summed over C2u's planar samples are 5.1 G lane-operations, 131 us at the chip's fp64 issue rate.
   if (CAP > 128 && ncnd >= 16)
+  {
     for (;;)
     {
       int c = 0;
       if (lane == 0)
-        c = atomicAdd(&next_col, 4);
+        c = atomicAdd(&next_col, 8);
       c = __builtin_amdgcn_readfirstlane(c);
       if (c >= ncnd)
         break;
-      int jj[4];
-      double jx[4], jy[4], jz[4], acc[4];
+      double jx[8], jy[8], jz[8], acc[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 8; u++)
       {
-        jj[u] = cand[min(c + u, ncnd - 1)];  // (a short last group repeats its last column; the repeats are not compared)
-        jx[u] = nx[jj[u]];
-        jy[u] = ny[jj[u]];
-        jz[u] = nz[jj[u]];
+        const int jj = cand[min(c + u, ncnd - 1)];  // (a short last group repeats its last column; the repeats are not compared)
+        jx[u] = nx[jj];
+        jy[u] = ny[jj];
+        jz[u] = nz[jj];
         acc[u] = 0.0;
       }
       for (int t = lane; t < ks; t += 64)
       {
         const double tx = nx[t], ty = ny[t], tz = nz[t];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 8; u++)
         {
           const double gdot = (tx * jx[u] + ty * jy[u]) + tz * jz[u];
           const double g2 = gdot * gdot;
           acc[u] += (g2 * g2) * g2;
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; u++)
+      auto sum32 = [](double a, double b) -> double {  // lanes < 32: a[l] + a[l + 32]; lanes >= 32: b[l - 32] + b[l]
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+        return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
+      };
+      auto sum16 = [](double a, double b) -> double {  // even rows: a over (l, l + 16); odd rows: b over (l - 16, l)
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+        return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
+      };
+      const double v0 = sum32(acc[0], acc[4]), v1 = sum32(acc[1], acc[5]), v2 = sum32(acc[2], acc[6]), v3 = sum32(acc[3], acc[7]);
+      const double w0 = sum16(v0, v2), w1 = sum16(v1, v3);  // rows: columns {0, 2, 4, 6} and {1, 3, 5, 7}
+      const bool up = (lane & 8) != 0;
+      double x = (up ? w1 : w0) + xor_partner_f64<8>(up ? w0 : w1);
+      x = x + xor_partner_f64<4>(x);
+      x = x + xor_partner_f64<2>(x);
+      x = x + xor_partner_f64<1>(x);  // lane l: the total of column c + (l >> 3)
+      const int u = lane >> 3;
+      const int jcol = cand[min(c + u, ncnd - 1)];
+      if (c + u < ncnd && (x > best || (x == best && jcol < best_j) || best_j == 0x7fffffff))
       {
-        const double a = wave_allsum_f64(acc[u]);
-        if (c + u < ncnd && (a > best || (a == best && jj[u] < best_j) || best_j == 0x7fffffff))
-        {
-          best = a;
-          best_j = jj[u];
-        }
+        best = x;
+        best_j = jcol;
       }
     }
+    // the lanes hold the best of their own columns: the wave's best (first index on ties) on every lane, as the loop below expects
+    for (int o = 32; o >= 8; o >>= 1)
+    {
+      const double ob = __shfl_xor(best, o);
+      const int oj = __shfl_xor(best_j, o);
+      if (oj != 0x7fffffff && (best_j == 0x7fffffff || ob > best || (ob == best && oj < best_j)))
+      {
+        best = ob;
+        best_j = oj;
+      }
+    }
+  }
   for (;;)
   {
     int c = 0;

@@ -233,6 +233,22 @@ int agh_localize(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n
 int agh_localize_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp,
   agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap, agh_hypothesis* hands_out,
   int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
+/* The same chain as two calls, so that the NEXT capture goes up while this one is searched (the caller of
+ * grasp_localizer.cpp:95-103 is handed one cloud after the other; the 8 MB upload of a 700k-point capture is 0.16 ms of a
+ * 0.8 ms call, serial in front of everything):
+ *   agh_localize_begin(ctx, cloud k)      queues the whole chain of cloud k and returns without waiting
+ *   agh_localize_stage(ctx, cloud k + 1)  copies capture k + 1 into the context's second raw buffer on a stream of its own,
+ *                                         beside cloud k's kernels (a pageable source: the call lasts as long as the copy)
+ *   agh_localize_end(ctx, outputs)        the one synchronisation; cloud k's results, exactly agh_localize's
+ *   agh_localize_begin(ctx, cloud k + 1)  recognises the staged capture (same pointer, stride and count): no upload
+ * agh_localize(...) is begin + end.  One chain may be in flight (AGH_ERR_STATE for a second begin, or an end without a
+ * begin); between begin and end only agh_localize_stage may be called on the context.  The buffers handed to begin and to stage
+ * must stay valid and unchanged until the agh_localize_end of their chain (begin) / the agh_localize_begin that adopts them
+ * (stage) has returned; sample_idx is copied by begin.  A staged capture that the next begin does not name is dropped. */
+int agh_localize_begin(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp);
+int agh_localize_stage(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n);
+int agh_localize_end(agh_ctx* ctx, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
+  agh_hypothesis* hands_out, int64_t hands_cap, int32_t* samples_out, agh_localize_result* result);
 
 /* The context's current cloud: packed xyz (3 floats per point) and camera ids; returns the number of points. */
 int agh_get_cloud(agh_ctx* ctx, float* xyz_out, int32_t* cam_out, int64_t cap);
@@ -345,6 +361,14 @@ int agh_comm_last_count(const agh_ctx* ctx, int64_t* n_hyp);
  * every rank's exchange buffer), *via_rccl = 1 for ncclAllGather, 0 for the in-process communicator's device copies.  Any of
  * the three may be NULL.  AGH_ERR_STATE without a communicator or before the first sharded search. */
 int agh_comm_last_exchange(const agh_ctx* ctx, int64_t* segment_bytes, int32_t* n_ranks, int32_t* via_rccl);
+/* Testing aid (tests/test_gpu_sharding.py): make this rank fail ON ITS OWN at the named sites of its next sharded call, as an
+ * out-of-memory or a launch error would -- 1: per-call buffers (device variant), 2: the Taubin launch, 4: growth of the exchange
+ * buffer, 8: the HOG / SVM launch of agh_classify_sharded*, 16: per-call buffers (host variant); one shot per bit.  What the tests
+ * then check is the contract of the sharded calls: such a rank still takes part in every collective (an empty segment whose header
+ * says so), every rank returns an error for the call (the failing rank its own, the others AGH_ERR_STATE, or AGH_ERR_HIP together
+ * when an exchange buffer could not grow), and the communicator stays usable. */
+int agh_comm_inject_fault(agh_ctx* ctx, int32_t sites);
+
 /* Tuning: record slots of one rank's exchange segment (0 = the default described at agh_find_hands_sharded_device; values
  * above 8 per sample are clipped).  Every rank must use the same value. */
 int agh_comm_set_segment_records(agh_ctx* ctx, int64_t records);

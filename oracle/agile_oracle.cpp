@@ -77,6 +77,8 @@ struct Cloud
   inline const float* pt(int64_t i) const { return xyz + i * stride; }
 };
 
+static inline bool finite_pt(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
 struct GridIndex
 {
   double cell = 0;
@@ -103,13 +105,22 @@ struct GridIndex
       mn[a] = 1e300;
       mx[a] = -1e300;
     }
+    /* A point with a non-finite coordinate is not part of the search structure: pcl::KdTreeFLANN::setInputCloud
+     * (hand_search.cpp:10-11; PCL 1.7 kdtree_flann.hpp, convertCloudToArray) skips every point its point representation calls
+     * invalid, so radiusSearch can never return it.  It keeps its index (the other points' indices do not move). */
+    int64_t n_finite = 0;
     for (int64_t i = 0; i < cl.n; i++)
+    {
+      if (!finite_pt(cl.pt(i)))
+        continue;
+      n_finite++;
       for (int a = 0; a < 3; a++)
       {
         mn[a] = std::min(mn[a], (double) cl.pt(i)[a]);
         mx[a] = std::max(mx[a], (double) cl.pt(i)[a]);
       }
-    if (cl.n == 0)
+    }
+    if (n_finite == 0)
       for (int a = 0; a < 3; a++)
         mn[a] = mx[a] = 0;
     for (int a = 0; a < 3; a++)
@@ -126,6 +137,11 @@ struct GridIndex
     std::vector<int64_t> key(cl.n);
     for (int64_t i = 0; i < cl.n; i++)
     {
+      if (!finite_pt(cl.pt(i)))
+      {
+        key[i] = -1;
+        continue;
+      }
       int64_t c[3];
       coords(cl.pt(i), c);
       key[i] = (c[2] * dim[1] + c[1]) * dim[0] + c[0];
@@ -133,15 +149,19 @@ struct GridIndex
     }
     for (int64_t k = 0; k < ncell; k++)
       start[k + 1] += start[k];
-    items.resize(cl.n);
+    items.resize(n_finite);
     std::vector<int64_t> fill(start.begin(), start.end() - 1);
     for (int64_t i = 0; i < cl.n; i++)
-      items[fill[key[i]]++] = (int32_t) i;
+      if (key[i] >= 0)
+        items[fill[key[i]]++] = (int32_t) i;
   }
 
   void query(const Cloud& cl, const float* q, double radius, std::vector<Neighbor>& out) const
   {
     out.clear();
+    /* a non-finite query (PCL asserts on one; with assertions compiled out FLANN finds nothing): no neighbours */
+    if (!finite_pt(q))
+      return;
     const float r2 = static_cast<float>(radius * radius);
     int64_t lo[3], hi[3];
     for (int a = 0; a < 3; a++)

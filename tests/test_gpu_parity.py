@@ -557,3 +557,51 @@ def test_larger_capacity_classes_are_switched_on_by_the_first_cloud_that_needs_t
     got = np.frombuffer(out_t.cpu().numpy().tobytes(), dtype=binding.HYP_DTYPE)[: int(n_t.item())]
     assert len(got) == len(ref) > 0
     assert _unstamped(got) == _unstamped(ref)
+
+
+def _with_non_finite_points(sc, seed=7):
+    """The scene with 1 % of its points made non-finite (a NaN in one coordinate, all NaN, +-Inf) and twenty of them added to the
+    sample list: what HandSearch::findHands sees when it is called on a raw capture (hands_test.cpp:21-40)."""
+    rng = np.random.default_rng(seed)
+    xyz = sc.xyz.copy()
+    bad = rng.permutation(sc.n)[:max(40, sc.n // 100)]
+    q = bad.size // 4
+    xyz[bad[:q], rng.integers(0, 3, q)] = np.nan
+    xyz[bad[q:2 * q]] = np.inf
+    xyz[bad[2 * q:3 * q], 1] = -np.inf
+    xyz[bad[3 * q:]] = np.nan
+    samples = np.unique(np.concatenate([sc.samples, bad[:20]])).astype(np.int32)
+    return xyz, bad, samples
+
+
+@pytest.mark.parametrize("scene_name", ["tiny", "small"])
+def test_non_finite_points_bit_exact(scene_name):
+    """agh_set_cloud with NaN / Inf points.  Defined as PCL's kd-tree defines it (setInputCloud drops them:
+    they are nobody's neighbour; indices do not move); a sample AT such a point has no frame and no hypotheses.  GPU == oracle."""
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config(scene_name)
+    xyz, bad, samples = _with_non_finite_points(sc)
+    ctx = _ctx(sc)
+    ctx.set_cloud(xyz, sc.cam)
+    hyps = ctx.find_hands(samples)
+    ref = O.find_hands(O.default_params(sc.cam_origins), xyz, sc.cam, samples, want_images=True)
+    fr = ctx.frames()
+    for f in ("valid", "n_nb", "majority_cam", "max_index", "params", "eigenvalue", "normal", "axis", "binormal"):
+        assert np.array_equal(fr[f], ref["frames"][f]), f
+    at_bad = np.isin(samples, bad)
+    assert at_bad.sum() >= 20 and not fr["valid"][at_bad].any() and fr["valid"][~at_bad].all()
+    nt, nh = ctx.neighbor_counts()
+    assert np.array_equal(nt, ref["frames"]["n_nb"]) and np.array_equal(nh, ref["nh"])
+    assert len(hyps) > 5
+    assert_hyps_equal(hyps, ref["hyps"])
+    assert np.array_equal(ctx.images(), ref["images"])
+    # ... and the device-resident entry points, and a cloud without one finite point
+    import torch
+
+    ctx.set_cloud_torch(torch.from_numpy(xyz).cuda(), torch.from_numpy(sc.cam).cuda())
+    assert_hyps_equal(ctx.find_hands(samples), ref["hyps"])
+    nothing = np.full((64, 3), np.nan, np.float32)
+    ctx.set_cloud(nothing, np.zeros(64, np.int32))
+    assert len(ctx.find_hands(np.arange(8, dtype=np.int32))) == 0

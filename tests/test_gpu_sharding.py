@@ -555,3 +555,103 @@ def test_antipodal_pass_refuses_clouds_of_different_sizes_on_every_rank(tiny_sce
     assert [code for _, code in res] == [binding.AGH_ERR_STATE] * 3
     res = _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(few))  # still usable
     assert len({len(h) for h in res}) == 1 and len(res[0]) > 0
+
+
+# ---- round 6: no rank leaves alone ----
+@pytest.mark.parametrize("site, host", [(1, False), (2, False), (2, True), (16, True)])
+def test_a_rank_that_fails_on_its_own_takes_part_and_every_rank_returns(tiny_scene, site, host):
+    """VERDICT r5 item 7.  Rank 1 of three fails on its own after the argument checks -- its per-call buffers cannot be allocated
+    (sites 1 / 16), its Taubin launch fails (2).  It used to return at once and leave its peers inside the all-gather (raw RCCL: for
+    ever; in-process: the group aborted).  Now it takes part with an empty segment whose header says so: the failing rank returns its
+    own error, the others AGH_ERR_STATE, nobody hangs, and the communicator is usable for the next call."""
+    import torch
+
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    ctxs = _group(sc, 3)
+    ctxs[1].comm_inject_fault(site)
+    if host:
+        res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    else:
+        S = sc.samples.size
+        s_t = torch.from_numpy(sc.samples).cuda()
+        bufs = [(torch.zeros(8 * S * 160, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"))
+                for _ in ctxs]
+
+        def dev(r, c):
+            c.find_hands_sharded_torch(s_t, bufs[r][0], bufs[r][1])
+            c.synchronize()  # (device variants report the merged flags here)
+
+        res = _run_ranks_codes(ctxs, dev)
+    codes = [code for _, code in res]
+    assert codes[1] == binding.AGH_ERR_HIP and codes[0] == codes[2] == binding.AGH_ERR_STATE, codes
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):  # the communicator survived
+        _same(hyps, ref)
+
+
+def test_a_rank_without_a_cloud_fails_the_call_on_every_rank(tiny_scene):
+    """`!has_cloud` on ONE rank (a caller's bug) used to be that rank's early return and its peers' hang.  The rank now takes part
+    like one with an empty cloud and flags its header: AGH_ERR_NO_CLOUD on every rank, communicator usable."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctxs = [binding.Context(sc.cam_origins) for _ in range(3)]
+    ctxs[0].set_cloud(sc.xyz, sc.cam)
+    ctxs[2].set_cloud(sc.xyz, sc.cam)
+    binding.comm_init_local(ctxs)
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    assert [code for _, code in res] == [binding.AGH_ERR_NO_CLOUD] * 3
+    ctxs[1].set_cloud(sc.xyz, sc.cam)
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        _same(hyps, ref)
+
+
+def test_exchange_buffer_growth_is_agreed_on(tiny_scene):
+    """The buffers the collectives themselves need are grown first and the outcome is agreed on (8 bytes per rank, only on a call
+    that grows one): a rank that is out of memory makes EVERY rank return AGH_ERR_HIP before the first variable-size collective,
+    and the next call grows them again on every rank."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    one = binding.Context(sc.cam_origins)
+    one.set_cloud(sc.xyz, sc.cam)
+    ref = one.find_hands(sc.samples)
+    ctxs = _group(sc, 3)
+    ctxs[2].comm_inject_fault(4)
+    res = _run_ranks_codes(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    assert [code for _, code in res] == [binding.AGH_ERR_HIP] * 3
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples)):
+        _same(hyps, ref)
+    # the same in the offline all-points pass (its cloud sizes travel with the same words)
+    for hyps in _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples, calculates_antipodal=True)):
+        assert len(hyps) == len(ref)
+
+
+def test_a_rank_that_cannot_classify_fails_the_call_on_every_rank(tiny_scene, svm_model):
+    """agh_classify_sharded: no SVM on one rank, or its HOG / SVM launch fails -- the rank still joins the label exchange."""
+    from agile_grasp_amd import binding
+
+    sc = tiny_scene
+    ctxs = _group(sc, 3)
+    for r in (0, 2):
+        ctxs[r].load_svm(*svm_model)
+    _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    res = _run_ranks_codes(ctxs, lambda r, c: c.classify_sharded())
+    codes = [code for _, code in res]
+    assert codes[1] == binding.AGH_ERR_NO_SVM and codes[0] == codes[2] == binding.AGH_ERR_STATE, codes
+    ctxs[1].load_svm(*svm_model)
+    _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    ctxs[0].comm_inject_fault(8)
+    res = _run_ranks_codes(ctxs, lambda r, c: c.classify_sharded())
+    codes = [code for _, code in res]
+    assert codes[0] == binding.AGH_ERR_HIP and codes[1] == codes[2] == binding.AGH_ERR_STATE, codes
+    _run_ranks(ctxs, lambda r, c: c.find_hands_sharded(sc.samples))
+    keeps = [k for _, k in _run_ranks(ctxs, lambda r, c: c.classify_sharded())]
+    assert all(np.array_equal(k, keeps[0]) for k in keeps) and keeps[0].size > 0

@@ -331,3 +331,31 @@ def test_shipped_svm_separates_antipodal_hands_through_this_hog_and_not_through_
     for ws in scrambled:
         _k, s2 = O.classify(r["images"], ws, rho)
         assert _auc(half, -s2) < auc - 0.08
+
+
+def test_non_finite_points_are_invisible():
+    """pcl::KdTreeFLANN::setInputCloud drops points with a non-finite coordinate (hand_search.cpp:10-11), so the search on a
+    cloud that holds some equals the search on the cloud without them (indices remapped), and a sample AT one has no frame."""
+    from agile_grasp_amd import synthetic
+
+    sc = synthetic.config("tiny")
+    rng = np.random.default_rng(7)
+    xyz = sc.xyz.copy()
+    bad = rng.permutation(sc.n)[:120]
+    xyz[bad[:30], rng.integers(0, 3, 30)] = np.nan
+    xyz[bad[30:60]] = np.inf
+    xyz[bad[60:90], 1] = -np.inf
+    xyz[bad[90:]] = np.nan
+    samples = np.unique(np.concatenate([sc.samples, bad[:10]])).astype(np.int32)
+    p = O.default_params(sc.cam_origins)
+    a = O.find_hands(p, xyz, sc.cam, samples)
+    keep = np.ones(sc.n, bool)
+    keep[bad] = False
+    remap = np.cumsum(keep) - 1
+    b = O.find_hands(p, xyz[keep], sc.cam[keep], remap[samples[keep[samples]]].astype(np.int32))
+    assert len(a["hyps"]) == len(b["hyps"]) > 0
+    for f in ("orientation", "finger_index", "depth_index", "n_in_box", "cam_source", "axis", "approach", "binormal", "bottom",
+              "surface", "width"):
+        assert np.array_equal(a["hyps"][f], b["hyps"][f]), f
+    assert not a["frames"]["valid"][np.isin(samples, bad)].any()
+    assert np.array_equal(a["frames"]["valid"][~np.isin(samples, bad)], b["frames"]["valid"])

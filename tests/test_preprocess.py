@@ -236,3 +236,52 @@ def test_localize_edge_cases(svm_model):
     # an empty capture
     got = ctx.localize(np.zeros((0, 3), np.float32), 0, rc.workspace, n_samples=16)
     assert got["n_voxels"] == 0 and got["n_hypotheses"] == 0 and len(got["handles"]) == 0
+
+
+@pytest.mark.gpu
+def test_localize_begin_stage_end_equals_the_one_call(svm_model):
+    """the chain as agh_localize_begin / agh_localize_end with the NEXT capture staged in between
+    (agh_localize_stage: a second raw buffer, a second stream, under the kernels of the chain in flight).  A stream of captures of
+    different sizes through the split calls equals the same stream through agh_localize, every field; a staged capture that the
+    next begin does not name is dropped; the state errors are loud."""
+    from agile_grasp_amd import binding, synthetic
+
+    w, rho = svm_model
+    raws = [synthetic.make_raw_cloud(120_000, 7, n_objects=4), synthetic.make_raw_cloud(60_000, 8, n_objects=2),
+            synthetic.make_raw_cloud(200_000, 9, n_objects=6)]
+    one, two = binding.Context(raws[0].cam_origins), binding.Context(raws[0].cam_origins)
+    for c in (one, two):
+        c.load_svm(w, rho)
+    with pytest.raises(binding.AghError) as e:
+        two.localize_end()
+    assert e.value.code == binding.AGH_ERR_STATE
+    order = [0, 1, 2, 1, 0, 2, 2]
+    clouds = [np.ascontiguousarray(raws[k].xyz) for k in order]  # (one array object per capture: staged captures are named by it)
+    kw = [dict(n_samples=500, sample_seed=11 + i, classify=True, min_inliers=2) for i in range(len(order))]
+    got = []
+    two.localize_begin(clouds[0], raws[order[0]].size_left, raws[order[0]].workspace, **kw[0])
+    with pytest.raises(binding.AghError) as e:  # one chain in flight
+        two.localize_begin(clouds[0], raws[order[0]].size_left, raws[order[0]].workspace, **kw[0])
+    assert e.value.code == binding.AGH_ERR_STATE
+    for i in range(len(order)):
+        if i + 1 < len(order):
+            # every second time the staged capture is NOT the one the next begin names: it must be dropped, not searched
+            two.localize_stage(clouds[i + 1] if i % 2 == 0 else clouds[(i + 2) % len(order)])
+        got.append(two.localize_end())
+        if i + 1 < len(order):
+            rc = raws[order[i + 1]]
+            two.localize_begin(clouds[i + 1], rc.size_left, rc.workspace, **kw[i + 1])
+    n_handles = 0
+    for i, k in enumerate(order):
+        ref = one.localize(raws[k].xyz, raws[k].size_left, raws[k].workspace, **kw[i])
+        g = got[i]
+        assert g["n_voxels"] == ref["n_voxels"] and g["n_hypotheses"] == ref["n_hypotheses"] > 0
+        assert np.array_equal(g["samples"], ref["samples"]) and np.array_equal(g["inlier_idx"], ref["inlier_idx"])
+        for f in HYP_FIELDS:
+            assert np.array_equal(g["hands"][f], ref["hands"][f]), f
+        for f in HANDLE_FIELDS:
+            assert np.array_equal(g["handles"][f], ref["handles"][f]), f
+        n_handles += len(ref["handles"])
+    assert n_handles > 0
+    # the context is an ordinary one afterwards
+    assert two.cloud()[0].shape[0] == got[-1]["n_voxels"]
