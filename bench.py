@@ -431,13 +431,40 @@ def pipeline_extra(steps: int):
     td = [one_dev() for _ in range(steps)]
     assert td[-1][1:] == t1[-1][1:], (td[-1], t1[-1])
     assert t4[-1][1:] == t1[-1][1:], (t4[-1], t1[-1])
+    # a STREAM of captures: the next capture staged (agh_localize_stage: second raw buffer, second stream) between
+    # agh_localize_begin and agh_localize_end of this one, so its upload runs under this one's kernels
+    caps = [np.ascontiguousarray(rc.xyz.copy()) for _ in range(3)]
+    kw = dict(samples=samples, classify=True, min_inliers=3, min_length=0.005)
+
+    def stream(n):
+        t = []
+        ctx.localize_begin(caps[0], rc.size_left, rc.workspace, **kw)
+        t0 = time.perf_counter()
+        for i in range(n):
+            if i + 1 < n:
+                ctx.localize_stage(caps[(i + 1) % 3])
+            r = ctx.localize_end()
+            if i + 1 < n:
+                ctx.localize_begin(caps[(i + 1) % 3], rc.size_left, rc.workspace, **kw)
+            t1_ = time.perf_counter()
+            t.append((t1_ - t0, r["n_hypotheses"], len(r["hands"]), len(r["handles"])))
+            t0 = t1_
+        return t
+
+    stream(4)
+    ts = stream(steps + 2)[1:-1]  # (the first capture of a stream has nothing to hide behind, the last one stages nothing)
+    assert ts[-1][1:] == t1[-1][1:], (ts[-1], t1[-1])
     return {"workload": "raw two-view capture, 699999 points -> 3 mm voxels -> 2000-sample search -> HOG + SVM -> handle search "
                         "(grasp_localizer.cpp:95-103), host buffers in and out",
             "voxels": int(nv), "hypotheses": int(t1[-1][1]), "svm_kept": int(t1[-1][2]), "handles": int(t1[-1][3]),
             "four_calls_ms": statistics.median(t[0] for t in t4) * 1e3, "agh_localize_ms": statistics.median(t[0] for t in t1) * 1e3,
             "agh_localize_min_ms": min(t[0] for t in t1) * 1e3, "agh_localize_max_ms": max(t[0] for t in t1) * 1e3,
             "four_calls_min_ms": min(t[0] for t in t4) * 1e3, "four_calls_max_ms": max(t[0] for t in t4) * 1e3,
-            "agh_localize_device_ms": statistics.median(t[0] for t in td) * 1e3, "calls": steps}
+            "agh_localize_device_ms": statistics.median(t[0] for t in td) * 1e3, "calls": steps,
+            "begin_stage_end_ms": statistics.median(t[0] for t in ts) * 1e3, "begin_stage_end_min_ms": min(t[0] for t in ts) * 1e3,
+            "begin_stage_end_max_ms": max(t[0] for t in ts) * 1e3,
+            "begin_stage_end_note": "per capture of a stream, steady state: agh_localize_begin(k) / agh_localize_stage(k + 1) / "
+                                    "agh_localize_end(k) -- capture k + 1 goes up under capture k's kernels; same results"}
 
 
 def settle(ctx, step, fence):

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 for cfg in C2 C3 C4; do
   rm -rf /tmp/kt_$cfg
   # (--batch-clouds 0: every k_hand_sweep launch of the trace is the single-cloud launch the bench line's roofline describes)
@@ -56,6 +56,13 @@ timeout 300 python bench.py --config C4 --steps 20 --no-cpu-baseline > $OUT/${TA
 timeout 300 python scripts/preprocess_bench.py 2> /dev/null | grep raw_points > $OUT/${TAG}_preprocess.jsonl
 timeout 300 python scripts/handles_bench.py 2> /dev/null | grep '"hands"' > $OUT/${TAG}_handles.jsonl
 timeout 300 python scripts/pipeline_bench.py 2> /dev/null | tail -1 > $OUT/${TAG}_pipeline.json
+# a stream of captures: agh_localize against agh_localize_begin / _stage / _end (the next upload under this capture's kernels)
+timeout 300 python scripts/micro/pipeline_overlap.py 40 2> /dev/null | grep '^{' > $OUT/${TAG}_pipeline_overlap.json
+# the axis-aligned scene of SURVEY 8d (K1c's exhaustive argmax) under the kernel trace
+rm -rf /tmp/kt_C2u
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_C2u -o kt -- python $R/scripts/micro/quick_bench.py C2u --steps 50 > /tmp/kt_C2u.log 2>&1)
+db=$(find /tmp/kt_C2u -name "*.db" | head -1)
+[ -n "$db" ] && python $R/scripts/rocpd_summary.py $db $OUT/${TAG}_c2u_kernel_trace_stats.csv > /dev/null
 # the one-call chain's kernel budget (agh_localize in a loop under rocprofv3 --kernel-trace)
 timeout 400 bash scripts/localize_trace.sh ${TAG}_localize > $OUT/${TAG}_localize_kernels_per_call.txt 2>&1
 cp $R/gpurun_out/${TAG}_localize_kernel_trace_stats.csv $OUT/ 2> /dev/null
