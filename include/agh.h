@@ -242,9 +242,11 @@ int agh_localize_device(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, 
  *   agh_localize_end(ctx, outputs)        the one synchronisation; cloud k's results, exactly agh_localize's
  *   agh_localize_begin(ctx, cloud k + 1)  recognises the staged capture (same pointer, stride and count): no upload
  * agh_localize(...) is begin + end.  One chain may be in flight (AGH_ERR_STATE for a second begin, or an end without a
- * begin); between begin and end only agh_localize_stage may be called on the context.  The buffers handed to begin and to stage
- * must stay valid and unchanged until the agh_localize_end of their chain (begin) / the agh_localize_begin that adopts them
- * (stage) has returned; sample_idx is copied by begin.  A staged capture that the next begin does not name is dropped. */
+ * begin); between begin and end only agh_localize_stage may be called on the context.  The capture handed to begin must stay valid
+ * and unchanged until the agh_localize_end of its chain has returned, the one handed to stage until the agh_localize_end of the
+ * chain that adopts it has (a pageable source has been read when agh_localize_stage returns; a pinned one is read asynchronously);
+ * sample_idx is copied by begin.  A staged capture that the next begin does not name is dropped (its copy may still be running:
+ * keep the source until the next agh_localize_end or agh_synchronize). */
 int agh_localize_begin(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n, const agh_localize_params* lp);
 int agh_localize_stage(agh_ctx* ctx, const float* xyz, int64_t stride_bytes, int64_t n);
 int agh_localize_end(agh_ctx* ctx, agh_handle* handles_out, int64_t handle_cap, int32_t* inlier_idx_out, int64_t idx_cap,
