@@ -20,6 +20,7 @@ constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (q
 constexpr int kSumStride = 40;     // doubles per sample in the sums buffer
 constexpr int kSlots = 8;          // hypothesis slots per sample = hand orientations (rotating_hand.cpp:13)
 constexpr int kImageWords = 250;   // 80x100 occupancy bitmap, one bit per pixel
+constexpr int kSweepWg4MinSamples = 4096;  // k_hand_sweep launches beyond this many samples run four work-groups per CU (hand_sweep.hip, WG4)
 constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
 
 // Uniform grid over the cloud's bounding box (stands in for the kd-tree of hand_search.cpp:10-11).

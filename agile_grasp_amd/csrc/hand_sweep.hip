@@ -164,14 +164,18 @@ __device__ __forceinline__ unsigned lowmask(int n)
 // for the training instances createInstance(h, cam_pos, cam = 0 / 1) (learning.cpp:389-397).
 // NT: threads of a work-group -- 256 (four waves, two orientations each, three work-groups per CU) or 512 (eight waves, an
 // orientation each, two work-groups per CU with a tile that holds every neighbourhood of the voxelised clouds in one piece).
-template <int MODE, int PX, int PY, int NT>
+// WG4: four work-groups per CU with a 1408-point tile instead of three with 2176 points -- for launches of many rounds of
+// work-groups (C4, a batch of clouds), where the fourth resident work-group is worth more than the tile (round 6, after the parking
+// of multi-tile neighbourhoods was gone: C4 228 -> 214 us; at C2's 2.6 rounds the two are equal, and round 5 -- with the parking --
+// had measured 97 against 73 us).
+template <int MODE, int PX, int PY, int NT, int WG4>
 #ifndef AGH_SWEEP_WGS
 #define AGH_SWEEP_WGS 3
 #endif
 #ifndef AGH_SWEEP_TILE
 #define AGH_SWEEP_TILE 2176
 #endif
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : (WG4 ? 4 : AGH_SWEEP_WGS)) void k_hand_sweep(GridView gv, const HandGeom* __restrict__ geom_p,
   const agh_frame* __restrict__ frames, const int32_t* __restrict__ samples, const int32_t* __restrict__ cam_source,
   int S, float r2f, double rpad, const double* __restrict__ normals, double img_cell,
   int32_t* __restrict__ status, agh_hypothesis* __restrict__ slots, uint32_t* __restrict__ images, int debug_stop, long long* __restrict__ dbg,
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : AGH_SWEEP_WGS) void k_hand_swee
   constexpr int NW = NT / 64, kOW = 8 / NW;  // waves; orientations a wave owns in the finger logic and the results
   constexpr int kImgPlanes = TRAIN ? 16 : 8;  // TRAIN: plane o = camera 0's points, plane 8 + o = camera 1's
   // the block must stay under a third of the CU's 160 KiB (512-B granules)
-  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : (NT == 512 ? 3712 : AGH_SWEEP_TILE));
+  constexpr int kTile = TRAIN ? 1280 : (NORMALS ? 1728 : (NT == 512 ? 3712 : (WG4 ? 1408 : AGH_SWEEP_TILE)));
+  static_assert(!WG4 || (MODE == 0 && NT == 256), "the four-per-CU form exists for the online variant only");
   __shared__ double2 pts[kTile];
   __shared__ unsigned pid[NORMALS ? kTile : 1];
   __shared__ RowTable rt;
@@ -1352,13 +1357,14 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
 #ifndef AGH_SWEEP_NT
 #define AGH_SWEEP_NT 256  // threads of the online variant's work-groups (512: eight waves, two per CU, one 3712-point tile -- measured, not faster)
 #endif
-#define AGH_LAUNCH_SWEEP_NT(N, PX, PY, NT)                                                                                  \
-  do                                                                                                                        \
-  {                                                                                                                         \
-    if (timed)                                                                                                              \
-      hipExtLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT>), dim3(Si), dim3(NT), 0, st, ev_start, ev_stop, 0, AGH_SWEEP_ARGS); \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT>), dim3(Si), dim3(NT), 0, st, AGH_SWEEP_ARGS);                           \
+#define AGH_LAUNCH_SWEEP_NT(N, PX, PY, NT) AGH_LAUNCH_SWEEP_W(N, PX, PY, NT, 0)
+#define AGH_LAUNCH_SWEEP_W(N, PX, PY, NT, W4)                                                                                    \
+  do                                                                                                                             \
+  {                                                                                                                              \
+    if (timed)                                                                                                                   \
+      hipExtLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT, W4>), dim3(Si), dim3(NT), 0, st, ev_start, ev_stop, 0, AGH_SWEEP_ARGS); \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_hand_sweep<N, PX, PY, NT, W4>), dim3(Si), dim3(NT), 0, st, AGH_SWEEP_ARGS);                           \
   } while (0)
   // (the variants with normals need more than the 128 registers that eight-wave work-groups, two per CU, leave a lane)
 #define AGH_LAUNCH_SWEEP(N, PX, PY) AGH_LAUNCH_SWEEP_NT(N, PX, PY, ((N) == 0 ? AGH_SWEEP_NT : 256))
@@ -1369,6 +1375,8 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
     AGH_LAUNCH_SWEEP(1, 2, 1);
   else if (nrm)
     AGH_LAUNCH_SWEEP(1, kLutProbe, kLutProbe);
+  else if (few && Si > kSweepWg4MinSamples && AGH_SWEEP_NT == 256)
+    AGH_LAUNCH_SWEEP_W(0, 2, 1, 256, 1);  // many rounds of work-groups: four per CU (see WG4)
   else if (few)
     AGH_LAUNCH_SWEEP(0, 2, 1);
   else
@@ -1376,6 +1384,7 @@ int hand_sweep(Ctx* c, const int32_t* d_samples, int64_t S, bool use_normals, hi
   c->last_has_cam_images = train;
 #undef AGH_LAUNCH_SWEEP
 #undef AGH_LAUNCH_SWEEP_NT
+#undef AGH_LAUNCH_SWEEP_W
 #undef AGH_SWEEP_ARGS
   timing_mark(c, "hand_sweep", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
