@@ -50,6 +50,16 @@ def main():
             if args.classify:
                 ctx.classify_torch(keep_t, stream=st)
 
+        # (two untimed steps first: a cloud that needs the larger capacity classes switches them on -- AGH_ERR_RETRY -- and the
+        # steps that follow run the context's final configuration; bench.py's settle)
+        for _ in range(2):
+            step()
+            torch.cuda.synchronize()
+            try:
+                ctx.synchronize()
+            except binding.AghError as e:
+                if e.code != binding.AGH_ERR_RETRY:
+                    raise
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.5:
             for _ in range(10):
