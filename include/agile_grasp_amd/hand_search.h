@@ -287,6 +287,17 @@ public:
     hands_out.clear();
     handles_out.clear();
     inliers_out.clear();
+    return localizeBegin(cloud_in, size_left, workspace, cell_size, indices, svm_filename, min_inliers, min_length) &&
+           localizeEnd(hands_out, handles_out, inliers_out);
+  }
+
+  /** The same chain as two calls (agh_localize_begin / agh_localize_end), for a caller that holds the NEXT capture while this
+   *  one is searched: between the two, localizeStage(next) uploads it on a second stream under this capture's kernels, and the
+   *  localizeBegin that is later handed the same cloud object finds it on the device.  One chain may be in flight; `cloud_in`
+   *  must stay alive and unchanged until localizeEnd has returned. */
+  bool localizeBegin(const PointCloud::Ptr& cloud_in, int size_left, const VectorXd& workspace, double cell_size,
+    const std::vector<int>& indices, const std::string& svm_filename, int min_inliers, double min_length)
+  {
     if (!ensureContext())
       return false;
     if (agh_load_svm_file(ctx_, svm_filename.c_str()) != AGH_OK)
@@ -301,23 +312,53 @@ public:
     for (int i = 0; i < 6; i++)
       lp.workspace[i] = workspace(i);
     lp.cell_size = cell_size;
-    std::vector<std::int32_t> idx(indices.begin(), indices.end());
+    std::vector<std::int32_t> idx(indices.begin(), indices.end());  // (copied by agh_localize_begin)
     lp.sample_idx = idx.empty() ? nullptr : idx.data();
     lp.n_samples = idx.empty() ? (std::int64_t) (num_samples_ < 0 ? 0 : num_samples_) : (std::int64_t) idx.size();
     lp.sample_seed = sample_seed_set_ ? (std::uint64_t) sample_seed_ : (std::uint64_t) std::time(nullptr);
     lp.min_inliers = min_inliers;
     lp.reserved = 0;
     lp.min_length = min_length;
-    const std::int64_t cap = lp.n_samples * 8 < 8192 ? lp.n_samples * 8 + 1 : 8193;
+    loc_cap_ = lp.n_samples * 8 < 8192 ? lp.n_samples * 8 + 1 : 8193;
+    last_samples_.assign((std::size_t) lp.n_samples, 0);
+    const std::int64_t n = (std::int64_t) cloud_in->size();
+    if (agh_localize_begin(ctx_, n > 0 ? &cloud_in->points[0].x : nullptr, (std::int64_t) sizeof(cloud_in->points[0]), n, &lp) != AGH_OK)
+    {
+      fail("agh_localize_begin");
+      return false;
+    }
+    return true;
+  }
+
+  /** agh_localize_stage: the NEXT capture up, beside the chain in flight (keep `next` alive and unchanged until the
+   *  localizeEnd of the chain that searches it has returned). */
+  bool localizeStage(const PointCloud::Ptr& next)
+  {
+    if (!ensureContext() || !next)
+      return false;
+    const std::int64_t n = (std::int64_t) next->size();
+    if (agh_localize_stage(ctx_, n > 0 ? &next->points[0].x : nullptr, (std::int64_t) sizeof(next->points[0]), n) != AGH_OK)
+    {
+      fail("agh_localize_stage");
+      return false;
+    }
+    return true;
+  }
+
+  bool localizeEnd(std::vector<agh_hypothesis>& hands_out, std::vector<agh_handle>& handles_out, std::vector<std::int32_t>& inliers_out)
+  {
+    hands_out.clear();
+    handles_out.clear();
+    inliers_out.clear();
+    if (!ctx_)
+      return false;
+    const std::int64_t cap = loc_cap_;
     hands_out.resize((std::size_t) cap);
     handles_out.resize((std::size_t) cap);
     inliers_out.resize((std::size_t) cap);
-    last_samples_.assign((std::size_t) lp.n_samples, 0);
     agh_localize_result res;
-    const std::int64_t n = (std::int64_t) cloud_in->size();
-    const int rc = agh_localize(ctx_, n > 0 ? &cloud_in->points[0].x : nullptr, (std::int64_t) sizeof(cloud_in->points[0]), n, &lp,
-      handles_out.data(), cap, inliers_out.data(), cap, hands_out.data(), cap, last_samples_.empty() ? nullptr : last_samples_.data(),
-      &res);
+    const int rc = agh_localize_end(ctx_, handles_out.data(), cap, inliers_out.data(), cap, hands_out.data(), cap,
+      last_samples_.empty() ? nullptr : last_samples_.data(), &res);
     if (rc != AGH_OK)
     {
       hands_out.clear();
@@ -452,6 +493,7 @@ private:
 
   agh_ctx* ctx_;
   std::int64_t searched_n_ = 0;
+  std::int64_t loc_cap_ = 1;  // room for the results of the chain localizeBegin queued
   agh_params params_;
   Matrix4d cam_tf_left_, cam_tf_right_;
   int num_threads_, num_samples_;

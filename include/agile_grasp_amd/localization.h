@@ -216,33 +216,85 @@ public:
   std::vector<Handle> localizeHandles(const PointCloud::Ptr& cloud_in, int size_left, const std::vector<int>& indices,
     const std::string& svm_filename, int min_inliers, double min_length, std::vector<GraspHypothesis>* antipodal_hands = nullptr)
   {
-    std::vector<Handle> handle_list;
     if (antipodal_hands)
       antipodal_hands->clear();
-    if (filters_boundaries_)
+    if (!localizeHandlesBegin(cloud_in, size_left, indices, svm_filename, min_inliers, min_length))
+      return std::vector<Handle>();
+    return localizeHandlesEnd(antipodal_hands);
+  }
+
+  /** Additional: the same chain for a node that already holds the NEXT capture while this one is searched
+   *  (GraspLocalizer::cloud_callback queues clouds, grasp_localizer.cpp:55-75):
+   *      loc.localizeHandlesBegin(cloud_k, size_left, indices, svm, min_inliers, 0.005);   // queued, not waited for
+   *      loc.stageNextCloud(cloud_k1);                                                     // its upload runs under cloud k's kernels
+   *      handles = loc.localizeHandlesEnd(&antipodal_hands);                               // the one synchronisation
+   *      loc.localizeHandlesBegin(cloud_k1, ...);                                          // finds cloud k + 1 on the device
+   *  Same results as localizeHandles.  The clouds must stay alive and unchanged until the localizeHandlesEnd of their chain
+   *  has returned (which then filters NaNs out of the searched cloud in place, as localization.cpp:27 does). */
+  bool localizeHandlesBegin(const PointCloud::Ptr& cloud_in, int size_left, const std::vector<int>& indices,
+    const std::string& svm_filename, int min_inliers, double min_length)
+  {
+    pending_cloud_ = PointCloud::Ptr();
+    pending_three_calls_ = false;
+    if (filters_boundaries_)  // (a host-side filter between the search and the classifier: the three calls, at End)
     {
-      std::vector<GraspHypothesis> kept = predictAntipodalHands(localizeHands(cloud_in, size_left, indices, false, false), svm_filename);
-      if (antipodal_hands)
-        *antipodal_hands = kept;
-      return findHandles(kept, min_inliers, min_length);
+      pending_cloud_ = cloud_in;
+      pending_three_calls_ = true;
+      pending_size_left_ = size_left;
+      pending_indices_ = indices;
+      pending_svm_ = svm_filename;
+      pending_min_inliers_ = min_inliers;
+      pending_min_length_ = min_length;
+      return true;
     }
     if (size_left == 0 || !cloud_in || cloud_in->size() == 0)
     {
       std::cout << "Input cloud is empty!\n";
       std::cout << size_left << std::endl;
-      return handle_list;
+      return false;
     }
     std::ifstream f(svm_filename.c_str());
     if (!f.good())
     {
       std::cout << " Error: File " << svm_filename << " does not exist!\n";  // learning.cpp:172-178
-      return handle_list;
+      return false;
     }
     ensureSearch();
+    if (!search_->localizeBegin(cloud_in, size_left, workspace_, 0.003, indices, svm_filename, min_inliers, min_length))
+      return false;
+    pending_cloud_ = cloud_in;
+    return true;
+  }
+
+  /** agh_localize_stage through the adapter: the next capture up, beside the chain in flight */
+  bool stageNextCloud(const PointCloud::Ptr& next)
+  {
+    if (filters_boundaries_ || !next || next->size() == 0)
+      return false;
+    ensureSearch();
+    return search_->localizeStage(next);
+  }
+
+  std::vector<Handle> localizeHandlesEnd(std::vector<GraspHypothesis>* antipodal_hands = nullptr)
+  {
+    std::vector<Handle> handle_list;
+    if (antipodal_hands)
+      antipodal_hands->clear();
+    if (!pending_cloud_)
+      return handle_list;
+    PointCloud::Ptr cloud_in = pending_cloud_;
+    pending_cloud_ = PointCloud::Ptr();
+    if (pending_three_calls_)
+    {
+      std::vector<GraspHypothesis> kept = predictAntipodalHands(localizeHands(cloud_in, pending_size_left_, pending_indices_, false, false), pending_svm_);
+      if (antipodal_hands)
+        *antipodal_hands = kept;
+      return findHandles(kept, pending_min_inliers_, pending_min_length_);
+    }
     std::vector<agh_hypothesis> hands;
     std::vector<agh_handle> handles;
     std::vector<std::int32_t> idx;
-    if (!search_->localize(cloud_in, size_left, workspace_, 0.003, indices, svm_filename, min_inliers, min_length, hands, handles, idx))
+    if (!search_->localizeEnd(hands, handles, idx))
       return handle_list;
     remove_nan_in_place(*cloud_in);  // localization.cpp:27 filters the caller's cloud in place
     std::shared_ptr<std::vector<GraspHypothesis> > kept(new std::vector<GraspHypothesis>());
@@ -328,6 +380,13 @@ private:
   bool deterministic_;
   int device_;
   bool keeps_training_images_ = false;
+  // localizeHandlesBegin -> localizeHandlesEnd
+  PointCloud::Ptr pending_cloud_;
+  bool pending_three_calls_ = false;
+  int pending_size_left_ = 0, pending_min_inliers_ = 0;
+  double pending_min_length_ = 0.0;
+  std::vector<int> pending_indices_;
+  std::string pending_svm_;
   std::unique_ptr<HandSearch> search_;
   PointCloud::Ptr last_cloud_;
   VectorXi last_cam_;

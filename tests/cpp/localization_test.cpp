@@ -93,6 +93,38 @@ int main(int argc, char** argv)
     }
     return 0;
   }
+  if (std::strcmp(argv[3], "stream") == 0)
+  {
+    // a node that holds the next capture while this one is searched: localizeHandlesBegin / stageNextCloud / localizeHandlesEnd
+    // over three captures (copies of the cloud: distinct objects) against localizeHandles on the first
+    PointCloud::Ptr clouds[3];
+    for (int k = 0; k < 3; k++)
+      clouds[k] = PointCloud::Ptr(new PointCloud(*cloud));
+    std::vector<GraspHypothesis> kept1;
+    PointCloud::Ptr ref_cloud(new PointCloud(*cloud));
+    std::vector<Handle> handles1 = loc.localizeHandles(ref_cloud, (int) size_left, idx, argv[2], 2, 0.005, &kept1);
+    std::printf("CHAIN1 %zu %zu\n", kept1.size(), handles1.size());
+    if (!loc.localizeHandlesBegin(clouds[0], (int) size_left, idx, argv[2], 2, 0.005))
+      return 3;
+    for (int k = 0; k < 3; k++)
+    {
+      if (k + 1 < 3 && !loc.stageNextCloud(clouds[k + 1]))
+        return 4;
+      std::vector<GraspHypothesis> kept;
+      std::vector<Handle> handles = loc.localizeHandlesEnd(&kept);
+      if (k + 1 < 3 && !loc.localizeHandlesBegin(clouds[k + 1], (int) size_left, idx, argv[2], 2, 0.005))
+        return 5;
+      bool same = kept.size() == kept1.size() && handles.size() == handles1.size();
+      for (size_t i = 0; same && i < kept.size(); i++)
+        same = kept[i].getGraspSurface()(0) == kept1[i].getGraspSurface()(0) && kept[i].getGraspBottom()(1) == kept1[i].getGraspBottom()(1) &&
+               kept[i].getGraspWidth() == kept1[i].getGraspWidth();
+      for (size_t i = 0; same && i < handles.size(); i++)
+        same = handles[i].getInliers() == handles1[i].getInliers() && handles[i].getAxis()(0) == handles1[i].getAxis()(0) &&
+               handles[i].getCenter()(1) == handles1[i].getCenter()(1) && handles[i].getWidth() == handles1[i].getWidth();
+      std::printf("STREAM %d %zu %zu %d\n", k, kept.size(), handles.size(), same ? 1 : 0);
+    }
+    return 0;
+  }
   const bool antipodal = std::strcmp(argv[3], "antipodal") == 0;  // calculates_antipodal (antipodal_test.cpp:61)
   std::vector<GraspHypothesis> hands = loc.localizeHands(cloud, (int) size_left, idx, antipodal, false);
   if (antipodal)

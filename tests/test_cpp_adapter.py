@@ -246,6 +246,27 @@ def test_localization_one_call_chain_equals_the_three_calls(tmp_path):
 
 
 @pytest.mark.gpu
+def test_localization_stream_with_staged_uploads_equals_the_one_call(tmp_path):
+    """Localization::localizeHandlesBegin / stageNextCloud / localizeHandlesEnd over three captures (agh_localize_begin / _stage /
+    _end: the next capture's upload under this one's kernels) return what localizeHandles returns, capture by capture."""
+    exe = _build_loc(tmp_path)
+    xyz, size_left, ws, cams = _raw_cloud()
+    vox, vcam = _preprocess_numpy(xyz, size_left, ws)
+    idx = np.sort(np.random.default_rng(1).permutation(len(vox))[:300]).astype(np.int32)
+    path = str(tmp_path / "raw.bin")
+    _dump_raw(path, xyz, size_left, idx, ws, cams)
+    out = subprocess.run([exe, path, os.path.join(GOLD, "svm_032015_linear_20_20_same"), "stream"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    c1 = [l.split()[1:] for l in lines if l.startswith("CHAIN1")][0]
+    st = [l.split()[1:] for l in lines if l.startswith("STREAM")]
+    assert int(c1[0]) > 0 and len(st) == 3
+    for k, r in enumerate(st):
+        assert r == [str(k), c1[0], c1[1], "1"], (r, c1)
+
+
+@pytest.mark.gpu
 def test_localization_facade_antipodal_labels(tmp_path):
     """src/tests/antipodal_test.cpp: localizeHands with calculates_antipodal = true (all-points normals pass + 20 degree
     antipodal test); the half / full labels must be the ones the C ABI gives for the same voxelised cloud."""
