@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = ["voxelize.hip", "grid.hip", "taubin.hip", "hand_sweep.hip", "hog_svm.hip", "handles.hip", "train.hip", "points.hip", "shard.hip", "api.hip"]
+SRC = ["voxelize.hip", "grid.hip", "taubin.hip", "hand_sweep.hip", "hog_svm.hip", "handles.hip", "train.hip", "points.hip", "shard.hip", "localize.hip", "api.hip"]
 LIB = os.path.join(HERE, "lib", "libagile_grasp_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
          "-fno-gpu-rdc"]

@@ -439,6 +439,25 @@ bool timing_launch_events(Ctx* c, const char* name, hipEvent_t* start, hipEvent_
 void timing_begin(Ctx* c, hipStream_t st);
 int32_t next_epoch();
 int ensure_call_buffers(Ctx* c, int64_t S);
+int ensure_host_staging(Ctx* c, int64_t samples, int64_t records);
+constexpr int64_t kPinHeaderBytes = 256;  // pinned staging of the host-buffer entry points: [header | sample indices | records]
+// (re)allocation of one of the context's device buffers
+template <typename T>
+inline int dev_alloc(Ctx* c, T** p, size_t count)
+{
+  if (*p)
+  {
+    (void) hipFree(*p);
+    *p = nullptr;
+  }
+  const hipError_t e = hipMalloc((void**) p, (count > 0 ? count : 1) * sizeof(T));
+  if (e != hipSuccess)
+  {
+    c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return AGH_ERR_HIP;
+  }
+  return AGH_OK;
+}
 int ensure_clouds(Ctx* c, int C);
 int ensure_draws(Ctx* c, int64_t count, hipStream_t st);
 int normals_pass(Ctx* c, int64_t p0, int64_t p1, hipStream_t st);
@@ -861,3 +880,10 @@ struct agh_ctx
 {
   agh::Ctx c;
 };
+
+// api.hip's stages as localize.hip queues them
+int preprocess_device_impl(agh_ctx* ctx, const float* d_xyz, int64_t stride_bytes, int64_t n, int64_t size_left, int dense,
+  const double workspace[6], double cell_size, int64_t* n_voxels_out, void* hip_stream, bool defer_count, bool* deferred);
+bool handle_thresholds(double* x1, double* x2);
+int ensure_handle_buffers(agh::Ctx* c, int64_t n_hands);
+int flags_to_status(agh::Ctx* c, const int32_t* flags);
