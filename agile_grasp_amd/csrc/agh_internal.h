@@ -20,6 +20,7 @@ constexpr int kNumSums = 37;       // distinct sequential sums behind M and N (q
 constexpr int kSumStride = 40;     // doubles per sample in the sums buffer
 constexpr int kSlots = 8;          // hypothesis slots per sample = hand orientations (rotating_hand.cpp:13)
 constexpr int kImageWords = 250;   // 80x100 occupancy bitmap, one bit per pixel
+constexpr int kBigListGrid = 512;  // work-groups of the 4096-class Taubin launches, which walk the list of the samples beyond 1152 neighbours
 constexpr int kSweepWg4MinSamples = 4096;  // k_hand_sweep launches beyond this many samples run four work-groups per CU (hand_sweep.hip, WG4)
 constexpr int64_t kNormalsChunk = 16384;  // points per batch of the all-points normals pass
 
@@ -252,6 +253,7 @@ struct Ctx
   int32_t* d_samples = nullptr;
   double* d_sums = nullptr;        // s_cap * kSumStride
   int32_t* d_nt = nullptr;         // n_taubin
+  int32_t* d_ovf = nullptr;        // {count, samples...}: the samples k_taubin_moments<1152> hands on to the 4096 class (s_cap + 16)
   int32_t* d_nh = nullptr;         // n_hands
   int32_t* d_status = nullptr;
   int* d_weight = nullptr;         // candidate count of each sample's hand-search ball (scheduling weight)

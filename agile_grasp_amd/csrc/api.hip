@@ -209,7 +209,7 @@ int ensure_call_buffers(Ctx* c, int64_t S)
     return rc;
   if ((rc = dev_alloc(c, &c->d_sums, cap * kSumStride)))
     return rc;
-  if ((rc = dev_alloc(c, &c->d_nt, cap)))
+  if ((rc = dev_alloc(c, &c->d_nt, cap)) || (rc = dev_alloc(c, &c->d_ovf, cap + 16)))
     return rc;
   if ((rc = dev_alloc(c, &c->d_nh, cap)) || (rc = dev_alloc(c, &c->d_scloud, cap)))
     return rc;
@@ -515,7 +515,7 @@ void agh_destroy(agh_ctx* ctx)
     c->d_images, c->d_slot_index, c->d_scan_tmp, c->d_out_own, c->d_nout, c->d_out_images, c->d_draw_ofs, c->d_draws,
     c->d_flags, c->d_normals, c->d_svm_w, c->d_hog, c->d_geom, c->d_desc_out, c->d_svm_sums, c->d_keep, c->d_vox_desc,
     c->d_weight, c->d_order, c->d_order_sweep, c->d_vmask, c->d_cloud_off, c->d_scloud, c->d_idx_own, c->d_tile_state, c->d_h_hands, c->d_h_bits, c->d_h_rowcnt, c->d_h_first,
-    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count, c->d_huge_sorted, c->d_huge_normals, c->d_huge_base, c->d_stage_xyz };
+    c->d_h_n, c->d_h_idx, c->d_h_counts, c->d_h_handles, c->d_h_tmp, c->d_images_cam, c->d_xbuf, c->d_nbuf, c->d_xcnt, c->d_cls_images, c->d_cls_keep, c->d_cls_sums, c->d_dbg, c->d_svm_svT, c->d_svm_alpha, c->d_cls_desc, c->d_cls_kbuf, c->d_vox_code, c->d_vox_blk, c->d_vox_blk2, c->d_vox_total, c->d_vox_bitmap, c->d_vox_xyz, c->d_vox_cam, c->d_raw_xyz, c->d_huge_stage, c->d_huge_key, c->d_huge_count, c->d_huge_sorted, c->d_huge_normals, c->d_huge_base, c->d_stage_xyz, c->d_ovf };
   for (void* p : ptrs)
     if (p)
       (void) hipFree(p);

@@ -45,8 +45,13 @@ template <int CAP>
 __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
-  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud, long long* __restrict__ dbg)
+  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud, long long* __restrict__ dbg,
+  int32_t* __restrict__ ovf_out, const int32_t* __restrict__ ovf_list)
 {
+  // ovf_out (the 1152 class): the samples it hands on -- more than 1152 neighbours -- are LISTED ({count, samples...}), and the
+  // 4096 class (ovf_list) is launched as a few hundred work-groups that walk that list instead of one work-group per sample of
+  // which nearly all return at once.  At 100 KB of LDS a CU holds one such work-group, so the 16 000 empty ones of a batch of
+  // eight clouds (37 listed samples) were 50 us of the launch, and as many again in k_taubin_frame (round 6).
 #ifdef AGH_DEBUG_HOOKS  // scripts/moments_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=moments)
 #define AGH_MSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[(int64_t) blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
   long long mt_prod = 0, mt_cons = 0, mt_wait = 0, mt_last = 0;
@@ -74,10 +79,11 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   int* fillc = hist + (kSortBins + 1);
   double* termbuf = reinterpret_cast<double*>(scratch);
 
-  const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (zero_flags && blockIdx.x == 0 && tid < 8)
     zero_flags[tid] = 0;  // first kernel of an agh_find_hands call: the flags are only set by later kernels
+  // one sample per work-group (s = blockIdx.x), or the listed samples blockIdx.x, blockIdx.x + gridDim.x, ...
+  auto body = [&](const int s) {
   if (!first_class && status[s] != kStatusOverflow)
     return;  // an earlier (smaller) capacity class already handled this sample
   // (n_points < 0: the host only knows a bound -- agh_localize, whose cloud is still being voxelised when this launch is queued --
@@ -200,6 +206,8 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     {
       status[s] = kStatusOverflow;
       nt[s] = n;
+      if (ovf_out)
+        ovf_out[1 + atomicAdd(&ovf_out[0], 1)] = s;
     }
     return;
   }
@@ -421,6 +429,19 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     dbg[(int64_t) blockIdx.x * 8 + 7] = mt_wait;
   }
 #endif
+  };  // body
+  if constexpr (CAP == 4096)  // (only this instantiation carries the loop: in the others it cost registers they do not have)
+  {
+    const int n_items = ovf_list ? min(ovf_list[0], S) : S;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x)
+    {
+      body(ovf_list ? ovf_list[1 + it] : it);
+      if (it + (int) gridDim.x < n_items)
+        __syncthreads();  // (the next sample reuses the tiles)
+    }
+  }
+  else
+    body((int) blockIdx.x);
 #undef AGH_MSTAMP
 #undef AGH_MLAP
 }
@@ -884,8 +905,10 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
   const int32_t* __restrict__ draw_ofs, const int32_t* __restrict__ draws, double cam0x, double cam0y, double cam0z,
   double cam1x, double cam1y, double cam1z, agh_frame* __restrict__ frames, double* __restrict__ normals_out, int nmin, int debug_stop,
   const int* __restrict__ order, long long* __restrict__ dbg, const float4* __restrict__ pool_sorted,
-  const long long* __restrict__ huge_base)
+  const long long* __restrict__ huge_base, const int32_t* __restrict__ ovf_list)
 {
+  // (ovf_list: the 4096 class walks the list of the samples beyond 1152 neighbours that k_taubin_moments<1152> made, a few hundred
+  // work-groups instead of one per sample -- see there)
 #ifdef AGH_DEBUG_HOOKS  // scripts/frame_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=frame)
 #define AGH_FSTAMP(i, t) do { if (dbg && threadIdx.x == (t)) dbg[(int64_t) (order ? order[blockIdx.x] : (int) blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -912,8 +935,8 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     pad_[blockIdx.x % (AGH_FRAME_PAD / 4)] = 1;
 #endif
 
-  const int s = order ? order[blockIdx.x] : (int) blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto body = [&](const int s) {
   const int n = nt[s];
   const double* ev = eig + (int64_t) s * 12;
   const bool ok = status[s] == kStatusOk && ev[11] != 0.0;
@@ -1498,6 +1521,19 @@ __global__ __launch_bounds__(THREADS, (CAP == 1152 && THREADS == 256) ? 5 : ((CA
     }
     AGH_FSTAMP(7, 0);
   }
+  };  // body
+  if constexpr (CAP == 4096)  // (only this instantiation carries the loop: in the others it cost registers they do not have)
+  {
+    const int n_items = ovf_list ? min(ovf_list[0], S) : S;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x)
+    {
+      body(ovf_list ? ovf_list[1 + it] : (order ? order[it] : it));
+      if (it + (int) gridDim.x < n_items)
+        __syncthreads();  // (the next sample reuses the tiles)
+    }
+  }
+  else
+    body(order ? order[blockIdx.x] : (int) blockIdx.x);
 #undef AGH_FSTAMP
 }
 
@@ -1744,11 +1780,16 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   bool first = true;
   int32_t* zf = c->zero_flags_pending ? c->d_flags : nullptr;
   c->zero_flags_pending = false;
+  // (the samples the 1152 class hands on are listed for the 4096 class: see k_taubin_moments)
+  int32_t* const ovf = (c->big_classes && c->d_ovf) ? c->d_ovf : nullptr;
+  const int big_grid = std::min(Si, kBigListGrid);
+  if (ovf && hipMemsetAsync(ovf, 0, sizeof(int32_t), st) != hipSuccess)
+    return AGH_ERR_HIP;
   if (small_first)
   {
     hipLaunchKernelGGL(k_taubin_moments<256>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 1, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
-      zf, c->d_scloud, moments_dbg);
+      zf, c->d_scloud, moments_dbg, (int32_t*) nullptr, (const int32_t*) nullptr);
     zf = nullptr;
     first = false;
   }
@@ -1758,11 +1799,11 @@ int taubin_moments_eigen(Ctx* c, const int32_t* d_samples, int64_t S, double rad
   if (first || c->big_classes)
     hipLaunchKernelGGL(k_taubin_moments<1152>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, first ? 1 : 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
-      zf, c->d_scloud, moments_dbg);
+      zf, c->d_scloud, moments_dbg, ovf, (const int32_t*) nullptr);
   if (c->big_classes)
-    hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
+    hipLaunchKernelGGL(k_taubin_moments<4096>, dim3(ovf ? big_grid : Si), dim3(256), 0, st, gv, c->d_xyz, c->stride_floats, d_samples, Si,
       r2f, rpad, 0, c->d_sums, d_nt, c->d_status, c->d_nbr, c->nbr_stride, c->debug_stop_moments, c->n_is_bound ? -1 : (int) c->n,
-      (int32_t*) nullptr, c->d_scloud, (long long*) nullptr);
+      (int32_t*) nullptr, c->d_scloud, (long long*) nullptr, (int32_t*) nullptr, (const int32_t*) ovf);
   if (c->huge_classes && c->d_huge_stage)
   {
     // (one slot of the pool per flagged sample, handed out by the kernel; the counter starts every launch at zero)
@@ -1830,12 +1871,13 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
 #endif
   // the longest-first order k_taubin_eigen's sorter made for exactly this launch (same sample list, same count), else sample order
   const int* frame_order = (c->order_frame_s == Si && c->order_frame_samples == d_samples) ? (const int*) c->d_order : nullptr;
-#define AGH_LAUNCH_FRAME(CAP, THREADS, NMIN)                                                                            \
-  hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(Si), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,      \
+#define AGH_LAUNCH_FRAME(CAP, THREADS, NMIN) AGH_LAUNCH_FRAME_L(CAP, THREADS, NMIN, Si, (const int32_t*) nullptr)
+#define AGH_LAUNCH_FRAME_L(CAP, THREADS, NMIN, GRID, LIST)                                                              \
+  hipLaunchKernelGGL((k_taubin_frame<CAP, THREADS>), dim3(GRID), dim3(THREADS), 0, st, c->d_nbr, c->nbr_stride, d_nt,    \
     c->d_eig, c->d_status, c->d_xyz, c->stride_floats, d_samples, Si, rand_mode, c->d_draw_ofs, c->d_draws, co[0], co[1], \
     co[2], co[3], co[4], co[5], d_frames, write_normals ? c->d_normals : nullptr, NMIN, c->debug_stop_frame,           \
     frame_order, frame_dbg, (const float4*) c->d_huge_sorted,                                                          \
-    (const long long*) (c->huge_classes ? c->d_huge_base : nullptr))
+    (const long long*) (c->huge_classes ? c->d_huge_base : nullptr), LIST)
   if (small_class)
     AGH_LAUNCH_FRAME(128, 64, 0);
   if (rand_mode && !small_class)
@@ -1852,7 +1894,9 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
       AGH_LAUNCH_FRAME(1152, 256, 128);
     else
       AGH_LAUNCH_FRAME(1152, 256, 0);
-    if (c->big_classes)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set)
+    if (c->big_classes && c->d_ovf)  // (n_t > 1152 needs K1a's 4096 class, which only runs with this set: the samples it listed)
+      AGH_LAUNCH_FRAME_L(4096, 256, 1152, std::min(Si, kBigListGrid), (const int32_t*) c->d_ovf);
+    else if (c->big_classes)
       AGH_LAUNCH_FRAME(4096, 256, 1152);
     if (c->huge_classes)  // (its 24 bytes of LDS per normal still fit: 147 KB)
     {
@@ -1864,6 +1908,7 @@ int taubin_frame_stage(Ctx* c, const int32_t* d_samples, int64_t S, double radiu
     }
   }
 #undef AGH_LAUNCH_FRAME
+#undef AGH_LAUNCH_FRAME_L
   timing_mark(c, "taubin_frame", st);
   return hipGetLastError() == hipSuccess ? AGH_OK : AGH_ERR_HIP;
 }
