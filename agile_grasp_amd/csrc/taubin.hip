@@ -41,17 +41,14 @@ constexpr int kChunk = 56;      // neighbours per summation chunk (56 x 37 doubl
 // Capacity classes: 1152 neighbours is what a two-view cloud voxelised at the reference's 3 mm holds in a 3 cm ball at most
 // (C2 / C4 / C5: median 560, 99th percentile 980, maximum 1132), and it is the largest class whose 38.4 KB of LDS and 128
 // VGPRs leave room for FOUR work-groups per CU (the 1536 class it replaces ran three); denser clouds fall through to 4096.
+// (the work of one sample: the kernel below calls it once -- or, in the 4096 class, for every sample of a list)
 template <int CAP>
-__global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
+__device__ __forceinline__ void taubin_moments_sample(const int s, GridView gv, const float* __restrict__ xyz, int64_t stride,
   const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
   int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
   int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud, long long* __restrict__ dbg,
-  int32_t* __restrict__ ovf_out, const int32_t* __restrict__ ovf_list)
+  int32_t* __restrict__ ovf_out)
 {
-  // ovf_out (the 1152 class): the samples it hands on -- more than 1152 neighbours -- are LISTED ({count, samples...}), and the
-  // 4096 class (ovf_list) is launched as a few hundred work-groups that walk that list instead of one work-group per sample of
-  // which nearly all return at once.  At 100 KB of LDS a CU holds one such work-group, so the 16 000 empty ones of a batch of
-  // eight clouds (37 listed samples) were 50 us of the launch, and as many again in k_taubin_frame (round 6).
 #ifdef AGH_DEBUG_HOOKS  // scripts/moments_clocks.py: per-work-group phase timestamps (AGH_DEBUG_CLOCKS_KERNEL=moments)
 #define AGH_MSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[(int64_t) blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
   long long mt_prod = 0, mt_cons = 0, mt_wait = 0, mt_last = 0;
@@ -82,8 +79,6 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (zero_flags && blockIdx.x == 0 && tid < 8)
     zero_flags[tid] = 0;  // first kernel of an agh_find_hands call: the flags are only set by later kernels
-  // one sample per work-group (s = blockIdx.x), or the listed samples blockIdx.x, blockIdx.x + gridDim.x, ...
-  auto body = [&](const int s) {
   if (!first_class && status[s] != kStatusOverflow)
     return;  // an earlier (smaller) capacity class already handled this sample
   // (n_points < 0: the host only knows a bound -- agh_localize, whose cloud is still being voxelised when this launch is queued --
@@ -429,21 +424,35 @@ __global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(Gri
     dbg[(int64_t) blockIdx.x * 8 + 7] = mt_wait;
   }
 #endif
-  };  // body
+#undef AGH_MSTAMP
+#undef AGH_MLAP
+}
+
+// ovf_out (the 1152 class): the samples it hands on -- more than 1152 neighbours -- are LISTED ({count, samples...}), and the
+// 4096 class (ovf_list) is launched as a few hundred work-groups that walk that list instead of one work-group per sample of
+// which nearly all return at once.  At 100 KB of LDS a CU holds one such work-group, so the 16 000 empty ones of a batch of
+// eight clouds (37 listed samples) were 50 us of the launch, and as many again in k_taubin_frame (round 6).
+template <int CAP>
+__global__ __launch_bounds__(256, CAP <= 1152 ? 4 : 1) void k_taubin_moments(GridView gv, const float* __restrict__ xyz, int64_t stride,
+  const int32_t* __restrict__ samples, int S, float r2f, double rpad, int first_class, double* __restrict__ sums,
+  int32_t* __restrict__ nt, int32_t* __restrict__ status, float4* __restrict__ nbr, int64_t nbr_stride, int debug_stop,
+  int n_points, int32_t* __restrict__ zero_flags, int32_t* __restrict__ scloud, long long* __restrict__ dbg,
+  int32_t* __restrict__ ovf_out, const int32_t* __restrict__ ovf_list)
+{
   if constexpr (CAP == 4096)  // (only this instantiation carries the loop: in the others it cost registers they do not have)
   {
     const int n_items = ovf_list ? min(ovf_list[0], S) : S;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x)
     {
-      body(ovf_list ? ovf_list[1 + it] : it);
+      taubin_moments_sample<CAP>(ovf_list ? ovf_list[1 + it] : it, gv, xyz, stride, samples, S, r2f, rpad, first_class, sums, nt, status,
+        nbr, nbr_stride, debug_stop, n_points, zero_flags, scloud, dbg, ovf_out);
       if (it + (int) gridDim.x < n_items)
         __syncthreads();  // (the next sample reuses the tiles)
     }
   }
   else
-    body((int) blockIdx.x);
-#undef AGH_MSTAMP
-#undef AGH_MLAP
+    taubin_moments_sample<CAP>((int) blockIdx.x, gv, xyz, stride, samples, S, r2f, rpad, first_class, sums, nt, status, nbr, nbr_stride,
+      debug_stop, n_points, zero_flags, scloud, dbg, ovf_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
