@@ -402,15 +402,7 @@ int grid_build(Ctx* c, hipStream_t st)
   hipLaunchKernelGGL(k_bbox, dim3(nparts, C), dim3(kBboxThreads), 0, st, c->d_xyz, c->stride_floats,
     (const int*) c->d_cloud_off, c->d_bbox_part);
   // (also for an empty cloud: one work-group writes the descriptor of an empty grid)
-  // (every work-group of k_cell_count first reduces k_bbox's slots for itself: in a batch of clouds, where the launch is several
-  // rounds of work-groups, fewer of them with more points each)
-  int nblk_count = nblk;
-  {
-    static const int cap_total = [] { const char* e = std::getenv("AGH_CELLCOUNT_WGS"); return e ? std::atoi(e) : 0; }();
-    if (cap_total > 0 && C > 1)
-      nblk_count = std::max(1, std::min(nblk, std::max(256, cap_total / C)));
-  }
-  hipLaunchKernelGGL(k_cell_count, dim3(nblk_count, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
+  hipLaunchKernelGGL(k_cell_count, dim3(nblk, C), dim3(256), 0, st, c->d_xyz, c->stride_floats, (const int*) c->d_cloud_off,
     c->d_desc, c->d_cell_of, c->d_rank_of, c->d_cell_count, (const float*) c->d_bbox_part, nparts, base_cell);
   hipLaunchKernelGGL(k_cell_scan, dim3(C == 1 ? 256 : 64, C), dim3(256), 0, st, c->d_cell_count, c->d_desc, c->d_tile_state,
     c->build_gen, c->d_cell_start, (const int*) c->d_cloud_off);
