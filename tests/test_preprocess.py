@@ -239,11 +239,12 @@ def test_localize_edge_cases(svm_model):
 
 
 @pytest.mark.gpu
-def test_localize_begin_stage_end_equals_the_one_call(svm_model):
+@pytest.mark.parametrize("pinned", [False, True])
+def test_localize_begin_stage_end_equals_the_one_call(svm_model, pinned):
     """the chain as agh_localize_begin / agh_localize_end with the NEXT capture staged in between
     (agh_localize_stage: a second raw buffer, a second stream, under the kernels of the chain in flight).  A stream of captures of
     different sizes through the split calls equals the same stream through agh_localize, every field; a staged capture that the
-    next begin does not name is dropped; the state errors are loud."""
+    next begin does not name is dropped; the state errors are loud.  Once with pageable captures, once with page-locked ones."""
     from agile_grasp_amd import binding, synthetic
 
     w, rho = svm_model
@@ -257,6 +258,13 @@ def test_localize_begin_stage_end_equals_the_one_call(svm_model):
     assert e.value.code == binding.AGH_ERR_STATE
     order = [0, 1, 2, 1, 0, 2, 2]
     clouds = [np.ascontiguousarray(raws[k].xyz) for k in order]  # (one array object per capture: staged captures are named by it)
+    if pinned:
+        # page-locked captures: agh_localize_stage's copy is then truly asynchronous -- it is still running when the call returns,
+        # and only the event the adopting begin makes the chain wait for orders it in front of the voxeliser
+        import torch
+
+        keep_alive = [torch.from_numpy(c.copy()).pin_memory() for c in clouds]
+        clouds = [t.numpy() for t in keep_alive]
     kw = [dict(n_samples=500, sample_seed=11 + i, classify=True, min_inliers=2) for i in range(len(order))]
     got = []
     two.localize_begin(clouds[0], raws[order[0]].size_left, raws[order[0]].workspace, **kw[0])
