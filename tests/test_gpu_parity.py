@@ -605,3 +605,26 @@ def test_non_finite_points_bit_exact(scene_name):
     nothing = np.full((64, 3), np.nan, np.float32)
     ctx.set_cloud(nothing, np.zeros(64, np.int32))
     assert len(ctx.find_hands(np.arange(8, dtype=np.int32))) == 0
+
+
+def test_big_class_list_walk_with_several_samples_per_work_group():
+    """The 4096 class of the Taubin stage runs as 512 work-groups that walk the list of the samples the 1152 class handed on
+    (round 6).  3000 samples of the over-dense `small` scene put ~1500 samples on that list: every work-group takes three of them
+    in turn (the tiles are reused from one sample to the next).  Frames and hypotheses against the oracle, bit for bit."""
+    from agile_grasp_amd import synthetic
+    from oracle import oracle_py as O
+
+    sc = synthetic.config("small")
+    samples = np.sort(np.random.default_rng(3).permutation(sc.n)[:3000]).astype(np.int32)
+    ctx = _ctx(sc)
+    ctx.set_cloud(sc.xyz, sc.cam)
+    hyps = ctx.find_hands(samples)
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, samples)
+    n_nb = ref["frames"]["n_nb"]
+    assert (n_nb > 1152).sum() > 1024 and n_nb.max() <= 4096
+    assert_frames_equal(ctx.frames(), ref["frames"])
+    assert_hyps_equal(hyps, ref["hyps"])
+    # ... and through the all-points pass (batches of 16 384 points at r = 0.01: the same kernels' other classes)
+    hyps = ctx.find_hands(samples[:400], calculates_antipodal=True)
+    ref = O.find_hands(O.default_params(sc.cam_origins), sc.xyz, sc.cam, samples[:400], calculates_antipodal=True)
+    assert_hyps_equal(hyps, ref["hyps"])
