@@ -47,7 +47,7 @@ import torch  # noqa: E402
 
 from bench_extras import (HBM_ACHIEVABLE_GBS, HBM_PEAK_GBS, batched_throughput, c5_batch_sharded_secondary,  # noqa: E402
                           cloud_per_gpu_secondary, host_api_c_extra, host_api_extra, pipeline_extra, sample_sharded_secondary, settle,
-                          single_cloud_extra, sq_issue_figures, static_traffic, taubin_stage_rooflines, timed_intervals)
+                          single_cloud_extra, sq_issue_figures, static_traffic, taubin_stage_rooflines, timed_intervals, two_streams_extra)
 
 
 def cpu_baseline(sc, n_sub: int, normals_mode: int, classify: bool, svm):
@@ -522,6 +522,8 @@ def main():
                                                    "C2, the reference's production mode: 50 x rand() % n normals per sample")
                 res["untilted_rand50"] = single_cloud_extra(args, dev, stream, "C2u", binding.NORMALS_RAND50,
                                                             "C2u (axis-aligned) in the reference's production mode")
+            res["two_streams"] = two_streams_extra(args, dev, "C2", normals_mode)
+            res["three_streams"] = two_streams_extra(args, dev, "C2", normals_mode, n_lanes=3)
             res["host_api"] = host_api_extra(args, dev, sc, normals_mode)
             res["host_api_c"] = host_api_c_extra(sc, max(20, args.steps))
             res["pipeline"] = pipeline_extra(max(20, args.steps))

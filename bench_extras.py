@@ -214,6 +214,48 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
     return res
 
 
+def two_streams_extra(args, dev, scene_name, normals_mode, n_lanes: int = 2):
+    """The same C2 step on TWO (n_lanes) contexts and as many HIP streams, taking turns: cloud k's chain (grid build ... compaction) on
+    one stream while cloud k + 1's runs on the other -- each chain is 2.6 rounds of work-groups per kernel, and the other stream's kernels fill
+    the rounds that are not full.  The throughput of a stream of clouds WITHOUT batching them into one launch set (the `batched` key
+    is the upper end of that); never the headline: the headline's steps run one after the other on one stream."""
+    from agile_grasp_amd import binding, synthetic
+
+    sc = synthetic.config(scene_name)
+    xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
+    s_t = torch.from_numpy(sc.samples).to(dev)
+    S = sc.samples.size
+    lanes = []
+    for _ in range(n_lanes):
+        ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+        st = torch.cuda.Stream(device=dev)
+        lanes.append((ctx, st, torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
+    k = [0]
+
+    def step():
+        ctx, st, out_t, nout_t = lanes[k[0] % n_lanes]
+        k[0] += 1
+        ctx.set_cloud_torch(xyz_t, cam_t, stream=st.cuda_stream)
+        ctx.find_hands_torch(s_t, out_t, nout_t, stream=st.cuda_stream)
+
+    for ctx, st, _, _ in lanes:
+        for _ in range(n_lanes):  # (settle runs two steps: every context gets its own)
+            settle(ctx, step, torch.cuda.synchronize)
+    spin(step, torch.cuda.synchronize, min(args.spin_seconds, 0.2))
+    steps = max(10, args.steps)
+    steps += (-steps) % n_lanes
+    spread = timed_intervals(step, torch.cuda.synchronize, steps, 5)
+    dt = spread["median_ms"] * 1e-3
+    n = [int(l[3].item()) for l in lanes]
+    for ctx, _, _, _ in lanes:
+        ctx.synchronize()
+        ctx.close()
+    assert len(set(n)) == 1
+    return {"workload": f"{scene_name}: the headline's step on {n_lanes} contexts and {n_lanes} streams, taking turns (cloud k + 1's chain runs "
+                        "beside cloud k's)", "contexts": n_lanes, "hypotheses": n[0], "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_spread": spread,
+            "value": n[0] / dt, "unit": "hypotheses/s"}
+
+
 def host_api_extra(args, dev, sc, normals_mode):
     """What a caller of the HOST-buffer entry points pays (agh_set_cloud + agh_find_hands: the C++ adapter's
     HandSearch::findHands, hand_search.h:101-104 takes a host cloud): upload of the cloud, grid build, search, the list written
