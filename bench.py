@@ -32,6 +32,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -313,11 +314,14 @@ def main():
             step()
         fence()
         ctx.timing()  # drop the warm-up kernel times
+        gc.collect()
+        gc.disable()  # (the timed region is 20 steps = 4 ms: a collector pause is a measurable fraction of it)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dt = time.perf_counter() - t0
+        gc.enable()
         if not distributed:
             break
         if lib_comm:
