@@ -309,13 +309,16 @@ def main():
                 step()
             torch.cuda.synchronize()
     fence()
+    gc.collect()
     while True:
         for _ in range(args.warmup):
             step()
         fence()
         ctx.timing()  # drop the warm-up kernel times
-        gc.collect()
-        gc.disable()  # (the timed region is 20 steps = 4 ms: a collector pause is a measurable fraction of it)
+        # (the timed region is 20 steps = 4 ms: a collector pause is a measurable fraction of it.  No gc.collect() HERE: tens of
+        # milliseconds of host work between the warm-up and the timed steps let the GPU's clocks fall -- the interval then read
+        # 0.215 ms with the five that followed falling back to 0.199)
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
