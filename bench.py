@@ -293,6 +293,7 @@ def main():
         torch.cuda.synchronize()
 
     settle(ctx, step, fence)
+    gc.collect()  # (here, before the clock spin -- see the timed region)
     # Clocks: a cold GPU runs the first milliseconds below its sustained clock and these kernels are issue bound, so the
     # same step runs untimed for a moment first (the W warm-up steps and the K timed steps follow unchanged).
     if distributed:
@@ -309,15 +310,14 @@ def main():
                 step()
             torch.cuda.synchronize()
     fence()
-    gc.collect()
     while True:
         for _ in range(args.warmup):
             step()
         fence()
         ctx.timing()  # drop the warm-up kernel times
-        # (the timed region is 20 steps = 4 ms: a collector pause is a measurable fraction of it.  No gc.collect() HERE: tens of
-        # milliseconds of host work between the warm-up and the timed steps let the GPU's clocks fall -- the interval then read
-        # 0.215 ms with the five that followed falling back to 0.199)
+        # (the timed region is 20 steps = 4 ms: a collector pause is a measurable fraction of it.  No gc.collect() anywhere between
+        # the clock spin and the timed steps: tens of milliseconds of host work let the GPU's clocks fall -- with one in front of
+        # the timed steps the interval read 0.215 ms, with one in front of the warm-up steps 0.206, the intervals after it 0.199)
         gc.disable()
         t0 = time.perf_counter()
         for _ in range(args.steps):
