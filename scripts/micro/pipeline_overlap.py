@@ -48,11 +48,34 @@ def main(n_caps=40):
             t0 = t1
         return t, r
 
+    # two contexts taking turns: capture k + 1 begins (upload and all) on the other context before capture k is collected -- the two
+    # chains' kernels run side by side (bench.py's `two_streams`, for the online chain); no staging needed
+    ctx2 = binding.Context(rc.cam_origins)
+    ctx2.load_svm(z["w"], float(z["rho"]))
+    ctx2.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    lanes = [ctx, ctx2]
+
+    def two_contexts():
+        t = []
+        lanes[0].localize_begin(caps[0], rc.size_left, rc.workspace, **kw)
+        t0 = time.perf_counter()
+        for i in range(n_caps):
+            if i + 1 < n_caps:
+                lanes[(i + 1) & 1].localize_begin(caps[(i + 1) % 4], rc.size_left, rc.workspace, **kw)
+            r = lanes[i & 1].localize_end()
+            t1 = time.perf_counter()
+            t.append(t1 - t0)
+            t0 = t1
+        return t, r
+
     for _ in range(2):
         serial()
         overlapped()
+        two_contexts()
     ts, rs = serial()
     to, ro = overlapped()
+    t2, r2 = two_contexts()
+    assert r2["n_hypotheses"] == rs["n_hypotheses"] and np.array_equal(r2["inlier_idx"], rs["inlier_idx"])
     assert rs["n_hypotheses"] == ro["n_hypotheses"] and np.array_equal(rs["inlier_idx"], ro["inlier_idx"])
     for f in ("axis", "center", "width"):
         assert np.array_equal(rs["handles"][f], ro["handles"][f]), f
@@ -64,7 +87,7 @@ def main(n_caps=40):
     print(json.dumps({"workload": "stream of raw two-view captures, 699999 points each -> 3 mm voxels -> 2000-sample search -> HOG + SVM -> "
                                   "handle search, host buffers in and out", "captures": n_caps, "hypotheses": int(rs["n_hypotheses"]),
                       "handles": int(len(rs["handles"])), "agh_localize_per_capture": st(ts),
-                      "begin_stage_end_per_capture": st(to),
+                      "begin_stage_end_per_capture": st(to), "two_contexts_taking_turns_per_capture": st(t2),
                       "note": "steady state of a caller that stages capture k + 1 (agh_localize_stage) between agh_localize_begin and "
                               "agh_localize_end of capture k; results equal agh_localize's bit for bit"}))
 
