@@ -432,6 +432,30 @@ def pipeline_extra(steps: int):
     stream(4)
     ts = stream(steps + 2)[1:-1]  # (the first capture of a stream has nothing to hide behind, the last one stages nothing)
     assert ts[-1][1:] == t1[-1][1:], (ts[-1], t1[-1])
+    # ... and with TWO contexts taking turns: capture k + 1 begins (upload and all) on the other context before capture k is
+    # collected, so the two chains' kernels run side by side (the `two_streams` key, for the online chain)
+    ctx2 = binding.Context(rc.cam_origins)
+    ctx2.load_svm(z["w"], float(z["rho"]))
+    ctx2.preprocess(rc.xyz, rc.size_left, rc.workspace)
+    lanes = [ctx, ctx2]
+
+    def turns(n):
+        t = []
+        lanes[0].localize_begin(caps[0], rc.size_left, rc.workspace, **kw)
+        t0 = time.perf_counter()
+        for i in range(n):
+            if i + 1 < n:
+                lanes[(i + 1) & 1].localize_begin(caps[(i + 1) % 3], rc.size_left, rc.workspace, **kw)
+            r = lanes[i & 1].localize_end()
+            t1_ = time.perf_counter()
+            t.append((t1_ - t0, r["n_hypotheses"], len(r["hands"]), len(r["handles"])))
+            t0 = t1_
+        return t
+
+    turns(4)
+    tt = turns(steps + 2)[1:-1]
+    assert tt[-1][1:] == t1[-1][1:], (tt[-1], t1[-1])
+    ctx2.close()
     return {"workload": "raw two-view capture, 699999 points -> 3 mm voxels -> 2000-sample search -> HOG + SVM -> handle search "
                         "(grasp_localizer.cpp:95-103), host buffers in and out",
             "voxels": int(nv), "hypotheses": int(t1[-1][1]), "svm_kept": int(t1[-1][2]), "handles": int(t1[-1][3]),
@@ -441,6 +465,10 @@ def pipeline_extra(steps: int):
             "agh_localize_device_ms": statistics.median(t[0] for t in td) * 1e3, "calls": steps,
             "begin_stage_end_ms": statistics.median(t[0] for t in ts) * 1e3, "begin_stage_end_min_ms": min(t[0] for t in ts) * 1e3,
             "begin_stage_end_max_ms": max(t[0] for t in ts) * 1e3,
+            "two_contexts_ms": statistics.median(t[0] for t in tt) * 1e3, "two_contexts_min_ms": min(t[0] for t in tt) * 1e3,
+            "two_contexts_max_ms": max(t[0] for t in tt) * 1e3,
+            "two_contexts_note": "per capture of a stream, two contexts taking turns: agh_localize_begin(k + 1) on the other context before "
+                                 "agh_localize_end(k) -- the two chains' kernels side by side; same results",
             "begin_stage_end_note": "per capture of a stream, steady state: agh_localize_begin(k) / agh_localize_stage(k + 1) / "
                                     "agh_localize_end(k) -- capture k + 1 goes up under capture k's kernels; same results"}
 
