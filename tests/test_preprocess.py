@@ -293,3 +293,37 @@ def test_localize_begin_stage_end_equals_the_one_call(svm_model, pinned):
     assert n_handles > 0
     # the context is an ordinary one afterwards
     assert two.cloud()[0].shape[0] == got[-1]["n_voxels"]
+
+
+@pytest.mark.gpu
+def test_two_contexts_taking_turns_equal_the_one_call(svm_model):
+    """Two chains in flight: capture k + 1 begins on the other context before capture k is collected (the two chains' kernels run
+    side by side on the GPU; the contexts share nothing).  Every capture's result equals agh_localize's."""
+    from agile_grasp_amd import binding, synthetic
+
+    w, rho = svm_model
+    raws = [synthetic.make_raw_cloud(120_000, 7, n_objects=4), synthetic.make_raw_cloud(60_000, 8, n_objects=2),
+            synthetic.make_raw_cloud(200_000, 9, n_objects=6)]
+    one = binding.Context(raws[0].cam_origins)
+    lanes = [binding.Context(raws[0].cam_origins), binding.Context(raws[0].cam_origins)]
+    for c in [one] + lanes:
+        c.load_svm(w, rho)
+    order = [0, 1, 2, 2, 1, 0, 1]
+    clouds = [np.ascontiguousarray(raws[k].xyz) for k in order]
+    kw = [dict(n_samples=400, sample_seed=21 + i, classify=True, min_inliers=2) for i in range(len(order))]
+    got = []
+    lanes[0].localize_begin(clouds[0], raws[order[0]].size_left, raws[order[0]].workspace, **kw[0])
+    for i in range(len(order)):
+        if i + 1 < len(order):
+            rc = raws[order[i + 1]]
+            lanes[(i + 1) & 1].localize_begin(clouds[i + 1], rc.size_left, rc.workspace, **kw[i + 1])
+        got.append(lanes[i & 1].localize_end())
+    for i, k in enumerate(order):
+        ref = one.localize(raws[k].xyz, raws[k].size_left, raws[k].workspace, **kw[i])
+        g = got[i]
+        assert g["n_voxels"] == ref["n_voxels"] and g["n_hypotheses"] == ref["n_hypotheses"] > 0
+        assert np.array_equal(g["samples"], ref["samples"]) and np.array_equal(g["inlier_idx"], ref["inlier_idx"])
+        for f in HYP_FIELDS:
+            assert np.array_equal(g["hands"][f], ref["hands"][f]), f
+        for f in HANDLE_FIELDS:
+            assert np.array_equal(g["handles"][f], ref["handles"][f]), f
