@@ -214,6 +214,32 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
     return res
 
 
+def side_by_side(contexts, launch, collect, make_ctx, tries: int = 6):
+    """Contexts whose chains really run side by side.  HIP maps a process's streams onto a handful of hardware queues in turn, and two
+    streams that land on the SAME queue run one after the other -- in a process that has created many streams (this one) that is a
+    coin toss per pair.  So: time the last context's chain in flight TOGETHER with the first one's against the two one after the
+    other, and while that shows no overlap replace the last context by a new one (whose stream is the next queue's).  `launch(ctx)`
+    queues a chain without waiting, `collect(ctx)` waits for it."""
+    def both(overlapped):
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            if overlapped:
+                launch(contexts[0]); launch(contexts[-1]); collect(contexts[0]); collect(contexts[-1])
+            else:
+                launch(contexts[0]); collect(contexts[0]); launch(contexts[-1]); collect(contexts[-1])
+            t.append(time.perf_counter() - t0)
+        return statistics.median(t)
+
+    for _ in range(tries):
+        both(True)
+        if both(True) < 0.85 * both(False):
+            return True
+        contexts[-1].close()
+        contexts[-1] = make_ctx()
+    return False
+
+
 def two_streams_extra(args, dev, scene_name, normals_mode, n_lanes: int = 2):
     """The same C2 step on TWO (n_lanes) contexts and as many HIP streams, taking turns: cloud k's chain (grid build ... compaction) on
     one stream while cloud k + 1's runs on the other -- each chain is 2.6 rounds of work-groups per kernel, and the other stream's kernels fill
@@ -225,18 +251,37 @@ def two_streams_extra(args, dev, scene_name, normals_mode, n_lanes: int = 2):
     xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
     s_t = torch.from_numpy(sc.samples).to(dev)
     S = sc.samples.size
-    lanes = []
+    torch.cuda.synchronize()  # (the contexts launch on their own streams: the tensors above must be there)
+
+    def make_ctx():
+        return binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+
+    bufs = [(torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)) for _ in range(n_lanes)]
+    ctxs, all_side_by_side = [], True
+
+    def launch(c):  # (on the context's OWN stream)
+        c.set_cloud_torch(xyz_t, cam_t)
+        c.find_hands_torch(s_t, bufs[0][0] if c is ctxs[0] else bufs[-1][0], bufs[0][1] if c is ctxs[0] else bufs[-1][1])
+
+    def collect(c):
+        try:
+            c.synchronize()
+        except binding.AghError as e:
+            if e.code != binding.AGH_ERR_RETRY:
+                raise
+
     for _ in range(n_lanes):
-        ctx = binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
-        st = torch.cuda.Stream(device=dev)
-        lanes.append((ctx, st, torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
+        ctxs.append(make_ctx())
+        if len(ctxs) > 1:
+            all_side_by_side = side_by_side(ctxs, launch, collect, make_ctx) and all_side_by_side
+    lanes = [(c, None, bufs[i][0], bufs[i][1]) for i, c in enumerate(ctxs)]
     k = [0]
 
     def step():
         ctx, st, out_t, nout_t = lanes[k[0] % n_lanes]
         k[0] += 1
-        ctx.set_cloud_torch(xyz_t, cam_t, stream=st.cuda_stream)
-        ctx.find_hands_torch(s_t, out_t, nout_t, stream=st.cuda_stream)
+        ctx.set_cloud_torch(xyz_t, cam_t)  # (each context on its own stream)
+        ctx.find_hands_torch(s_t, out_t, nout_t)
 
     for ctx, st, _, _ in lanes:
         for _ in range(n_lanes):  # (settle runs two steps: every context gets its own)
@@ -252,7 +297,7 @@ def two_streams_extra(args, dev, scene_name, normals_mode, n_lanes: int = 2):
         ctx.close()
     assert len(set(n)) == 1
     return {"workload": f"{scene_name}: the headline's step on {n_lanes} contexts and {n_lanes} streams, taking turns (cloud k + 1's chain runs "
-                        "beside cloud k's)", "contexts": n_lanes, "hypotheses": n[0], "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_spread": spread,
+                        "beside cloud k's)", "contexts": n_lanes, "side_by_side": all_side_by_side, "hypotheses": n[0], "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_spread": spread,
             "value": n[0] / dt, "unit": "hypotheses/s"}
 
 
@@ -434,10 +479,17 @@ def pipeline_extra(steps: int):
     assert ts[-1][1:] == t1[-1][1:], (ts[-1], t1[-1])
     # ... and with TWO contexts taking turns: capture k + 1 begins (upload and all) on the other context before capture k is
     # collected, so the two chains' kernels run side by side (the `two_streams` key, for the online chain)
-    ctx2 = binding.Context(rc.cam_origins)
-    ctx2.load_svm(z["w"], float(z["rho"]))
-    ctx2.preprocess(rc.xyz, rc.size_left, rc.workspace)
-    lanes = [ctx, ctx2]
+    def make_ctx():
+        c2 = binding.Context(rc.cam_origins)
+        c2.load_svm(z["w"], float(z["rho"]))
+        c2.preprocess(rc.xyz, rc.size_left, rc.workspace)
+        return c2
+
+    lanes = [ctx, make_ctx()]
+    # (two streams of this process may share a hardware queue: side_by_side() replaces the second context until they do not)
+    overlap = side_by_side(lanes, lambda c: c.localize_begin(caps[0] if c is lanes[0] else caps[1], rc.size_left, rc.workspace, **kw),
+                           lambda c: c.localize_end(), make_ctx)
+    ctx2 = lanes[1]
 
     def turns(n):
         t = []
@@ -466,7 +518,7 @@ def pipeline_extra(steps: int):
             "begin_stage_end_ms": statistics.median(t[0] for t in ts) * 1e3, "begin_stage_end_min_ms": min(t[0] for t in ts) * 1e3,
             "begin_stage_end_max_ms": max(t[0] for t in ts) * 1e3,
             "two_contexts_ms": statistics.median(t[0] for t in tt) * 1e3, "two_contexts_min_ms": min(t[0] for t in tt) * 1e3,
-            "two_contexts_max_ms": max(t[0] for t in tt) * 1e3,
+            "two_contexts_max_ms": max(t[0] for t in tt) * 1e3, "two_contexts_side_by_side": overlap,
             "two_contexts_note": "per capture of a stream, two contexts taking turns: agh_localize_begin(k + 1) on the other context before "
                                  "agh_localize_end(k) -- the two chains' kernels side by side; same results",
             "begin_stage_end_note": "per capture of a stream, steady state: agh_localize_begin(k) / agh_localize_stage(k + 1) / "
