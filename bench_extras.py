@@ -214,7 +214,7 @@ def single_cloud_extra(args, dev, stream, scene_name, normals_mode, label, svm=N
     return res
 
 
-def side_by_side(contexts, launch, collect, make_ctx, tries: int = 6):
+def side_by_side(contexts, launch, collect, make_ctx, tries: int = 6, close=lambda lane: lane.close()):
     """Contexts whose chains really run side by side.  HIP maps a process's streams onto a handful of hardware queues in turn, and two
     streams that land on the SAME queue run one after the other -- in a process that has created many streams (this one) that is a
     coin toss per pair.  So: time the last context's chain in flight TOGETHER with the first one's against the two one after the
@@ -235,7 +235,7 @@ def side_by_side(contexts, launch, collect, make_ctx, tries: int = 6):
         both(True)
         if both(True) < 0.85 * both(False):
             return True
-        contexts[-1].close()
+        close(contexts[-1])
         contexts[-1] = make_ctx()
     return False
 
@@ -251,37 +251,32 @@ def two_streams_extra(args, dev, scene_name, normals_mode, n_lanes: int = 2):
     xyz_t, cam_t = torch.from_numpy(sc.xyz).to(dev), torch.from_numpy(sc.cam).to(dev)
     s_t = torch.from_numpy(sc.samples).to(dev)
     S = sc.samples.size
-    torch.cuda.synchronize()  # (the contexts launch on their own streams: the tensors above must be there)
+    torch.cuda.synchronize()  # (the lanes launch on streams of their own: the tensors above must be there)
 
-    def make_ctx():
-        return binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0)
+    # a lane: a context, a (non-blocking) HIP stream, its output buffers.  (On the contexts' OWN streams -- hipStreamCreate's
+    # blocking kind -- two such chains did not overlap at all: 0.195 ms per step; the online chain's do, see pipeline_extra.)
+    def make_lane():
+        return (binding.Context(sc.cam_origins, normals_mode=normals_mode, device=dev.index, profile=0), torch.cuda.Stream(device=dev),
+                torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
 
-    bufs = [(torch.zeros(8 * S * 160, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)) for _ in range(n_lanes)]
-    ctxs, all_side_by_side = [], True
+    def launch(lane):
+        lane[0].set_cloud_torch(xyz_t, cam_t, stream=lane[1].cuda_stream)
+        lane[0].find_hands_torch(s_t, lane[2], lane[3], stream=lane[1].cuda_stream)
 
-    def launch(c):  # (on the context's OWN stream)
-        c.set_cloud_torch(xyz_t, cam_t)
-        c.find_hands_torch(s_t, bufs[0][0] if c is ctxs[0] else bufs[-1][0], bufs[0][1] if c is ctxs[0] else bufs[-1][1])
-
-    def collect(c):
-        try:
-            c.synchronize()
-        except binding.AghError as e:
-            if e.code != binding.AGH_ERR_RETRY:
-                raise
-
+    lanes, all_side_by_side = [], True
     for _ in range(n_lanes):
-        ctxs.append(make_ctx())
-        if len(ctxs) > 1:
-            all_side_by_side = side_by_side(ctxs, launch, collect, make_ctx) and all_side_by_side
-    lanes = [(c, None, bufs[i][0], bufs[i][1]) for i, c in enumerate(ctxs)]
+        lanes.append(make_lane())
+        torch.cuda.synchronize()
+        if len(lanes) > 1:
+            all_side_by_side = side_by_side(lanes, launch, lambda lane: lane[1].synchronize(), make_lane,
+                                            close=lambda lane: lane[0].close()) and all_side_by_side
     k = [0]
 
     def step():
         ctx, st, out_t, nout_t = lanes[k[0] % n_lanes]
         k[0] += 1
-        ctx.set_cloud_torch(xyz_t, cam_t)  # (each context on its own stream)
-        ctx.find_hands_torch(s_t, out_t, nout_t)
+        ctx.set_cloud_torch(xyz_t, cam_t, stream=st.cuda_stream)
+        ctx.find_hands_torch(s_t, out_t, nout_t, stream=st.cuda_stream)
 
     for ctx, st, _, _ in lanes:
         for _ in range(n_lanes):  # (settle runs two steps: every context gets its own)
