@@ -474,11 +474,7 @@ int agh_create(const agh_params* p, agh_ctx** out)
     agh_destroy(ctx);
     return rc;
   };
-#ifdef AGH_CTX_STREAM_NONBLOCKING  // experiment (scripts/micro/two_threads_host_api.py): see profiles/NOTES.md "which streams overlap"
-  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
-#else
   if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess)
-#endif
   {
     c->err = "hipSetDevice/hipStreamCreate failed";
     return fail(AGH_ERR_HIP);
